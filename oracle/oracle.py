@@ -1,0 +1,385 @@
+"""CPU oracle for the GCN aggregation hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module, and only as the checker / the reported CPU
+baseline.  The product package never imports it; the product path fails loudly
+when its HIP library is missing instead of falling back to anything in here.
+
+Two layers:
+
+* ``lib()``            -- ctypes binding of ``oracle/pgcn_oracle.c`` (plain C
+                          restatement of ``Parallel-GCN/main.c:GCN()`` and of the
+                          aggregation operator; fp32 storage + accumulation).
+* numpy functions      -- independent restatements used to cross-check the C
+                          code (float64 "shadow" arithmetic), the host-side
+                          helpers of ``GPU/PGCN.py`` (communication maps, the
+                          ``run()`` training loop with ReLU / log_softmax /
+                          nll_loss / Adam), and ``preprocess/GrB-GNN-IDG.py``'s
+                          normalisation.
+
+Every function cites the reference file:line it follows (paths relative to
+``/root/reference``).  Parity pinning is described in ``pgcn_oracle.c``'s
+header: the aggregation operator and the PGCN.py training loop are pinned by
+golden vectors generated from the reference's own ``GPU/PGCN.py``
+(``tests/golden/make_golden.py``); the GraphBLAS/MPI training loop of
+``Parallel-GCN/main.c`` is UNPINNED against a reference binary (GraphBLAS is
+absent and unfetchable), and only cross-checked float32-C vs float64-numpy.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_LIB_FAST = None
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/pgcn_oracle.c with gcc (``make -C oracle``)."""
+    so = os.path.join(_HERE, "_build", "libpgcn_oracle.so")
+    src = os.path.join(_HERE, "pgcn_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return so
+
+
+def _bind(path: str):
+    L = ctypes.CDLL(path)
+    L.oracle_spmm_csr_f32.argtypes = [ctypes.c_int64, _i64p, _i32p, _f32p, _f32p, ctypes.c_int64,
+                                      _f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int]
+    L.oracle_spmm_csr_f32.restype = None
+    L.oracle_spmm_csr_rows_f32.argtypes = [ctypes.c_int64, _i32p, _i64p, _i32p, _f32p, _f32p,
+                                           ctypes.c_int64, _f32p, ctypes.c_int64, ctypes.c_int32,
+                                           ctypes.c_int]
+    L.oracle_spmm_csr_rows_f32.restype = None
+    L.oracle_gather_rows_f32.argtypes = [_f32p, ctypes.c_int64, _i32p, ctypes.c_int64, _f32p,
+                                         ctypes.c_int64, ctypes.c_int32]
+    L.oracle_gather_rows_f32.restype = None
+    L.oracle_scatter_rows_f32.argtypes = [_f32p, ctypes.c_int64, _i32p, ctypes.c_int64, _f32p,
+                                          ctypes.c_int64, ctypes.c_int32, ctypes.c_int]
+    L.oracle_scatter_rows_f32.restype = None
+    L.oracle_dist_aggregate_f32.argtypes = [ctypes.c_int64, _i64p, _i32p, _f32p, _i32p,
+                                            ctypes.c_int32, _f32p, ctypes.c_int64, _f32p,
+                                            ctypes.c_int64, ctypes.c_int32]
+    L.oracle_dist_aggregate_f32.restype = None
+    L.oracle_pargcn_train.argtypes = [ctypes.c_int64, _i64p, _i32p, _f32p, _i32p, ctypes.c_int32,
+                                      ctypes.c_int32, _i32p, ctypes.POINTER(_f32p), _f32p, _f32p,
+                                      _u8p, ctypes.c_int32, ctypes.c_float, _f32p, _f32p, _i64p]
+    L.oracle_pargcn_train.restype = ctypes.c_int
+    L.oracle_num_threads.restype = ctypes.c_int
+    return L
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "_build", "libpgcn_oracle.so")
+        if not os.path.exists(so):
+            so = build()
+        _LIB = _bind(so)
+    return _LIB
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+def _csr_arrays(A: sp.csr_matrix):
+    A = A.tocsr()
+    rowptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    col = np.ascontiguousarray(A.indices, dtype=np.int32)
+    val = np.ascontiguousarray(A.data, dtype=np.float32)
+    return rowptr, col, val
+
+
+# --------------------------------------------------------------------------
+# C-backed operators
+
+
+def spmm_csr(rowptr: np.ndarray, col: np.ndarray, val: np.ndarray, B: np.ndarray,
+             C: Optional[np.ndarray] = None, accumulate: bool = False) -> np.ndarray:
+    """C = A.B (or C += A.B), fp32, CSR order.  Parallel-GCN/main.c:271."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    nrows = rowptr.shape[0] - 1
+    f = B.shape[1]
+    if C is None:
+        C = np.zeros((nrows, f), dtype=np.float32)
+    assert C.dtype == np.float32 and C.flags.c_contiguous and C.shape == (nrows, f)
+    lib().oracle_spmm_csr_f32(nrows, _p(rowptr, _i64p), _p(col, _i32p), _p(val, _f32p),
+                              _p(B, _f32p), B.shape[1], _p(C, _f32p), f, f, int(accumulate))
+    return C
+
+
+def spmm(A: sp.spmatrix, B: np.ndarray) -> np.ndarray:
+    rowptr, col, val = _csr_arrays(A)
+    return spmm_csr(rowptr, col, val, B)
+
+
+def gather_rows(H: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """GPU/PGCN.py:104 ``H[indices]``."""
+    H = np.ascontiguousarray(H, dtype=np.float32)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    out = np.empty((idx.shape[0], H.shape[1]), dtype=np.float32)
+    lib().oracle_gather_rows_f32(_p(H, _f32p), H.shape[1], _p(idx, _i32p), idx.shape[0],
+                                 _p(out, _f32p), H.shape[1], H.shape[1])
+    return out
+
+
+def scatter_rows(H: np.ndarray, idx: np.ndarray, src: np.ndarray, accumulate: bool) -> None:
+    """GPU/PGCN.py:115 ``X[indices] = buf`` / accumulate form of main.c:295,400."""
+    assert H.dtype == np.float32 and H.flags.c_contiguous
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    lib().oracle_scatter_rows_f32(_p(H, _f32p), H.shape[1], _p(idx, _i32p), idx.shape[0],
+                                  _p(src, _f32p), src.shape[1], H.shape[1], int(accumulate))
+
+
+def dist_aggregate(A: sp.spmatrix, part: Sequence[int], P: int, H: np.ndarray) -> np.ndarray:
+    """AH = A.H with the local-then-per-source summation order of main.c:271,295."""
+    rowptr, col, val = _csr_arrays(A)
+    part = np.ascontiguousarray(part, dtype=np.int32)
+    H = np.ascontiguousarray(H, dtype=np.float32)
+    n, f = H.shape
+    out = np.empty((n, f), dtype=np.float32)
+    lib().oracle_dist_aggregate_f32(n, _p(rowptr, _i64p), _p(col, _i32p), _p(val, _f32p),
+                                    _p(part, _i32p), P, _p(H, _f32p), f, _p(out, _f32p), f, f)
+    return out
+
+
+def pargcn_train(A: sp.spmatrix, part: Sequence[int], P: int, d: Sequence[int],
+                 W: Dict[int, np.ndarray], H0: np.ndarray, Y: np.ndarray, Ymask: np.ndarray,
+                 epochs: int = 3, alpha: float = 0.01):
+    """Parallel-GCN/main.c:GCN() with P virtual ranks (C, fp32).
+
+    ``d`` = nneurons (d[0]=n); ``W[l]`` (l=1..L-1) is d[l] x d[l+1].  Returns
+    (err per epoch, updated W dict, output H_{L-1}, stats[P,2])."""
+    rowptr, col, val = _csr_arrays(A)
+    part = np.ascontiguousarray(part, dtype=np.int32)
+    d = np.ascontiguousarray(d, dtype=np.int32)
+    L = d.shape[0] - 1
+    n = int(d[0])
+    Wc = {l: np.array(W[l], dtype=np.float32, order="C", copy=True) for l in range(1, L)}
+    arr = (_f32p * L)()
+    for l in range(1, L):
+        arr[l] = _p(Wc[l], _f32p)
+    H0 = np.ascontiguousarray(H0, dtype=np.float32)
+    Y = np.ascontiguousarray(Y, dtype=np.float32)
+    Ymask = np.ascontiguousarray(Ymask, dtype=np.uint8)
+    err = np.zeros(epochs, dtype=np.float32)
+    Hl = np.zeros((n, int(d[L])), dtype=np.float32)
+    stats = np.zeros((P, 2), dtype=np.int64)
+    rc = lib().oracle_pargcn_train(n, _p(rowptr, _i64p), _p(col, _i32p), _p(val, _f32p),
+                                   _p(part, _i32p), P, L, _p(d, _i32p), arr, _p(H0, _f32p),
+                                   _p(Y, _f32p), _p(Ymask, _u8p), epochs, alpha,
+                                   _p(err, _f32p), _p(Hl, _f32p), _p(stats, _i64p))
+    if rc != 0:
+        raise ValueError("oracle_pargcn_train rc=%d" % rc)
+    return err, Wc, Hl, stats
+
+
+# --------------------------------------------------------------------------
+# numpy restatements (independent of the C code)
+
+
+def normalize_adjacency(A: sp.spmatrix) -> sp.csr_matrix:
+    """preprocess/GrB-GNN-IDG.py:45-68: A_hat = Dr^-1/2 (A - diag + I) Dc^-1/2."""
+    A = sp.coo_matrix(A, dtype=np.float64)
+    keep = A.row != A.col  # :47-50 zero the diagonal then eliminate
+    A = sp.coo_matrix((A.data[keep], (A.row[keep], A.col[keep])), shape=A.shape).tocsr()
+    n = A.shape[0]
+    A = A + sp.identity(n, format="csr")  # :53-54
+    col_sum = 1.0 / np.sqrt(np.asarray(A.sum(axis=0)).reshape(-1))  # :56-59
+    row_sum = 1.0 / np.sqrt(np.asarray(A.sum(axis=1)).reshape(-1))  # :63-66
+    A = sp.diags(row_sum) @ A @ sp.diags(col_sum)  # :70
+    A = A.tocsr()
+    A.sort_indices()
+    return A.astype(np.float32)
+
+
+def communication_maps(A: sp.spmatrix, partvec: Sequence[int], rank: int, size: int
+                       ) -> Tuple[Dict[int, np.ndarray], Dict[int, np.ndarray]]:
+    """GPU/PGCN.py:37-51 compute_communication_maps, vectorised.
+
+    recv_map[q] = sorted unique columns owned by q that appear in my rows;
+    send_map[q] = sorted unique columns owned by me that appear in q's rows;
+    the own rank is popped (:49-50).  Stored explicit zeros count as entries,
+    exactly like the reference's loop over ``A.nnz``."""
+    A = sp.coo_matrix(A)
+    pv = np.asarray(partvec, dtype=np.int64)
+    pr, pc = pv[A.row], pv[A.col]
+    send_map, recv_map = {}, {}
+    for q in range(size):
+        if q == rank:
+            continue
+        recv_map[q] = np.unique(A.col[(pr == rank) & (pc == q)]).astype(np.int64)
+        send_map[q] = np.unique(A.col[(pc == rank) & (pr == q)]).astype(np.int64)
+    return send_map, recv_map
+
+
+def dist_aggregate_messages(A: sp.spmatrix, part: Sequence[int], P: int, H: np.ndarray,
+                            dtype=np.float64) -> Tuple[np.ndarray, np.ndarray]:
+    """Explicit message-passing restatement of main.c:238-299 with P rank objects.
+
+    Every rank holds only its owned rows, packs ``H[S_pq]`` for each target
+    (main.c:245-267), computes the local product (271) and accumulates one
+    product per received message (275-299).  Returns (AH, rows_sent[p, q])."""
+    A = sp.csr_matrix(A)
+    part = np.asarray(part)
+    n, f = H.shape
+    Hd = H.astype(dtype)
+    out = np.zeros((n, f), dtype=dtype)
+    rows_sent = np.zeros((P, P), dtype=np.int64)
+    owned = [np.nonzero(part == p)[0] for p in range(P)]
+    maps = [communication_maps(A, part, p, P) for p in range(P)]
+    # "network": mailbox[(src, dst)] = (global ids, rows)
+    mailbox = {}
+    for p in range(P):
+        send_map, _ = maps[p]
+        for q, ids in send_map.items():
+            if ids.size:
+                mailbox[(p, q)] = (ids, Hd[ids].copy())
+                rows_sent[p, q] = ids.size
+    for p in range(P):
+        Ap = A[owned[p]].astype(dtype)
+        # local piece: a rank's H has no rows outside its part
+        Hloc = np.zeros((n, f), dtype=dtype)
+        Hloc[owned[p]] = Hd[owned[p]]
+        acc = Ap @ Hloc
+        for q in range(P):
+            if (q, p) not in mailbox:
+                continue
+            ids, rows = mailbox[(q, p)]
+            Hcap = np.zeros((n, f), dtype=dtype)
+            Hcap[ids] = rows  # GrB_Matrix_build of the received tuples, main.c:293
+            acc = acc + Ap @ Hcap  # main.c:295
+        out[owned[p]] = acc
+    return out, rows_sent
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def pargcn_train_np(A: sp.spmatrix, d: Sequence[int], W: Dict[int, np.ndarray], H0: np.ndarray,
+                    Y: np.ndarray, Ymask: np.ndarray, epochs: int = 3, alpha: float = 0.01,
+                    dtype=np.float64):
+    """float64 shadow of Parallel-GCN/main.c:GCN() (single address space; the
+    partition only affects fp32 summation order, which float64 arbitrates)."""
+    A = sp.csr_matrix(A).astype(dtype)
+    L = len(d) - 1
+    n = d[0]
+    W = {l: np.array(W[l], dtype=dtype) for l in range(1, L)}
+    H = {0: H0.astype(dtype)}
+    Z = {}
+    errs = []
+    Ym = Ymask.astype(bool)
+    Yd = Y.astype(dtype)
+    for _ in range(epochs):
+        for l in range(1, L):  # main.c:233
+            AH = A @ H[l - 1]
+            Z[l] = AH @ W[l]  # :303
+            H[l] = _sigmoid(Z[l])  # :308
+        Pm = H[L - 1]
+        T = np.where(Ym, -1.0 * Yd * np.log(np.where(Ym, Pm, 1.0)), Pm)  # :318 (union)
+        errs.append(T.sum())  # :320
+        D = np.where(Ym, Pm - Yd, Pm) / (Pm * (1 - Pm))  # :325-328
+        s = _sigmoid(Z[L - 1])
+        G = {L - 1: D * (s * (1 - s)) / n}  # :330-335
+        for l in range(L - 1, 0, -1):  # :338
+            AG = A @ G[l]  # :376 (A, not A^T)
+            if l != 1:
+                s = _sigmoid(Z[l - 1])
+                G[l - 1] = (AG @ W[l].T) * (s * (1 - s))  # :407-410
+            dW = H[l - 1].T @ AG  # :417
+            W[l] = W[l] - alpha * dW  # :430
+    return np.array(errs), W, H[L - 1]
+
+
+# ---- GPU/PGCN.py training loop (ReLU / log_softmax / nll / Adam) ---------
+
+
+def _log_softmax(x):
+    m = x.max(axis=1, keepdims=True)
+    z = x - m
+    return z - np.log(np.exp(z).sum(axis=1, keepdims=True))
+
+
+class _Adam:
+    """torch.optim.Adam defaults (lr given, betas 0.9/0.999, eps 1e-8), PGCN.py:200."""
+
+    def __init__(self, params: List[np.ndarray], lr: float):
+        self.p, self.lr = params, lr
+        self.m = [np.zeros_like(p) for p in params]
+        self.v = [np.zeros_like(p) for p in params]
+        self.t = 0
+
+    def step(self, grads):
+        self.t += 1
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        for p, g, m, v in zip(self.p, grads, self.m, self.v):
+            m *= b1
+            m += (1 - b1) * g
+            v *= b2
+            v += (1 - b2) * g * g
+            bc1 = 1 - b1 ** self.t
+            bc2 = 1 - b2 ** self.t
+            denom = np.sqrt(v) / np.sqrt(bc2) + eps
+            p -= (self.lr / bc1) * m / denom
+
+
+def pgcn_train_np(A: sp.spmatrix, part: Sequence[int], P: int, weights: List[np.ndarray],
+                  H0: np.ndarray, labels: np.ndarray, epochs: int = 5, lr: float = 1e-3,
+                  dtype=np.float64):
+    """GPU/PGCN.py:run() 194-226 with exact aggregation (no Q1-Q3 quirks).
+
+    ``weights[l]`` is the ``nn.Linear`` weight (out x in) of layer l.  Returns
+    (rank-0 loss per epoch, final weights).  Loss semantics follow the
+    reference literally (Q4): every rank averages nll over ALL n rows of an
+    n x f logits matrix whose non-owned rows are zero (PGCN.py:213-215), the
+    per-rank gradients are summed and divided by P (:150-154)."""
+    A = sp.csr_matrix(A).astype(dtype)
+    part = np.asarray(part)
+    n, f = H0.shape
+    Ws = [np.array(w, dtype=dtype) for w in weights]
+    opt = _Adam(Ws, lr)
+    H0 = H0.astype(dtype)
+    onehot = np.zeros((n, f), dtype=dtype)
+    onehot[np.arange(n), labels] = 1
+    losses = []
+    own0 = part == 0
+    for _ in range(epochs):
+        acts, pre, agg = [H0], [], []
+        for W in Ws:  # PGCN.forward :144-148
+            AH = A @ acts[-1]
+            Zl = AH @ W.T
+            agg.append(AH)
+            pre.append(Zl)
+            acts.append(np.maximum(Zl, 0))
+        logits = acts[-1]
+        logp = _log_softmax(logits)
+        nll = -(logp * onehot).sum(axis=1)
+        # rank 0's printed loss: owned rows + (n - n_0) rows of zero logits (nll = log f)
+        losses.append((nll[own0].sum() + (n - own0.sum()) * np.log(f)) / n)
+        # sum over ranks of d(local mean over n)/dW, then / P (average_gradients)
+        g = (np.exp(logp) - onehot) / n / P
+        grads = [None] * len(Ws)
+        for l in range(len(Ws) - 1, -1, -1):
+            g = g * (pre[l] > 0)
+            grads[l] = g.T @ agg[l]
+            g = A.T @ (g @ Ws[l])  # PSpMM.backward :130-134 (A^T)
+        opt.step(grads)
+    return np.array(losses), Ws

@@ -1,0 +1,72 @@
+"""pytest configuration: marker registration + shared fixtures/helpers."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PKG_NAME = "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd"
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+
+
+def pkg(sub: str = ""):
+    """Import the product package (its directory name is not a Python identifier)."""
+    return importlib.import_module(PKG_NAME + (("." + sub) if sub else ""))
+
+
+def golden(name: str):
+    arrays = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        meta = json.load(f)
+    return arrays, meta
+
+
+def read_partvec(path: str):
+    with open(path) as f:
+        return list(map(int, f.readline().split()))
+
+
+def gpath(name: str) -> str:
+    return os.path.join(GOLDEN, name)
+
+
+SPMM_CASES = [
+    # golden name, matrix, part vector, P
+    ("ref_karate_hp3", "karate.mtx", "karate.mtx.3.hp", 3),
+    ("ref_karate_stchp3", "karate.mtx", "karate.mtx.3.stchp", 3),
+    ("ref_karate_rp2", "karate.mtx", "karate.mtx.2.rp", 2),
+    ("ref_karate_p1", "karate.mtx", "karate.mtx.1.rp", 1),
+    ("ref_gemat11_hp3", "gemat11.mtx", "gemat11.mtx.3.hp", 3),
+    ("ref_gemat11_rp3", "gemat11.mtx", "gemat11.mtx.3.rp", 3),
+    ("ref_gemat11_rp2", "gemat11.mtx", "gemat11.mtx.2.rp", 2),
+    ("ref_gemat11pA_rp2", "gemat11p.A.mtx", "gemat11.mtx.2.rp", 2),
+    ("ref_gemat11pA_hp3", "gemat11p.A.mtx", "gemat11.mtx.3.hp", 3),
+]
+TRAIN_CASES = [
+    ("ref_train_karate", "karate.mtx", "karate.mtx.1.rp"),
+    ("ref_train_karateA", "karate.A.mtx", "karate.mtx.1.rp"),
+    ("ref_train_gemat11pA", "gemat11p.A.mtx", "gemat11.mtx.1.rp"),
+]
+
+
+def golden_inputs(n: int, f: int, seed: int):
+    """The seeded H / G of tests/golden/make_golden.py:_worker."""
+    rng = np.random.default_rng(seed)
+    H = rng.random((n, f), dtype=np.float32) * 2 - 1
+    G = rng.random((n, f), dtype=np.float32) * 2 - 1
+    return H, G
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
