@@ -1,0 +1,112 @@
+/*
+ * pgcn_hip.h -- C ABI of the MI355X (gfx950) aggregation library, libpgcn_hip.so
+ *
+ * This is the drop-in boundary for the hot path of the reference's GPU engine
+ * (/root/reference/GPU/PGCN.py).  The reference has no FFI of its own: its hot
+ * path is a handful of PyTorch calls inside PSpMM / communicate_fgm.  Each entry
+ * point below replaces one of those call sites (cited per function) and is what
+ * a ctypes / cffi / pybind stub in the reference would bind.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*.
+ *   - every launch is asynchronous on the given stream; nothing synchronises,
+ *     nothing allocates device memory (work-space is passed in), so all calls
+ *     are graph-capturable and re-entrant across streams.
+ *   - return 0 on success, a negative PGCN_E* code otherwise; the HIP / RCCL
+ *     error text is kept per thread in pgcn_last_error().  Never throws.
+ *   - fp32 values, int32 column ids, int64 row pointers, row-major dense
+ *     panels with a leading dimension in ELEMENTS.
+ */
+#ifndef PGCN_HIP_H
+#define PGCN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGCN_ABI_VERSION 1
+
+#define PGCN_OK 0
+#define PGCN_EINVAL (-1)  /* bad argument (null pointer, misaligned, negative size) */
+#define PGCN_EHIP (-2)    /* a HIP runtime call / kernel launch failed              */
+#define PGCN_ERCCL (-3)   /* an RCCL call failed                                    */
+#define PGCN_ENOMEM (-4)  /* caller-provided capacity / work-space too small        */
+
+typedef void *pgcn_stream_t; /* hipStream_t */
+
+/* flags for the SpMM entry points */
+#define PGCN_SPMM_ACCUMULATE 1u  /* C += A.B instead of C = A.B                      */
+#define PGCN_SPMM_XCD_SWIZZLE 2u /* give each XCD (private L2) a contiguous row range */
+
+int pgcn_abi_version(void);
+const char *pgcn_last_error(void);
+
+/* ---- device query (plumbing for the bench / tests) ---------------------- */
+/* out[0]=#CUs, out[1]=wavefront size, out[2]=gcnArch number (950), out[3]=L2 bytes */
+int pgcn_device_info(int32_t device, int64_t out[4]);
+
+/* ---- CSR SpMM ------------------------------------------------------------
+ * C[nrows x f] (+)= A[nrows x *] . B[* x f]
+ * replaces  torch.sparse.mm(A, H)            GPU/PGCN.py:127
+ *      and  torch.sparse.mm(A.t(), grad)     GPU/PGCN.py:132 (pass the CSR of A^T)
+ *      ==   GrB_mxm(AH, PLUS_TIMES_FP32, A, H)  Parallel-GCN/main.c:271,295,376,400
+ * val may be NULL (pattern matrix, all ones).  One task per row, no work-space.
+ */
+int pgcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
+                      int64_t nrows, const float *B, int64_t ldb, float *C, int64_t ldc,
+                      int32_t f, uint32_t flags, pgcn_stream_t stream);
+
+/* Load-balanced variant driven by a plan (see pgcn_spmm_plan_host): rows longer
+ * than the plan's chunk are split into segments whose partial sums go through
+ * `partial_ws` (capacity partial_ws_elems >= nslots * f floats) and are combined in a fixed order by a second
+ * kernel -- deterministic, no atomics on C.  row_map (optional, device) maps CSR
+ * row r to output row row_map[r]: the row-subset form used for the boundary
+ * pass of the interior/boundary split and for the reverse-exchange unpack.    */
+int pgcn_spmm_csr_plan_f32(const int64_t *rowptr, const int32_t *col, const float *val,
+                           const int32_t *tasks, int64_t ntasks, const int32_t *fix,
+                           int64_t nfix, const int32_t *row_map, const float *B,
+                           int64_t ldb, float *C, int64_t ldc, int32_t f,
+                           float *partial_ws, int64_t partial_ws_elems, int64_t nslots,
+                           uint32_t flags, pgcn_stream_t stream);
+
+/* Host-side plan builder (pure CPU, no HIP).  rowptr_host: nrows+1 entries.
+ * tasks: 4 x int32 per task {row, offset within row, length, slot or -1}
+ * fix:   4 x int32 per split row {row, first slot, #segments, 0}
+ * Call with tasks == NULL to obtain the counts, then again with buffers.      */
+int pgcn_spmm_plan_host(const int64_t *rowptr_host, int64_t nrows, int32_t chunk,
+                        int32_t *tasks, int64_t cap_tasks, int32_t *fix, int64_t cap_fix,
+                        int64_t *ntasks, int64_t *nfix, int64_t *nslots);
+
+/* ---- boundary-row pack / unpack -------------------------------------------
+ * out[r,:] = H[idx[r],:]                      replaces H[indices]   GPU/PGCN.py:104
+ * H[idx[r],:] (+)= in[r,:]                    replaces X[indices] = buf   :115
+ *                                             (accumulate: main.c:295,400 semantics)
+ * idx entries must be unique within one call when accumulate != 0.            */
+int pgcn_gather_rows_f32(const float *H, int64_t ldh, const int32_t *idx, int64_t nidx,
+                         float *out, int64_t ldo, int32_t f, pgcn_stream_t stream);
+int pgcn_scatter_rows_f32(float *H, int64_t ldh, const int32_t *idx, int64_t nidx,
+                          const float *in, int64_t ldi, int32_t f, int32_t accumulate,
+                          pgcn_stream_t stream);
+
+/* ---- boundary-row exchange over RCCL (xGMI) --------------------------------
+ * One all-to-all-v: ncclGroupStart; ncclSend/ncclRecv per peer; ncclGroupEnd.
+ * replaces the 2.(P-1) blocking dist.send / dist.recv of GPU/PGCN.py:99-115
+ *      ==  the MPI_Isend / MPI_Irecv / MPI_Waitany loop of main.c:238-299.
+ * send_off / recv_off: HOST arrays of nranks+1 row offsets into the slabs
+ * (rows of `f` floats); the own-rank segment must be empty.                   */
+int pgcn_comm_unique_id(void *id128); /* writes 128 bytes (ncclUniqueId) */
+int pgcn_comm_init(void **comm, const void *id128, int32_t nranks, int32_t rank);
+int pgcn_comm_destroy(void *comm);
+int pgcn_exchange_alltoallv_f32(void *comm, const float *send, const int64_t *send_off,
+                                float *recv, const int64_t *recv_off, int32_t f,
+                                pgcn_stream_t stream);
+/* sum-all-reduce of a flat fp32 buffer (all layers' weight gradients fused in one
+ * call): replaces the L x dist.all_reduce of GPU/PGCN.py:150-154, main.c:425.  */
+int pgcn_allreduce_sum_f32(void *comm, float *buf, int64_t count, pgcn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGCN_HIP_H */

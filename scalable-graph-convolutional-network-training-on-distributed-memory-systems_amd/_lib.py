@@ -1,0 +1,89 @@
+"""ctypes binding of libpgcn_hip.so (the C ABI declared in include/pgcn_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or does not
+export a symbol the header declares, importing / calling raises.  The library is
+built in-tree by ``csrc/build.sh`` (``__graft_entry__.build()``), never JIT-cached
+outside the repository.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+# torch must map its own libamdhip64.so.7 / librccl.so.1 first: libpgcn_hip.so links
+# to the same SONAMEs and then shares torch's HIP runtime (streams, allocations).
+import torch  # noqa: F401  (import for its side effect on the loader)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpgcn_hip.so")
+
+PGCN_OK = 0
+SPMM_ACCUMULATE = 1
+SPMM_XCD_SWIZZLE = 2
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_u32 = ctypes.c_uint32
+
+# name -> (restype, argtypes); must list EVERY symbol of include/pgcn_hip.h
+SIGNATURES = {
+    "pgcn_abi_version": (ctypes.c_int, []),
+    "pgcn_last_error": (ctypes.c_char_p, []),
+    "pgcn_device_info": (ctypes.c_int, [_i32, ctypes.POINTER(_i64)]),
+    "pgcn_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _u32, _vp]),
+    "pgcn_spmm_csr_plan_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp,
+                                              _i64, _i32, _vp, _i64, _i64, _u32, _vp]),
+    "pgcn_spmm_plan_host": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i64,
+                                           ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                                           ctypes.POINTER(_i64)]),
+    "pgcn_gather_rows_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp]),
+    "pgcn_scatter_rows_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "pgcn_comm_unique_id": (ctypes.c_int, [_vp]),
+    "pgcn_comm_init": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i32, _i32]),
+    "pgcn_comm_destroy": (ctypes.c_int, [_vp]),
+    "pgcn_exchange_alltoallv_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "pgcn_allreduce_sum_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+}
+
+_LIB = None
+
+
+class PgcnError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh")], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout + out.stderr)
+    if out.returncode != 0:
+        raise PgcnError("building libpgcn_hip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with typed entry points.  Raises if it is not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise PgcnError(
+                "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the product path has no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if L.pgcn_abi_version() != 1:
+            raise PgcnError("libpgcn_hip.so ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != PGCN_OK:
+        msg = lib().pgcn_last_error().decode("utf-8", "replace")
+        raise PgcnError("%s failed (rc=%d): %s" % (what or "libpgcn_hip call", rc, msg))

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Builds libpgcn_hip.so for gfx950 in-tree (../lib/).  hipcc cross-compiles without a GPU.
+# The library links against libamdhip64.so.7 / librccl.so.1 by SONAME only: inside a
+# PyTorch process the loader re-uses the copies torch already mapped (same SONAMEs),
+# so torch's streams / device pointers are valid in here; stand-alone it uses /opt/rocm.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT"
+ROCM="${ROCM_PATH:-/opt/rocm}"
+HIPCC="${HIPCC:-$ROCM/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast -DNDEBUG ${PGCN_EXTRA_FLAGS:-}"
+pids=()
+for src in pgcn_spmm.hip pgcn_rows.hip; do
+  "$HIPCC" $FLAGS -c "$HERE/$src" -o "$OUT/${src%.hip}.o" &
+  pids+=($!)
+done
+"$HIPCC" $FLAGS -c "$HERE/pgcn_core.cpp" -o "$OUT/pgcn_core.o" & pids+=($!)
+"$HIPCC" $FLAGS -c "$HERE/pgcn_exchange.cpp" -o "$OUT/pgcn_exchange.o" & pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpgcn_hip.so" \
+  "$OUT/pgcn_spmm.o" "$OUT/pgcn_rows.o" "$OUT/pgcn_core.o" "$OUT/pgcn_exchange.o" \
+  -L"$ROCM/lib" -lrccl
+echo "built $OUT/libpgcn_hip.so"

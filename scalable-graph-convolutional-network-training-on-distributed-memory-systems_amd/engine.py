@@ -1,0 +1,223 @@
+"""Aggregation engine: the per-layer ``A_p . H`` with boundary-row exchange.
+
+This is the MI355X-native re-design of ``communicate_fgm`` + ``torch.sparse.mm``
+(/root/reference/GPU/PGCN.py:85-134), structured like the CPU engine's overlap
+(Parallel-GCN/main.c:238-299):
+
+    forward   pack boundary rows        (gather kernel, compute stream)
+              all-to-all-v              (RCCL, comm stream)      ||  C  = A_loc  . H      (compute stream)
+              wait                                                   C += A_halo . halo
+    backward  P = A_halo^T . G          (partials for rows owned by peers)
+              reverse all-to-all-v      (comm stream)            ||  dH = A_loc^T . G
+              wait                                                   dH[send rows] += received partials
+
+The received slab IS the halo panel: ``A_halo``'s column ids index it directly,
+so the reference's n x f scratch ``X``, the ``H + X`` add and the n x n index
+space disappear.  Unpack in backward ACCUMULATES (the reference assigns --
+quirk Q3, SURVEY 8a -- which drops partial sums for P >= 3).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .partition import Partition
+
+
+# --------------------------------------------------------------------------
+# exchangers
+
+
+class TorchDistExchanger:
+    """all-to-all-v through torch.distributed (backend 'nccl' == RCCL, or 'gloo').
+
+    With gloo and device tensors the slabs are staged through host memory; this is
+    the transport used by the CPU multi-process tests and by ``-b gloo``."""
+
+    name = "torch.distributed"
+
+    def __init__(self, rank: int, size: int, group=None):
+        self.rank, self.size, self.group = rank, size, group
+        self.backend = dist.get_backend(group)
+
+    def alltoallv(self, send: torch.Tensor, send_off: List[int], recv: torch.Tensor,
+                  recv_off: List[int], f: int) -> None:
+        in_split = [send_off[q + 1] - send_off[q] for q in range(self.size)]
+        out_split = [recv_off[q + 1] - recv_off[q] for q in range(self.size)]
+        s = send[:send_off[-1]]
+        r = recv[:recv_off[-1]]
+        if self.backend == "gloo" and s.is_cuda:
+            sh = s.cpu()
+            rh = torch.empty(r.shape, dtype=r.dtype)
+            dist.all_to_all_single(rh, sh, out_split, in_split, group=self.group)
+            r.copy_(rh)
+        else:
+            dist.all_to_all_single(r, s, out_split, in_split, group=self.group)
+
+    def allreduce_sum(self, buf: torch.Tensor) -> None:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+
+    def close(self):
+        pass
+
+
+class RcclExchanger:
+    """all-to-all-v through libpgcn_hip.so's own RCCL communicator (C ABI).
+
+    The ncclUniqueId is created on rank 0 and broadcast through the already
+    initialised torch.distributed process group (any backend)."""
+
+    name = "rccl-capi"
+
+    def __init__(self, rank: int, size: int, device: torch.device, group=None):
+        self.lib = _lib.lib()
+        self.rank, self.size, self.device = rank, size, device
+        box = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(self.lib.pgcn_comm_unique_id(buf), "pgcn_comm_unique_id")
+            box[0] = bytes(buf.raw)
+        dist.broadcast_object_list(box, src=0, group=group)
+        self._id = ctypes.create_string_buffer(box[0], 128)
+        comm = ctypes.c_void_p()
+        torch.cuda.set_device(device)
+        _lib.check(self.lib.pgcn_comm_init(ctypes.byref(comm), self._id, size, rank), "pgcn_comm_init")
+        self.comm = comm
+        self._off_t = ctypes.c_int64 * (size + 1)
+
+    def alltoallv(self, send: torch.Tensor, send_off: List[int], recv: torch.Tensor,
+                  recv_off: List[int], f: int) -> None:
+        so, ro = self._off_t(*send_off), self._off_t(*recv_off)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.pgcn_exchange_alltoallv_f32(
+            self.comm, send.data_ptr() if send.numel() else None, so,
+            recv.data_ptr() if recv.numel() else None, ro, f, stream), "pgcn_exchange_alltoallv_f32")
+
+    def allreduce_sum(self, buf: torch.Tensor) -> None:
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.pgcn_allreduce_sum_f32(self.comm, buf.data_ptr(), buf.numel(), stream),
+                   "pgcn_allreduce_sum_f32")
+
+    def close(self):
+        if self.comm:
+            self.lib.pgcn_comm_destroy(self.comm)
+            self.comm = None
+
+
+# --------------------------------------------------------------------------
+
+
+class AggregationEngine:
+    """Owns rank p's device-resident pieces and runs the aggregation forward/backward."""
+
+    def __init__(self, part: Partition, kernels, device: torch.device, exchanger=None,
+                 overlap: Optional[bool] = None):
+        self.part = part
+        self.k = kernels
+        self.device = torch.device(device)
+        self.rank, self.size = part.rank, part.size
+        self.exch = exchanger
+        if self.size > 1 and exchanger is None:
+            raise ValueError("a multi-rank partition needs an exchanger")
+        self.A_loc = kernels.prepare(part.A_loc)
+        self.A_halo = kernels.prepare(part.A_halo) if self.size > 1 else None
+        self.A_loc_T = kernels.prepare(part.A_loc_T) if part.A_loc_T is not None else None
+        self.A_halo_T = kernels.prepare(part.A_halo_T) if (self.size > 1 and part.A_halo_T is not None) else None
+        self.send_idx = part.send_idx.to(self.device)
+        self.send_off, self.recv_off = list(part.send_off), list(part.recv_off)
+        self.n_local, self.n_halo, self.n_send = part.n_local, part.n_halo, part.n_send
+        self._buf: Dict = {}
+        self.on_gpu = self.device.type == "cuda"
+        if overlap is None:
+            overlap = os.environ.get("PGCN_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap and self.on_gpu and self.size > 1)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.overlap else None
+        # PGCN.py:78-83 counters (rows and messages); host integers -> no device kernels
+        self.stats = {"send_volume": 0, "recv_volume": 0, "send_nmsg": 0, "recv_nmsg": 0}
+
+    # ------------------------------------------------------------------
+    def _slab(self, name: str, rows: int, f: int) -> torch.Tensor:
+        key = (name, f)
+        t = self._buf.get(key)
+        if t is None or t.shape[0] < rows:
+            t = torch.empty((max(rows, 1), f), dtype=torch.float32, device=self.device)
+            self._buf[key] = t
+        return t
+
+    def _exchange(self, send, send_off, recv, recv_off, f):
+        """Start the all-to-all-v (on the comm stream when overlapping); returns a waiter."""
+        self.stats["send_volume"] += send_off[-1]
+        self.stats["recv_volume"] += recv_off[-1]
+        self.stats["send_nmsg"] += self.size - 1   # PGCN.py:106 counts every peer, empty or not
+        self.stats["recv_nmsg"] += self.size - 1
+        if not self.overlap:
+            self.exch.alltoallv(send, send_off, recv, recv_off, f)
+            return lambda: None
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ready)
+            self.exch.alltoallv(send, send_off, recv, recv_off, f)
+            done.record(self.comm_stream)
+        return lambda: main.wait_event(done)
+
+    # ------------------------------------------------------------------
+    def forward(self, H: torch.Tensor) -> torch.Tensor:
+        """AH = A_p . [H ; halo]   (H: n_local x f, owned rows only)."""
+        if H.shape[0] != self.n_local:
+            raise ValueError("H must hold exactly the %d owned rows" % self.n_local)
+        H = H.contiguous()
+        f = H.shape[1]
+        C = torch.empty((self.n_local, f), dtype=torch.float32, device=self.device)
+        if self.size == 1:
+            return self.k.spmm(self.A_loc, H, C)
+        send = self._slab("send", self.n_send, f)
+        halo = self._slab("halo", self.n_halo, f)
+        self.k.gather_rows(H, self.send_idx, send)
+        wait = self._exchange(send, self.send_off, halo, self.recv_off, f)
+        self.k.spmm(self.A_loc, H, C)            # overlaps the exchange (main.c:271)
+        wait()
+        self.k.spmm(self.A_halo, halo, C, accumulate=True)   # main.c:295
+        return C
+
+    def backward(self, G: torch.Tensor) -> torch.Tensor:
+        """dH = (A^T . G)[owned rows], partial sums returned to their owners and ADDED."""
+        if self.A_loc_T is None:
+            raise RuntimeError("partition was built without the transposed pieces")
+        G = G.contiguous()
+        f = G.shape[1]
+        dH = torch.empty((self.n_local, f), dtype=torch.float32, device=self.device)
+        if self.size == 1:
+            return self.k.spmm(self.A_loc_T, G, dH)
+        partial = self._slab("halo", self.n_halo, f)
+        back = self._slab("send", self.n_send, f)
+        self.k.spmm(self.A_halo_T, G, partial)
+        wait = self._exchange(partial, self.recv_off, back, self.send_off, f)
+        self.k.spmm(self.A_loc_T, G, dH)
+        wait()
+        for q in range(self.size):                 # per peer: indices unique within a message
+            a, b = self.send_off[q], self.send_off[q + 1]
+            if b > a:
+                self.k.scatter_rows(dH, self.send_idx[a:b], back[a:b], accumulate=True)
+        return dH
+
+    def forward_symmetric_backward(self, G: torch.Tensor) -> torch.Tensor:
+        """Parallel-GCN's backward (main.c:343-404): exchange rows of G with the FORWARD
+        maps and apply A (valid when A = A^T)."""
+        return self.forward(G)
+
+    # ------------------------------------------------------------------
+    def alg_bytes_forward(self, f: int) -> int:
+        """Compulsory HBM bytes of one forward aggregation on this rank."""
+        b = self.A_loc.alg_bytes(f)
+        if self.size > 1:
+            b += 8 * self.A_halo.nnz + 8 * (self.A_halo.nrows + 1) + 4 * f * self.n_halo
+            b += 2 * 4 * f * self.n_send   # pack: read rows + write slab
+        return b

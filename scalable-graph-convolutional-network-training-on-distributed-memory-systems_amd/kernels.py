@@ -1,0 +1,185 @@
+"""Device kernels of the aggregation path: thin typed wrappers over the C ABI.
+
+``HipKernels`` is the ONLY kernel provider the product constructs.  It takes
+PyTorch CUDA tensors (PyTorch = device memory + streams, i.e. plumbing), passes
+raw device pointers and the current ``hipStream_t`` to ``libpgcn_hip.so`` and
+never computes anything itself.  There is no CPU implementation in this package:
+without a HIP device (or without the built library) construction raises.
+
+The small ``Kernels`` protocol exists so that the host logic (exchange ordering,
+PSpMM forward/backward structure, statistics) can be exercised by the CPU-only
+multi-process ``gloo`` tests with a checker-backed provider that lives in
+``tests/`` -- never in the product.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .partition import HostCSR
+
+DEFAULT_CHUNK = int(os.environ.get("PGCN_SPMM_CHUNK", "1024"))
+
+
+@dataclass
+class DeviceCSR:
+    """A CSR block resident in HBM plus its load-balancing plan."""
+    nrows: int
+    ncols: int
+    nnz: int
+    rowptr: torch.Tensor            # int64 [nrows+1]
+    col: torch.Tensor               # int32 [nnz]
+    val: Optional[torch.Tensor]     # fp32 [nnz] (None = pattern)
+    row_map: Optional[torch.Tensor]  # int32 [nrows] or None
+    tasks: Optional[torch.Tensor] = None  # int32 [ntasks,4]
+    fix: Optional[torch.Tensor] = None    # int32 [nfix,4]
+    ntasks: int = 0
+    nfix: int = 0
+    nslots: int = 0
+    ws: Optional[torch.Tensor] = None     # fp32 work-space for split rows (grown on demand)
+
+    def alg_bytes(self, f: int, n_cols_touched: Optional[int] = None, n_rows_out: Optional[int] = None) -> int:
+        """Algorithmic (compulsory) HBM bytes of one SpMM, SURVEY 8(d):
+        8.nnz + 8.(nrows+1) + 4.f.(cols touched) + 4.f.(rows written)."""
+        nc = self.ncols if n_cols_touched is None else n_cols_touched
+        nr = self.nrows if n_rows_out is None else n_rows_out
+        return 8 * self.nnz + 8 * (self.nrows + 1) + 4 * f * nc + 4 * f * nr
+
+
+def build_plan(rowptr_host: np.ndarray, chunk: int):
+    """Host-side split of long rows (pgcn_spmm_plan_host).  Returns (tasks, fix, nslots)
+    as numpy int32 arrays; tasks is None when no row exceeds ``chunk`` (the
+    one-task-per-row kernel path needs no plan)."""
+    L = _lib.lib()
+    rowptr_host = np.ascontiguousarray(rowptr_host, dtype=np.int64)
+    nrows = rowptr_host.shape[0] - 1
+    nt, nf, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, nrows, chunk, None, 0, None, 0,
+                                     ctypes.byref(nt), ctypes.byref(nf), ctypes.byref(ns)),
+               "pgcn_spmm_plan_host")
+    if nf.value == 0:
+        return None, None, 0
+    tasks = np.empty((nt.value, 4), dtype=np.int32)
+    fix = np.empty((nf.value, 4), dtype=np.int32)
+    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, nrows, chunk, tasks.ctypes.data,
+                                     nt.value, fix.ctypes.data, nf.value, ctypes.byref(nt),
+                                     ctypes.byref(nf), ctypes.byref(ns)), "pgcn_spmm_plan_host")
+    return tasks, fix, int(ns.value)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class HipKernels:
+    """libpgcn_hip.so on one MI355X.  Fails loudly when the device or library is missing."""
+
+    name = "hip"
+
+    def __init__(self, device: torch.device, xcd_swizzle: Optional[bool] = None, chunk: int = DEFAULT_CHUNK):
+        if not torch.cuda.is_available():
+            raise _lib.PgcnError("HipKernels needs a HIP device: torch.cuda.is_available() is False "
+                                 "(this package has no CPU fallback)")
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PgcnError("HipKernels needs a cuda (HIP) device, got %s" % device)
+        if xcd_swizzle is None:
+            xcd_swizzle = os.environ.get("PGCN_XCD_SWIZZLE", "1") != "0"
+        self.base_flags = _lib.SPMM_XCD_SWIZZLE if xcd_swizzle else 0
+        self.chunk = chunk
+
+    # -- data placement -------------------------------------------------
+    def prepare(self, csr: HostCSR, pattern_only: bool = False) -> DeviceCSR:
+        dev = self.device
+        rowptr_host = csr.rowptr.detach().cpu().numpy()
+        tasks, fix, nslots = build_plan(rowptr_host, self.chunk)
+        d = DeviceCSR(
+            nrows=csr.nrows, ncols=csr.ncols, nnz=csr.nnz,
+            rowptr=csr.rowptr.to(dev, torch.int64).contiguous(),
+            col=csr.col.to(dev, torch.int32).contiguous(),
+            val=None if pattern_only else csr.val.to(dev, torch.float32).contiguous(),
+            row_map=None if csr.row_map is None else csr.row_map.to(dev, torch.int32).contiguous())
+        if tasks is not None:
+            d.tasks = torch.from_numpy(tasks).to(dev)
+            d.fix = torch.from_numpy(fix).to(dev)
+            d.ntasks, d.nfix, d.nslots = tasks.shape[0], fix.shape[0], nslots
+        return d
+
+    # -- kernels ----------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check_dense(self, t: torch.Tensor, rows: int, what: str):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise _lib.PgcnError("%s must be a row-major fp32 CUDA matrix" % what)
+        if t.shape[0] < rows:
+            raise _lib.PgcnError("%s has %d rows, need %d" % (what, t.shape[0], rows))
+
+    def spmm(self, A: DeviceCSR, B: torch.Tensor, C: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+        """C (+)= A.B on the current stream.  C rows are addressed through A.row_map if set."""
+        f = B.shape[1]
+        self._check_dense(B, A.ncols, "B")
+        self._check_dense(C, 0, "C")
+        if C.shape[1] != f:
+            raise _lib.PgcnError("B and C widths differ")
+        if A.row_map is None and C.shape[0] < A.nrows:
+            raise _lib.PgcnError("C has too few rows")
+        flags = self.base_flags | (_lib.SPMM_ACCUMULATE if accumulate else 0)
+        if A.nrows == 0:
+            return C
+        if A.tasks is None and A.row_map is None:
+            _lib.check(self.lib.pgcn_spmm_csr_f32(
+                A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.nrows, B.data_ptr(),
+                B.stride(0), C.data_ptr(), C.stride(0), f, flags, self._stream()), "pgcn_spmm_csr_f32")
+            return C
+        if A.tasks is None:  # row_map without split rows: trivial plan, built once
+            t = torch.zeros((A.nrows, 4), dtype=torch.int32)
+            t[:, 0] = torch.arange(A.nrows, dtype=torch.int32)
+            rp = A.rowptr.cpu()
+            t[:, 2] = (rp[1:] - rp[:-1]).to(torch.int32)
+            t[:, 3] = -1
+            A.tasks, A.ntasks = t.to(self.device), A.nrows
+        need = A.nslots * f
+        if A.nfix and (A.ws is None or A.ws.numel() < need):
+            A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pgcn_spmm_csr_plan_f32(
+            A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.tasks.data_ptr(), A.ntasks,
+            _ptr(A.fix), A.nfix, _ptr(A.row_map), B.data_ptr(), B.stride(0), C.data_ptr(),
+            C.stride(0), f, _ptr(A.ws), 0 if A.ws is None else A.ws.numel(), A.nslots, flags,
+            self._stream()), "pgcn_spmm_csr_plan_f32")
+        return C
+
+    def gather_rows(self, H: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        n = idx.numel()
+        if n == 0:
+            return out
+        self._check_dense(H, 0, "H")
+        self._check_dense(out, n, "out")
+        _lib.check(self.lib.pgcn_gather_rows_f32(H.data_ptr(), H.stride(0), idx.data_ptr(), n,
+                                                 out.data_ptr(), out.stride(0), H.shape[1],
+                                                 self._stream()), "pgcn_gather_rows_f32")
+        return out
+
+    def scatter_rows(self, H: torch.Tensor, idx: torch.Tensor, src: torch.Tensor, accumulate: bool) -> torch.Tensor:
+        n = idx.numel()
+        if n == 0:
+            return H
+        self._check_dense(H, 0, "H")
+        self._check_dense(src, n, "src")
+        _lib.check(self.lib.pgcn_scatter_rows_f32(H.data_ptr(), H.stride(0), idx.data_ptr(), n,
+                                                  src.data_ptr(), src.stride(0), H.shape[1],
+                                                  int(accumulate), self._stream()), "pgcn_scatter_rows_f32")
+        return H
+
+    def device_info(self):
+        out = (ctypes.c_int64 * 4)()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.lib.pgcn_device_info(idx, out), "pgcn_device_info")
+        return {"cus": out[0], "wave": out[1], "gfx": out[2], "l2_bytes": out[3]}

@@ -1,0 +1,186 @@
+"""1D vertex partition of the adjacency matrix: local CSR pieces + boundary maps.
+
+Host-side (plumbing) restatement of what ``GPU/PGCN.py`` does in
+``compute_communication_maps`` (:37-51) and ``get_partitiont_of_adjacency_matrix``
+(:53-64), but producing the MI355X data layout instead of an n x n COO:
+
+* rank p keeps only its owned rows; rows are numbered 0..n_p-1 in ascending
+  global id (the reference keeps the global n x n index space, which is what
+  stops it from scaling -- SURVEY 5 "long-context" row);
+* the columns are split the way ``Parallel-GCN/main.c`` splits the product:
+  ``A_loc`` (columns owned by p, re-indexed to local ids; main.c:271) and
+  ``A_halo`` (columns owned by others, re-indexed to the position of that row in
+  the receive slab; main.c:295).  The receive slab is ordered by (owner rank,
+  global id): exactly the concatenation of the reference's ``recv_map[q]``
+  lists, so the sender's ``send_map[q]`` order matches with no index exchange;
+* the transposed pieces (CSR of ``A_loc^T`` and ``A_halo^T``) serve
+  ``PSpMM.backward`` (PGCN.py:132 ``A.t()``) without atomics.
+
+All heavy steps are torch tensor ops, so the same code runs on the GPU for the
+114 M-edge benchmark graph and on the CPU in the unit tests.  Integer work only:
+results are bit-exact by construction (checked against the reference's maps).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+
+@dataclass
+class HostCSR:
+    """A CSR block as torch tensors (any device): int64 rowptr, int32 col, fp32 val."""
+    nrows: int
+    ncols: int
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    val: torch.Tensor
+    row_map: Optional[torch.Tensor] = None  # compact row r -> output row row_map[r] (int32)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.numel())
+
+
+def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
+                 compact_rows: bool = False) -> HostCSR:
+    """Sort (r, c) lexicographically and build CSR.  Duplicate entries are kept as
+    separate stored entries (an uncoalesced COO sums them, PGCN.py:63)."""
+    dev = r.device
+    if r.numel():
+        key = r.to(torch.int64) * max(ncols, 1) + c.to(torch.int64)
+        order = torch.argsort(key, stable=True)
+        r, c, v = r[order], c[order], v[order]
+    row_map = None
+    if compact_rows:
+        rows_u, r = torch.unique(r, return_inverse=True)  # sorted
+        row_map = rows_u.to(torch.int32)
+        nrows = int(rows_u.numel())
+    counts = torch.bincount(r.to(torch.int64), minlength=nrows) if r.numel() else \
+        torch.zeros(nrows, dtype=torch.int64, device=dev)
+    rowptr = torch.zeros(nrows + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return HostCSR(nrows, ncols, rowptr, c.to(torch.int32).contiguous(),
+                   v.to(torch.float32).contiguous(), row_map)
+
+
+@dataclass
+class Partition:
+    """Everything rank ``rank`` needs for the aggregation path."""
+    n: int                      # global number of vertices
+    rank: int
+    size: int
+    owned: torch.Tensor         # int64 [n_p] global ids of owned rows, ascending
+    A_loc: HostCSR              # n_p x n_p
+    A_halo: HostCSR             # compact rows x n_halo (row_map -> local row)
+    A_loc_T: HostCSR            # n_p x n_p
+    A_halo_T: HostCSR           # n_halo x n_p   (all halo rows kept: every one is referenced)
+    send_idx: torch.Tensor      # int32 [n_send] LOCAL row ids, concatenated by target rank
+    send_off: List[int]         # size+1 offsets into send_idx (own segment empty)
+    recv_off: List[int]         # size+1 offsets into the receive slab (own segment empty)
+    halo_global: torch.Tensor   # int64 [n_halo] global ids of the receive slab rows
+    send_global: torch.Tensor   # int64 [n_send] global ids of send_idx
+    nnz_global: int = 0
+    symmetric: Optional[bool] = None
+    extra: Dict = field(default_factory=dict)
+
+    @property
+    def n_local(self) -> int:
+        return int(self.owned.numel())
+
+    @property
+    def n_halo(self) -> int:
+        return int(self.halo_global.numel())
+
+    @property
+    def n_send(self) -> int:
+        return int(self.send_idx.numel())
+
+    @property
+    def nnz_local(self) -> int:
+        return self.A_loc.nnz + self.A_halo.nnz
+
+    def send_map(self) -> Dict[int, torch.Tensor]:
+        """peer -> sorted global ids I send (== reference send_map, PGCN.py:47-50)."""
+        return {q: self.send_global[self.send_off[q]:self.send_off[q + 1]]
+                for q in range(self.size) if q != self.rank}
+
+    def recv_map(self) -> Dict[int, torch.Tensor]:
+        return {q: self.halo_global[self.recv_off[q]:self.recv_off[q + 1]]
+                for q in range(self.size) if q != self.rank}
+
+
+def _offsets(owner: torch.Tensor, size: int) -> List[int]:
+    cnt = torch.bincount(owner.to(torch.int64), minlength=size) if owner.numel() else \
+        torch.zeros(size, dtype=torch.int64)
+    off = [0]
+    for c in cnt.tolist():
+        off.append(off[-1] + int(c))
+    return off
+
+
+def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: int,
+                    partvec: torch.Tensor, rank: int, size: int,
+                    with_transpose: bool = True) -> Partition:
+    """Build rank ``rank``'s pieces from the GLOBAL COO (row, col, val) of A.
+
+    Mirrors the reference, where every rank parses the whole matrix (PGCN.py:171)
+    and filters its rows (:55-59) and boundary sets (:41-45)."""
+    dev = row.device
+    row = row.to(torch.int64)
+    col = col.to(torch.int64)
+    part = partvec.to(device=dev, dtype=torch.int64)
+    if part.numel() != n:
+        raise ValueError("part vector has %d entries, matrix has %d rows" % (part.numel(), n))
+    if part.numel() and (int(part.min()) < 0 or int(part.max()) >= size):
+        raise ValueError("part vector entries must be in [0, %d)" % size)
+    own_mask = part == rank
+    owned = torch.nonzero(own_mask).reshape(-1)
+    n_p = int(owned.numel())
+    g2l = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    g2l[owned] = torch.arange(n_p, dtype=torch.int64, device=dev)
+
+    prow = part[row]
+    pcol = part[col]
+    mine = prow == rank
+    r = g2l[row[mine]]
+    c = col[mine]
+    v = val[mine]
+    cp = pcol[mine]
+    loc = cp == rank
+
+    A_loc = csr_from_coo(r[loc], g2l[c[loc]], v[loc], n_p, n_p)
+    # halo columns, ordered by (owner, global id)  == concatenated recv_map lists
+    hkey = cp[~loc] * n + c[~loc]
+    huniq, hinv = torch.unique(hkey, return_inverse=True)
+    halo_global = huniq % n
+    halo_owner = huniq // n
+    n_halo = int(huniq.numel())
+    recv_off = _offsets(halo_owner.cpu(), size)
+    A_halo = csr_from_coo(r[~loc], hinv, v[~loc], n_p, n_halo, compact_rows=True)
+
+    A_loc_T = A_halo_T = None
+    if with_transpose:
+        A_loc_T = csr_from_coo(g2l[c[loc]], r[loc], v[loc], n_p, n_p)
+        A_halo_T = csr_from_coo(hinv, r[~loc], v[~loc], n_halo, n_p)
+
+    # rows of mine that other ranks need: (target rank, global id) sorted
+    theirs = (pcol == rank) & (prow != rank)
+    skey = prow[theirs] * n + col[theirs]
+    suniq = torch.unique(skey)
+    send_global = suniq % n
+    send_owner = suniq // n
+    send_off = _offsets(send_owner.cpu(), size)
+    send_idx = g2l[send_global].to(torch.int32)
+
+    return Partition(n=n, rank=rank, size=size, owned=owned, A_loc=A_loc, A_halo=A_halo,
+                     A_loc_T=A_loc_T, A_halo_T=A_halo_T, send_idx=send_idx.contiguous(),
+                     send_off=send_off, recv_off=recv_off, halo_global=halo_global,
+                     send_global=send_global, nnz_global=int(row.numel()))
+
+
+def read_partvec(path: str) -> List[int]:
+    """``-p`` file: FIRST line = n space separated part ids (PGCN.py:172-173)."""
+    with open(path) as f:
+        return list(map(int, f.readline().split()))

@@ -1,0 +1,102 @@
+"""Process bodies for the multi-process (gloo, CPU) tests.  Spawned by test_engine_gloo.py."""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _init(rank, P, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(P))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=P)
+
+
+def _pgcn_module(rank, P):
+    from conftest import pkg
+    from oracle_kernels import OracleKernels
+    M = pkg("PGCN")
+    M._kernel_provider = OracleKernels()       # test-only checker-backed kernels
+    M.myrank, M.world_size, M.device = rank, P, torch.device("cpu")
+    M._exchanger = None
+    return M
+
+
+def pspmm_worker(rank, P, port, path_A, path_pv, f, seed, q):
+    """PSpMM.apply forward + backward on the golden inputs, owned rows only."""
+    from conftest import golden_inputs, read_partvec
+    from scipy.io import mmread
+    _init(rank, P, port)
+    M = _pgcn_module(rank, P)
+    A = mmread(path_A)
+    part = read_partvec(path_pv)
+    M.send_map, M.recv_map = M.compute_communication_maps(A, part, rank, P)
+    eng = M.get_partitiont_of_adjacency_matrix(A, part, rank)
+    M.init_stats()
+    own = eng.part.owned.numpy()
+    Hfull, Gfull = golden_inputs(A.shape[0], f, seed)
+    H = torch.tensor(Hfull[own], requires_grad=True)
+    out = M.PSpMM.apply(eng, H)
+    stats_fwd = {k: int(v) for k, v in M.stats.items()}
+    out.backward(torch.tensor(Gfull[own]))
+    # the standalone communicate_fgm entry point
+    halo = M.communicate_fgm(H.detach(), backward=False)
+    ok_halo = bool(np.array_equal(halo.numpy(), Hfull[eng.part.halo_global.numpy()]))
+    q.put({"rank": rank, "own": own, "fwd": out.detach().numpy(), "bwd": H.grad.numpy(),
+           "stats_fwd": stats_fwd, "stats_all": {k: int(v) for k, v in M.stats.items()},
+           "ok_halo": ok_halo,
+           "send_map": {k: v.numpy() for k, v in M.send_map.items()}})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_worker(rank, P, port, path_A, path_pv, nlayers, f, seed, q):
+    """The drop-in's run() end to end (PGCN.py:162-238) over gloo."""
+    _init(rank, P, port)
+    M = _pgcn_module(rank, P)
+    torch.manual_seed(seed)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        model = M.run(rank, P, nlayers, f, path_A, path_pv, "gloo")
+    q.put({"rank": rank, "stdout": buf.getvalue(),
+           "weights": [m.linear.weight.detach().numpy() for m in model]})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def pargcn_worker(rank, P, port, path_A, path_pv, d, seed, q):
+    """Parallel-GCN semantics (pargcn.train) over gloo with the engine."""
+    from conftest import pkg, read_partvec
+    from oracle import oracle
+    from scipy.io import mmread
+    import scipy.sparse as sp
+    _init(rank, P, port)
+    M = _pgcn_module(rank, P)
+    A = oracle.normalize_adjacency(mmread(path_A))
+    A = ((A + A.T) * 0.5).tocoo().astype(np.float32)
+    part = read_partvec(path_pv)
+    eng = M.get_partitiont_of_adjacency_matrix(A, part, rank)
+    n = A.shape[0]
+    rng = np.random.default_rng(seed)
+    L = len(d) - 1
+    W = {l: torch.tensor((rng.random((d[l], d[l + 1]), dtype=np.float32) * 2 - 1) *
+                         np.float32(np.sqrt(6.0 / (d[l] + d[l + 1])))) for l in range(1, L)}
+    own = eng.part.owned.numpy()
+    H0 = torch.ones((own.size, d[1]))
+    Y = torch.zeros((own.size, d[L])); Y[:, 1] = 1
+    Ym = torch.zeros((own.size, d[L]), dtype=torch.uint8); Ym[:, 1] = 1
+    ar = (lambda t: dist.all_reduce(t)) if P > 1 else None
+    errs, Wn, Hl = pkg("pargcn").train(eng, d, W, H0, Y, Ym, epochs=3, alpha=0.01, allreduce=ar)
+    q.put({"rank": rank, "own": own, "errs": errs, "W": {l: w.numpy() for l, w in Wn.items()},
+           "Hl": Hl.numpy(), "stats": dict(eng.stats)})
+    dist.barrier()
+    dist.destroy_process_group()

@@ -1,0 +1,135 @@
+"""Multi-process CPU tests of the N>1 path (gloo, world_size 1..3).
+
+The HOST logic under test is the product's: partition layout, all-to-all-v ordering,
+PSpMM forward/backward structure, accumulate-on-receive, statistics, run().  The device
+kernels are replaced by the checker-backed provider in tests/oracle_kernels.py (the only
+way to execute on a box without a GPU; the real kernels are covered by -m gpu tests).
+Outputs are compared with golden vectors produced by the reference's own PGCN.py."""
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch.multiprocessing as mp
+from scipy.io import mmread
+
+import _workers
+from conftest import SPMM_CASES, TRAIN_CASES, golden, golden_inputs, gpath, read_partvec, rel_err
+from oracle import oracle
+
+TOL = 1e-5
+_port = [29800]
+
+
+def _spawn(fn, P, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    _port[0] += 1
+    procs = [ctx.Process(target=fn, args=(r, P, _port[0]) + args + (q,)) for r in range(P)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(P)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda r: r["rank"])
+
+
+@pytest.mark.parametrize("name,mtx,pv,P", [SPMM_CASES[i] for i in (0, 2, 3, 4, 5, 7, 8)])
+def test_pspmm_forward_backward(name, mtx, pv, P):
+    arrays, meta = golden(name)
+    res = _spawn(_workers.pspmm_worker, P, gpath(mtx), gpath(pv), meta["f"], meta["seed"])
+    A = sp.csr_matrix(mmread(gpath(mtx))).astype(np.float32)
+    n = A.shape[0]
+    _, G = golden_inputs(n, meta["f"], meta["seed"])
+    fwd = np.zeros((n, meta["f"]), np.float32)
+    bwd = np.zeros_like(fwd)
+    for r in res:
+        fwd[r["own"]] = r["fwd"]
+        bwd[r["own"]] = r["bwd"]
+        m = meta["ranks"][r["rank"]]
+        assert r["stats_fwd"] == m["stats_fwd"]                  # rows + messages, PGCN.py:105-114
+        assert r["ok_halo"]
+        # after fwd + bwd + one more forward exchange: 3 exchanges
+        assert r["stats_all"]["send_nmsg"] == 3 * (P - 1)
+        assert r["stats_all"]["send_volume"] == 2 * m["stats_fwd"]["send_volume"] + m["stats_fwd"]["recv_volume"]
+    assert rel_err(fwd, arrays["fwd"]) < TOL                     # reference PSpMM.forward
+    if "bwd" in arrays:
+        assert rel_err(bwd, arrays["bwd"]) < TOL                 # reference PSpMM.backward (P <= 2)
+    # P = 3: the reference overwrites partial sums (quirk Q3); the exact answer is A^T.G
+    assert rel_err(bwd, oracle.spmm(sp.csr_matrix(A.T), G)) < TOL
+
+
+@pytest.mark.parametrize("name,mtx,pv", TRAIN_CASES)
+def test_run_matches_reference_training_p1(name, mtx, pv):
+    arrays, meta = golden(name)
+    res = _spawn(_workers.run_worker, 1, gpath(mtx), gpath(pv), meta["nlayers"], meta["f"], meta["seed"])
+    out = res[0]["stdout"]
+    printed = [float(x) for x in re.findall(r"Epoch \d{5} \| Loss ([0-9.]+)", out)]
+    assert len(printed) == 4
+    np.testing.assert_allclose(printed, arrays["losses"][1:], rtol=2e-5, atol=6e-5)
+    for i, w in enumerate(res[0]["weights"]):
+        assert rel_err(w, arrays["w1_%d" % i]) < 1e-4
+    assert "total_vol: 0 total_nmsg: 0" in out and "Elapsed time" in out
+    assert "'send_volume': tensor(0)" in out
+
+
+@pytest.mark.parametrize("mtx,pv,P,L,f", [("karate.A.mtx", "karate.mtx.3.hp", 3, 3, 16),
+                                          ("gemat11p.A.mtx", "gemat11.mtx.2.rp", 2, 2, 8)])
+def test_run_multi_rank_matches_oracle(mtx, pv, P, L, f):
+    seed = 7
+    res = _spawn(_workers.run_worker, P, gpath(mtx), gpath(pv), L, f, seed)
+    A = sp.csr_matrix(mmread(gpath(mtx))).astype(np.float32)
+    n = A.shape[0]
+    part = read_partvec(gpath(pv))
+    import torch
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    w0 = [nn.Linear(f, f, bias=False).weight.detach().numpy() for _ in range(L)]
+    H0 = np.repeat(np.arange(n, dtype=np.float32)[:, None], f, axis=1)
+    losses, Ws = oracle.pgcn_train_np(A, part, P, w0, H0, np.arange(n) % f, epochs=5)
+    printed = [float(x) for x in re.findall(r"Epoch \d{5} \| Loss ([0-9.]+)", res[0]["stdout"])]
+    np.testing.assert_allclose(printed, losses[1:], rtol=5e-5, atol=6e-5)
+    for r in res:
+        for i, w in enumerate(r["weights"]):
+            assert rel_err(w, Ws[i]) < 2e-4
+    # volume KAT: rows per exchange x (1 + 4 epochs) x L layers x 2 directions
+    rows = sum(v.size for r in range(P) for v in oracle.communication_maps(A, part, r, P)[0].values())
+    m = re.search(r"total_vol: (\d+) total_nmsg: (\d+)", res[0]["stdout"])
+    assert int(m.group(1)) == rows * 5 * L * 2
+    assert int(m.group(2)) == P * (P - 1) * 5 * L * 2
+
+
+def test_total_vol_kat_gemat11_hp3():
+    """the reference prints total_vol 55380 / total_nmsg 180 for
+    PGCN.py -s 3 -l 3 -f 128 on gemat11 with the shipped .3.hp part vector."""
+    res = _spawn(_workers.run_worker, 3, gpath("gemat11.mtx"), gpath("gemat11.mtx.3.hp"), 3, 8, 1)
+    assert "total_vol: 55380 total_nmsg: 180" in res[0]["stdout"]
+
+
+def test_pargcn_semantics_multi_rank():
+    d = [4929, 16, 16, 2]
+    seed = 3
+    res = _spawn(_workers.pargcn_worker, 3, gpath("gemat11p.mtx"), gpath("gemat11.mtx.3.hp"), d, seed)
+    A = oracle.normalize_adjacency(mmread(gpath("gemat11p.mtx")))
+    A = ((A + A.T) * 0.5).tocsr().astype(np.float32)
+    n = d[0]
+    rng = np.random.default_rng(seed)
+    W = {l: (rng.random((d[l], d[l + 1]), dtype=np.float32) * 2 - 1) * np.float32(np.sqrt(6.0 / (d[l] + d[l + 1])))
+         for l in (1, 2)}
+    Y = np.zeros((n, 2), np.float32); Y[:, 1] = 1
+    Ym = np.zeros((n, 2), np.uint8); Ym[:, 1] = 1
+    part = read_partvec(gpath("gemat11.mtx.3.hp"))
+    err, Wc, Hl, st = oracle.pargcn_train(A, part, 3, d, W, np.ones((n, 16), np.float32), Y, Ym)
+    Hg = np.zeros((n, 2), np.float32)
+    for r in res:
+        np.testing.assert_allclose(r["errs"], err, rtol=1e-5)
+        for l in (1, 2):
+            assert rel_err(r["W"][l], Wc[l]) < TOL
+        Hg[r["own"]] = r["Hl"]
+        # engine counts ROWS per exchange (PGCN.py:105), the oracle SCALARS (main.c:264):
+        # 12 exchanges of rows_r rows vs rows_r x (16+16+2+16) scalars x 3 epochs
+        assert r["stats"]["send_volume"] % 12 == 0
+        assert r["stats"]["send_volume"] // 12 * 50 * 3 == st[r["rank"], 0]
+        assert r["stats"]["send_nmsg"] == st[r["rank"], 1]
+    assert rel_err(Hg, Hl) < TOL
