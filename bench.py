@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Benchmark of the GCN aggregation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): Reddit-shaped graph (n = 232 965, 114 615 892
+directed edges + self loops, seeded R-MAT stand-in -- the dataset is not in the image),
+3-layer GCN, f = 128, random 1D partition over N GPUs.  One *step* = one training epoch
+of GPU/PGCN.py:212-220 (forward, loss, backward, gradient all-reduce, Adam) = 2.L
+aggregations A.H through the HIP engine.  Metric: edges aggregated per second
+= 2.L.nnz / t_epoch, whole job; ms_per_step = ms/epoch.
+
+Extra objects in the JSON line:
+  roofline     dominant kernel = the local CSR SpMM (spmm_tasks_kernel): algorithmic bytes
+               (8.nnz + 8.(n_r+1) + 4.f.n_c + 4.f.n_r) / its average launch
+               duration, measured live with HIP events on the launch stream inside the
+               timed region; peak 8 TB/s.  `traffic` comes from separate rocprofv3 --pmc
+               passes (profiles/*.json) when present, else null.
+  cpu_baseline the CPU oracle (GraphBLAS-free restatement of Parallel-GCN's SpMM, OpenMP)
+               timed on this host on a bounded sample: rank 0, N = 1 only.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd"
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (6.29e12 measured copy ceiling)
+
+
+def pkg(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+class KernelTimer:
+    """Wraps HipKernels.spmm: HIP events on the launch stream around each launch of the
+    dominant kernel (the local-block SpMM), tagged by operand."""
+
+    def __init__(self, kernels, device):
+        self.k, self.device, self.records, self.on = kernels, device, [], False
+        self._spmm = kernels.spmm
+        kernels.spmm = self.spmm
+
+    def spmm(self, A, B, C, accumulate=False):
+        if not self.on:
+            return self._spmm(A, B, C, accumulate)
+        s = torch.cuda.current_stream(self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        out = self._spmm(A, B, C, accumulate)
+        e1.record(s)
+        self.records.append((id(A), B.shape[1], e0, e1))
+        return out
+
+    def summary(self, key_id, f):
+        ts = [e0.elapsed_time(e1) for (i, ff, e0, e1) in self.records if i == key_id and ff == f]
+        return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
+
+
+def cpu_baseline(part, f, budget_s=20.0):
+    """Oracle SpMM (all host cores, OpenMP) on the full local block: the CPU path timed
+    beside the GPU kernel.  Bounded sample: as many full-graph SpMMs as fit the budget."""
+    from oracle import oracle
+    L = oracle.lib()
+    rp = part.A_loc.rowptr.cpu().numpy().astype(np.int64)
+    ci = part.A_loc.col.cpu().numpy().astype(np.int32)
+    va = part.A_loc.val.cpu().numpy().astype(np.float32)
+    n = rp.shape[0] - 1
+    rng = np.random.default_rng(0)
+    B = rng.random((n, f), dtype=np.float32)
+    C = np.empty((n, f), dtype=np.float32)
+    p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+    reps, t_total = 0, 0.0
+    while True:
+        t0 = time.time()
+        L.oracle_spmm_csr_f32(n, p(rp, ctypes.c_int64), p(ci, ctypes.c_int32), p(va, ctypes.c_float),
+                              p(B, ctypes.c_float), f, p(C, ctypes.c_float), f, f, 0)
+        t_total += time.time() - t0
+        reps += 1
+        if t_total + t_total / reps > budget_s or reps >= 6:
+            break
+    cores = L.oracle_num_threads()
+    return {"value": ci.shape[0] * reps / t_total, "unit": "edges aggregated/s",
+            "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d full-graph CSR SpMM(s), f=%d, nnz=%d (1 of the 6 per epoch), oracle/pgcn_oracle.c "
+                      "with OpenMP on %d threads, %.1f s" % (reps, f, ci.shape[0], cores, t_total),
+            "ms_per_spmm": 1e3 * t_total / reps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="reddit")
+    ap.add_argument("--features", type=int, default=None)
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    dev = torch.device("cuda:%d" % (local_rank % torch.cuda.device_count()))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    synth, partition, engine, kernels, P = pkg("synth"), pkg("partition"), pkg("engine"), pkg("kernels"), pkg("PGCN")
+    n, nnz_dir, f, L = synth.SHAPES[args.workload]
+    f = args.features or f
+    L = args.layers or L
+
+    # ---- synthetic graph (same seed on every rank) + partition -------------------
+    t0 = time.time()
+    n, row, col, val = synth.make_graph(args.workload, seed=0, device=dev)
+    nnz = int(row.numel())
+    partvec = synth.random_partvec(n, world, seed=0) if world > 1 else torch.zeros(n, dtype=torch.int64)
+    if world > 1:   # all ranks must hold the same graph
+        chk = torch.stack([row.sum(), col.sum(), (val.double().sum() * 1e6).long()]).double()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "ranks generated different graphs"
+    part = partition.build_partition(row, col, val, n, partvec, rank, world)
+    del row, col, val
+    K = kernels.HipKernels(dev)
+    exch = engine.RcclExchanger(rank, world, dev) if world > 1 else None
+    eng = engine.AggregationEngine(part, K, dev, exch)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+
+    # ---- model: L x PGCN(f, f), PGCN.py:194-200 ----------------------------------
+    P.device, P.myrank, P.world_size = dev, rank, world
+    P.init_stats()
+    torch.manual_seed(0)
+    model = nn.Sequential(*[P.PGCN(eng, f, f) for _ in range(L)]).to(dev)
+    P.initiliaze_parameters(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    H = torch.rand(part.n_local, f, device=dev, generator=gen).requires_grad_(True)
+    labels = part.owned.to(dev) % f
+
+    def step():
+        logits = model(H)
+        loss = P.local_loss(logits, labels, n)
+        opt.zero_grad()
+        loss.backward()
+        P.average_gradients(model)
+        opt.step()
+        return loss
+
+    timer = KernelTimer(K, dev)
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(loss)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    edges_per_s = 2 * L * nnz * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (local-block forward SpMM) -----------------
+    roofline = None
+    avg_ms, launches = timer.summary(id(eng.A_loc), f)
+    if avg_ms:
+        alg = eng.A_loc.alg_bytes(f)
+        achieved = alg / (avg_ms * 1e-3)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as fh:
+                    rec = json.load(fh)
+                if rec.get("workload") == args.workload and rec.get("n_gpus") == world and rec.get("f") == f:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "spmm_tasks_kernel<32,4> (A_loc . H, forward)",
+                    "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK, "traffic": traffic,
+                    "alg_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": launches,
+                    "frac_of_measured_copy_ceiling_6.29TBs": achieved / 6.29e12,
+                    "gather_model_GBs": 4.0 * f * eng.A_loc.nnz / (avg_ms * 1e-3) / 1e9,
+                    "kernel_edges_per_s": eng.A_loc.nnz / (avg_ms * 1e-3)}
+        bavg, bl = timer.summary(id(eng.A_loc_T), f)
+        if bavg:
+            roofline["avg_launch_ms_backward_AT"] = bavg
+
+    out = {
+        "metric": "edges aggregated/sec (Reddit-shaped 3-layer GCN f=128, full training epoch)",
+        "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s-like R-MAT n=%d nnz=%d (incl. self loops), %d-layer GCN f=%d, "
+                               "random 1D partition over %d GPU(s), 1 step = 1 epoch (fwd+loss+bwd+allreduce+Adam)"
+                               % (args.workload, n, nnz, L, f, world),
+                   "n": n, "nnz": nnz, "f": f, "layers": L, "spmm_per_epoch": 2 * L,
+                   "partition": "random" if world > 1 else "none", "exchange": exch.name if exch else "none",
+                   "xcd_swizzle": bool(K.base_flags & 2), "chunk": K.chunk},
+        "roofline": roofline, "ms_per_epoch": ms_per_step, "loss": loss_val, "setup_s": setup_s,
+    }
+    if world > 1:
+        vol = torch.tensor([eng.stats["send_volume"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(vol)
+        out["exchange_rows_total"] = float(vol)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline(part, f, args.cpu_budget)
+        out["cpu_baseline"] = cb
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        exch.close()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,367 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's
+golden vectors.  Needs an MI355X:  python -m pytest tests -m gpu
+
+Tolerances: integer / index / copy work is bit-exact; fp32 SpMM agrees with the oracle
+within 1e-5 relative to the largest magnitude (north_star: "within 1e-5 relative fp32";
+the only difference is FMA contraction + the fixed segment-combine order of split rows)."""
+import contextlib
+import ctypes
+import io
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+from scipy.io import mmread
+
+from conftest import (SPMM_CASES, TRAIN_CASES, golden, golden_inputs, gpath, pkg, read_partvec,
+                      rel_err)
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    d = torch.device("cuda:0")
+    torch.cuda.set_device(d)
+    return d
+
+
+@pytest.fixture(scope="module")
+def K(dev):
+    return pkg("kernels").HipKernels(dev)
+
+
+def _host_csr(A):
+    partition = pkg("partition")
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    return partition.HostCSR(A.shape[0], A.shape[1], torch.from_numpy(A.indptr.astype(np.int64)),
+                             torch.from_numpy(A.indices.astype(np.int32)),
+                             torch.from_numpy(A.data.astype(np.float32)))
+
+
+def _spmm_gpu(K, dev, A, B, chunk=None, accumulate_into=None):
+    h = _host_csr(A)
+    if chunk is not None:
+        old, K.chunk = K.chunk, chunk
+    d = K.prepare(h)
+    if chunk is not None:
+        K.chunk = old
+    Bd = torch.from_numpy(B).to(dev)
+    if accumulate_into is None:
+        C = torch.full((A.shape[0], B.shape[1]), float("nan"), device=dev)
+        K.spmm(d, Bd, C)
+    else:
+        C = torch.from_numpy(accumulate_into).to(dev)
+        K.spmm(d, Bd, C, accumulate=True)
+    torch.cuda.synchronize()
+    return C.cpu().numpy(), d
+
+
+def test_library_and_device(K):
+    info = K.device_info()
+    assert info["gfx"] == 950 and info["wave"] == 64 and info["cus"] >= 200, info
+
+
+@pytest.mark.parametrize("mtx", ["karate.mtx", "gemat11.mtx", "gemat11p.A.mtx"])
+@pytest.mark.parametrize("f", [1, 2, 3, 4, 8, 16, 20, 64, 100, 128, 256, 300, 512])
+def test_spmm_matches_oracle(K, dev, mtx, f):
+    A = sp.csr_matrix(mmread(gpath(mtx))).astype(np.float32)
+    rng = np.random.default_rng(f)
+    B = rng.random((A.shape[1], f), dtype=np.float32) * 2 - 1
+    got, _ = _spmm_gpu(K, dev, A, B)
+    assert rel_err(got, oracle.spmm(A, B)) < TOL
+    got_t, _ = _spmm_gpu(K, dev, sp.csr_matrix(A.T), B)          # backward operand (A^T)
+    assert rel_err(got_t, oracle.spmm(sp.csr_matrix(A.T), B)) < TOL
+
+
+def test_spmm_unaligned_leading_dimension(K, dev):
+    """f % 4 == 0 but a padded / offset view forces the scalar kernel shape."""
+    A = sp.csr_matrix(mmread(gpath("gemat11p.A.mtx"))).astype(np.float32)
+    rng = np.random.default_rng(1)
+    Bp = torch.from_numpy(rng.random((A.shape[1], 19), dtype=np.float32)).to(dev)
+    B = Bp[:, 1:17]                                               # ld 19, base offset 4 bytes
+    d = K.prepare(_host_csr(A))
+    C = torch.empty((A.shape[0], 16), device=dev)
+    K.spmm(d, B, C)
+    torch.cuda.synchronize()
+    assert rel_err(C.cpu().numpy(), oracle.spmm(A, B.cpu().numpy().copy())) < TOL
+
+
+@pytest.mark.parametrize("f", [2, 16, 128, 260])
+def test_spmm_split_long_rows_deterministic(K, dev, f):
+    """Rows longer than the plan chunk go through partial slots + the fix-up kernel."""
+    synth = pkg("synth")
+    n, row, col, val = synth.make_graph(4000, 400000, seed=2)
+    A = sp.csr_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n, n))
+    assert np.diff(A.indptr).max() > 600
+    rng = np.random.default_rng(0)
+    B = rng.random((n, f), dtype=np.float32) * 2 - 1
+    ref = oracle.spmm(A, B)
+    got, d = _spmm_gpu(K, dev, A, B, chunk=128)
+    assert d.nfix > 0 and d.nslots > d.nfix
+    assert rel_err(got, ref) < TOL
+    got2, _ = _spmm_gpu(K, dev, A, B, chunk=128)
+    np.testing.assert_array_equal(got, got2)                      # no atomics => bit-reproducible
+    base = rng.random((n, f), dtype=np.float32)
+    acc, _ = _spmm_gpu(K, dev, A, B, chunk=128, accumulate_into=base)
+    assert rel_err(acc, ref + base) < TOL
+    acc1, _ = _spmm_gpu(K, dev, A, B, accumulate_into=base)        # unsplit accumulate
+    assert rel_err(acc1, ref + base) < TOL
+
+
+def test_spmm_edge_cases(K, dev):
+    # empty rows, empty matrix, single row, explicit zeros, duplicate-free pattern (val=None)
+    A = sp.csr_matrix((np.array([1., 2., 0., 3.], np.float32), np.array([0, 3, 1, 2], np.int32),
+                       np.array([0, 2, 2, 2, 4], np.int64)), shape=(4, 4))
+    B = np.arange(16, dtype=np.float32).reshape(4, 4)
+    got, _ = _spmm_gpu(K, dev, A, B)
+    np.testing.assert_array_equal(got, A.toarray() @ B)           # exact in fp32 (small ints)
+    Z = sp.csr_matrix((3, 4), dtype=np.float32)
+    got, _ = _spmm_gpu(K, dev, Z, B)
+    np.testing.assert_array_equal(got, np.zeros((3, 4), np.float32))
+    h = _host_csr(A)
+    d = K.prepare(h, pattern_only=True)
+    C = torch.empty((4, 4), device=dev)
+    K.spmm(d, torch.from_numpy(B).to(dev), C)
+    np.testing.assert_array_equal(C.cpu().numpy(), (A.toarray() != 0).astype(np.float32) @ B +
+                                  np.array([[0] * 4, [0] * 4, [0] * 4, B[1]]))  # stored zero counts as 1
+    # NaN / Inf in rows that are NOT referenced must not leak (no 0*Inf from padding lanes)
+    B2 = B.copy(); B2[0, :] = np.inf
+    A2 = sp.csr_matrix((np.array([1.], np.float32), np.array([2], np.int32), np.array([0, 1, 1], np.int64)),
+                       shape=(2, 4))
+    got, _ = _spmm_gpu(K, dev, A2, B2)
+    np.testing.assert_array_equal(got, np.vstack([B2[2], np.zeros(4, np.float32)]))
+
+
+def test_spmm_row_map(K, dev):
+    partition = pkg("partition")
+    A = sp.csr_matrix(mmread(gpath("gemat11p.A.mtx"))).astype(np.float32)
+    n = A.shape[0]
+    rows = np.sort(np.random.default_rng(0).permutation(n)[:1500]).astype(np.int32)
+    sub = _host_csr(A[rows])
+    sub.row_map = torch.from_numpy(rows)
+    rng = np.random.default_rng(2)
+    B = rng.random((n, 32), dtype=np.float32)
+    base = rng.random((n, 32), dtype=np.float32)
+    for chunk in (8, 4096):
+        old, K.chunk = K.chunk, chunk
+        d = K.prepare(sub)
+        K.chunk = old
+        C = torch.from_numpy(base).to(dev)
+        K.spmm(d, torch.from_numpy(B).to(dev), C, accumulate=True)
+        ref = base.copy()
+        ref[rows] += oracle.spmm(A[rows], B)
+        assert rel_err(C.cpu().numpy(), ref) < TOL
+        untouched = np.setdiff1d(np.arange(n), rows)
+        np.testing.assert_array_equal(C.cpu().numpy()[untouched], base[untouched])
+
+
+@pytest.mark.parametrize("f", [1, 4, 6, 128, 516])
+def test_gather_scatter_bit_exact(K, dev, f):
+    rng = np.random.default_rng(f)
+    H = rng.random((5000, f), dtype=np.float32)
+    idx = rng.permutation(5000)[:1733].astype(np.int32)
+    Hd, idxd = torch.from_numpy(H).to(dev), torch.from_numpy(idx).to(dev)
+    out = torch.empty((idx.size, f), device=dev)
+    K.gather_rows(Hd, idxd, out)
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.gather_rows(H, idx))
+    src = rng.random((idx.size, f), dtype=np.float32)
+    for acc in (False, True):
+        X = torch.from_numpy(H).to(dev)
+        K.scatter_rows(X, idxd, torch.from_numpy(src).to(dev), acc)
+        ref = H.copy()
+        oracle.scatter_rows(ref, idx, src, acc)
+        np.testing.assert_array_equal(X.cpu().numpy(), ref)
+    K.gather_rows(Hd, idxd[:0], out)                               # empty index list is a no-op
+
+
+class _PrecomputedExchanger:
+    """Test double for one GPU: RCCL refuses two ranks on one device, so the slab a rank
+    would receive is produced from the global matrix the test already holds."""
+
+    def __init__(self):
+        self.next_recv = None
+
+    def alltoallv(self, send, send_off, recv, recv_off, f):
+        self.sent = send[:send_off[-1]].clone()
+        recv[:recv_off[-1]] = self.next_recv
+
+    def allreduce_sum(self, buf):
+        pass
+
+
+@pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES)
+def test_engine_forward_backward_vs_reference_golden(K, dev, name, mtx, pv, P):
+    """Every rank's engine on the one GPU, checked against the reference's PSpMM outputs."""
+    partition, engine = pkg("partition"), pkg("engine")
+    arrays, meta = golden(name)
+    A = sp.coo_matrix(mmread(gpath(mtx)))
+    n, f = A.shape[0], meta["f"]
+    part = torch.tensor(read_partvec(gpath(pv)))
+    Hfull, Gfull = golden_inputs(n, f, meta["seed"])
+    At = sp.csr_matrix(A.T).astype(np.float32)
+    bwd_exact = oracle.spmm(At, Gfull)
+    row, col, val = (torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
+                     torch.from_numpy(A.data.astype(np.float32)))
+    fwd = np.zeros((n, f), np.float32)
+    engines = []
+    for r in range(P):
+        p = partition.build_partition(row, col, val, n, part, r, P)
+        ex = _PrecomputedExchanger() if P > 1 else None
+        eng = engine.AggregationEngine(p, K, dev, ex)
+        if P > 1:
+            ex.next_recv = torch.from_numpy(Hfull[p.halo_global.numpy()]).to(dev)
+        own = p.owned.numpy()
+        out = eng.forward(torch.from_numpy(Hfull[own]).to(dev))
+        torch.cuda.synchronize()
+        fwd[own] = out.cpu().numpy()
+        if P > 1:   # what was packed for the peers is exactly H[send_map rows]
+            np.testing.assert_array_equal(ex.sent.cpu().numpy(), Hfull[p.send_global.numpy()])
+        engines.append((eng, ex, p))
+    assert rel_err(fwd, arrays["fwd"]) < TOL
+    # backward: first pass collects every rank's halo partials, second pass delivers them
+    partials = {}
+    for eng, ex, p in engines:
+        if P > 1:
+            ex.next_recv = torch.zeros((p.n_send, f), device=dev)
+        eng.backward(torch.from_numpy(Gfull[p.owned.numpy()]).to(dev))
+        torch.cuda.synchronize()
+        if P > 1:
+            partials[p.rank] = (p.halo_global.numpy(), ex.sent.cpu().numpy(), list(p.recv_off))
+    bwd = np.zeros((n, f), np.float32)
+    for eng, ex, p in engines:
+        if P > 1:
+            back = np.zeros((p.n_send, f), np.float32)
+            for q in range(P):
+                if q == p.rank:
+                    continue
+                hg, slab, roff = partials[q]
+                seg = slice(roff[p.rank], roff[p.rank + 1])       # what q computed for my rows
+                a, b = p.send_off[q], p.send_off[q + 1]
+                np.testing.assert_array_equal(hg[seg], p.send_global.numpy()[a:b])
+                back[a:b] = slab[seg]
+            ex.next_recv = torch.from_numpy(back).to(dev)
+        out = eng.backward(torch.from_numpy(Gfull[p.owned.numpy()]).to(dev))
+        torch.cuda.synchronize()
+        bwd[p.owned.numpy()] = out.cpu().numpy()
+    assert rel_err(bwd, bwd_exact) < TOL
+    if "bwd" in arrays:
+        assert rel_err(bwd, arrays["bwd"]) < TOL
+
+
+@pytest.mark.parametrize("name,mtx,pv", TRAIN_CASES)
+def test_run_matches_reference_training(dev, name, mtx, pv):
+    """The drop-in's run() on the GPU at P=1 vs losses/weights of the reference's run()."""
+    arrays, meta = golden(name)
+    M = pkg("PGCN")
+    M._kernel_provider = None
+    M._exchanger = None
+    torch.manual_seed(meta["seed"])
+    w0 = [torch.nn.Linear(meta["f"], meta["f"], bias=False).weight.detach().numpy() for _ in range(meta["nlayers"])]
+    for i, w in enumerate(w0):                                     # same RNG stream as the golden run
+        np.testing.assert_array_equal(w, arrays["w0_%d" % i])
+    torch.manual_seed(meta["seed"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        model = M.run(0, 1, meta["nlayers"], meta["f"], gpath(mtx), gpath(pv), "nccl")
+    printed = [float(x) for x in re.findall(r"Epoch \d{5} \| Loss ([0-9.]+)", buf.getvalue())]
+    np.testing.assert_allclose(printed, arrays["losses"][1:], rtol=5e-5, atol=6e-5)
+    for i, m in enumerate(model):
+        assert rel_err(m.linear.weight.detach().cpu().numpy(), arrays["w1_%d" % i]) < 2e-4
+    assert type(M._kernel_provider).__name__ == "HipKernels"
+
+
+def test_pargcn_semantics_vs_oracle(K, dev):
+    """Parallel-GCN/main.c training loop with both aggregations on the HIP engine."""
+    partition, engine, pargcn = pkg("partition"), pkg("engine"), pkg("pargcn")
+    A = oracle.normalize_adjacency(mmread(gpath("gemat11p.mtx")))
+    A = ((A + A.T) * 0.5).tocoo().astype(np.float32)
+    n = A.shape[0]
+    d = [n, 16, 16, 2]
+    rng = np.random.default_rng(3)
+    W = {l: (rng.random((d[l], d[l + 1]), dtype=np.float32) * 2 - 1) * np.float32(np.sqrt(6.0 / (d[l] + d[l + 1])))
+         for l in (1, 2)}
+    Y = np.zeros((n, 2), np.float32); Y[:, 1] = 1
+    Ym = np.zeros((n, 2), np.uint8); Ym[:, 1] = 1
+    err, Wc, Hl, _ = oracle.pargcn_train(A, [0] * n, 1, d, W, np.ones((n, 16), np.float32), Y, Ym)
+    p = partition.build_partition(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
+                                  torch.from_numpy(A.data), n, torch.zeros(n, dtype=torch.int64), 0, 1)
+    eng = engine.AggregationEngine(p, K, dev)
+    errs, Wn, Hout = pargcn.train(eng, d, {l: torch.from_numpy(w).to(dev) for l, w in W.items()},
+                                  torch.ones((n, 16), device=dev), torch.from_numpy(Y).to(dev),
+                                  torch.from_numpy(Ym).to(dev))
+    np.testing.assert_allclose(errs, err, rtol=1e-5)
+    for l in (1, 2):
+        assert rel_err(Wn[l].cpu().numpy(), Wc[l]) < TOL
+    assert rel_err(Hout.cpu().numpy(), Hl) < TOL
+
+
+def test_full_size_properties_reddit_like(K, dev):
+    """BASELINE size (n = 232 965, ~114.8 M stored entries, f = 128): size-independent
+    properties + the oracle on a row sample."""
+    synth, partition, engine = pkg("synth"), pkg("partition"), pkg("engine")
+    n, row, col, val = synth.make_graph("reddit", seed=0, device=dev)
+    nnz = row.numel()
+    assert nnz == 114615892 + n
+    p = partition.build_partition(row, col, val, n, torch.zeros(n, dtype=torch.int64), 0, 1)
+    eng = engine.AggregationEngine(p, K, dev)
+    f = 128
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    X = torch.rand(n, f, device=dev, generator=gen) * 2 - 1
+    Yv = torch.rand(n, f, device=dev, generator=gen) * 2 - 1
+    AX, AY = eng.forward(X), eng.forward(Yv)
+    # determinism
+    assert torch.equal(AX, eng.forward(X))
+    # linearity: A(2X - 3Y) = 2AX - 3AY
+    lin = eng.forward(2 * X - 3 * Yv)
+    assert float((lin - (2 * AX - 3 * AY)).abs().max() / lin.abs().max()) < 2e-5
+    # checksum of checksums: 1^T (A X) = (A^T 1)^T X, column sums in float64
+    ones = torch.ones(n, 4, device=dev)
+    At1 = eng.backward(ones)[:, 0].double()
+    lhs = AX.double().sum(0)
+    rhs = (At1.unsqueeze(1) * X.double()).sum(0)
+    assert float((lhs - rhs).abs().max() / lhs.abs().max()) < 1e-5
+    # row sums of A_hat: A.1 computed by the kernel vs a float64 segment sum of the values
+    rs = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, row, val.double())
+    assert float((eng.forward(ones)[:, 0].double() - rs).abs().max() / rs.max()) < 1e-5
+    # symmetric matrix => backward operand gives the same product
+    assert float((eng.backward(X) - AX).abs().max() / AX.abs().max()) < 2e-5
+    # the oracle on a sample of rows (full CSR copied to the host once)
+    rows = np.sort(np.random.default_rng(0).choice(n, 600, replace=False)).astype(np.int32)
+    rp = p.A_loc.rowptr.cpu().numpy(); ci = p.A_loc.col.cpu().numpy(); va = p.A_loc.val.cpu().numpy()
+    Xh = X.cpu().numpy()
+    ref = np.zeros((n, f), np.float32)
+    L = oracle.lib()
+    L.oracle_spmm_csr_rows_f32(rows.size, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                               rp.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                               ci.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                               va.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                               Xh.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), f,
+                               ref.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), f, f, 0)
+    assert rel_err(AX.cpu().numpy()[rows], ref[rows]) < TOL
+
+
+def test_rccl_single_rank_comm(dev):
+    """C-ABI RCCL entry points on a 1-rank communicator (RCCL allows one rank per device)."""
+    _lib = pkg("_lib")
+    L = _lib.lib()
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(L.pgcn_comm_unique_id(uid), "unique_id")
+    comm = ctypes.c_void_p()
+    _lib.check(L.pgcn_comm_init(ctypes.byref(comm), uid, 1, 0), "comm_init")
+    buf = torch.arange(1000, dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.pgcn_allreduce_sum_f32(comm, buf.data_ptr(), buf.numel(), s), "allreduce")
+    off = (ctypes.c_int64 * 2)(0, 0)
+    _lib.check(L.pgcn_exchange_alltoallv_f32(comm, None, off, None, off, 128, s), "alltoallv")
+    bad = (ctypes.c_int64 * 2)(0, 3)
+    assert L.pgcn_exchange_alltoallv_f32(comm, None, bad, None, off, 128, s) == -1   # own segment non-empty
+    torch.cuda.synchronize()
+    assert torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float32))
+    _lib.check(L.pgcn_comm_destroy(comm), "comm_destroy")
