@@ -38,7 +38,9 @@ typedef void *pgcn_stream_t; /* hipStream_t */
 
 /* flags for the SpMM entry points */
 #define PGCN_SPMM_ACCUMULATE 1u  /* C += A.B instead of C = A.B                      */
-#define PGCN_SPMM_XCD_SWIZZLE 2u /* give each XCD (private L2) a contiguous row range */
+#define PGCN_SPMM_XCD_SWIZZLE 2u /* unsliced plans only: give each XCD a contiguous row range */
+#define PGCN_SPMM_OFFSETS32 4u   /* caller guarantees (max col + 1) * ldb * 4 < 2^32 bytes */
+#define PGCN_MAX_SLICES 8        /* = XCDs of an MI355X */
 
 int pgcn_abi_version(void);
 const char *pgcn_last_error(void);
@@ -58,25 +60,34 @@ int pgcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       int64_t nrows, const float *B, int64_t ldb, float *C, int64_t ldc,
                       int32_t f, uint32_t flags, pgcn_stream_t stream);
 
-/* Load-balanced variant driven by a plan (see pgcn_spmm_plan_host): rows longer
- * than the plan's chunk are split into segments whose partial sums go through
- * `partial_ws` (capacity partial_ws_elems >= nslots * f floats) and are combined in a fixed order by a second
- * kernel -- deterministic, no atomics on C.  row_map (optional, device) maps CSR
- * row r to output row row_map[r]: the row-subset form used for the boundary
- * pass of the interior/boundary split and for the reverse-exchange unpack.    */
+/* Load-balanced, XCD-sliced variant driven by a plan (see pgcn_spmm_plan_host).
+ * The entries of each row must be stored grouped by slice = col % nslices when the
+ * plan was built with nslices > 1; task segment s (seg[s]..seg[s+1], HOST array of
+ * nslices+1 entries) is executed by the workgroups with blockIdx % nslices == s, which
+ * the dispatcher places on XCD s: every private 4 MiB L2 then caches a disjoint 1/8 of
+ * the rows of B (placement only affects speed, never results).  Rows with several
+ * tasks combine their partial sums through `partial_ws` (capacity partial_ws_elems >=
+ * nslots * f floats) in a fixed order in a second kernel -- deterministic, no atomics
+ * on C.  row_map (optional, device) maps CSR row r to output row row_map[r]: the
+ * row-subset form used for the halo pass of the local/halo split.                  */
 int pgcn_spmm_csr_plan_f32(const int64_t *rowptr, const int32_t *col, const float *val,
-                           const int32_t *tasks, int64_t ntasks, const int32_t *fix,
-                           int64_t nfix, const int32_t *row_map, const float *B,
-                           int64_t ldb, float *C, int64_t ldc, int32_t f,
-                           float *partial_ws, int64_t partial_ws_elems, int64_t nslots,
-                           uint32_t flags, pgcn_stream_t stream);
+                           const int32_t *tasks, int64_t ntasks, const int64_t *seg,
+                           int32_t nslices, const int32_t *fix, int64_t nfix,
+                           const int32_t *row_map, const float *B, int64_t ldb, float *C,
+                           int64_t ldc, int32_t f, float *partial_ws, int64_t partial_ws_elems,
+                           int64_t nslots, uint32_t flags, pgcn_stream_t stream);
 
-/* Host-side plan builder (pure CPU, no HIP).  rowptr_host: nrows+1 entries.
- * tasks: 4 x int32 per task {row, offset within row, length, slot or -1}
- * fix:   4 x int32 per split row {row, first slot, #segments, 0}
+/* Host-side plan builder (pure CPU, no HIP).  rowptr_host: nrows+1 entries;
+ * slice_cnt: nrows x nslices entry counts per (row, slice) or NULL when nslices == 1.
+ * tasks: 4 x int32 per task {kbeg low, kbeg high, length, dst}: absolute offset of the
+ *        first entry, number of entries, dst >= 0 partial slot / dst < 0 direct row ~dst;
+ *        grouped by slice, longest first; seg (out, nslices+1) = segment boundaries.
+ * fix:   4 x int32 per multi-task row {row, first slot, #tasks, 0}
+ * Rows with <= small_row entries are not sliced (one direct task each).
  * Call with tasks == NULL to obtain the counts, then again with buffers.      */
-int pgcn_spmm_plan_host(const int64_t *rowptr_host, int64_t nrows, int32_t chunk,
-                        int32_t *tasks, int64_t cap_tasks, int32_t *fix, int64_t cap_fix,
+int pgcn_spmm_plan_host(const int64_t *rowptr_host, const int32_t *slice_cnt, int64_t nrows,
+                        int32_t nslices, int32_t chunk, int32_t small_row, int32_t *tasks,
+                        int64_t cap_tasks, int32_t *fix, int64_t cap_fix, int64_t *seg,
                         int64_t *ntasks, int64_t *nfix, int64_t *nslots);
 
 /* ---- boundary-row pack / unpack -------------------------------------------

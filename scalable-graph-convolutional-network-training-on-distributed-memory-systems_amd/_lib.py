@@ -21,6 +21,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpgcn_hip.so")
 PGCN_OK = 0
 SPMM_ACCUMULATE = 1
 SPMM_XCD_SWIZZLE = 2
+SPMM_OFFSETS32 = 4
+MAX_SLICES = 8
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -33,9 +35,9 @@ SIGNATURES = {
     "pgcn_last_error": (ctypes.c_char_p, []),
     "pgcn_device_info": (ctypes.c_int, [_i32, ctypes.POINTER(_i64)]),
     "pgcn_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _u32, _vp]),
-    "pgcn_spmm_csr_plan_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp,
-                                              _i64, _i32, _vp, _i64, _i64, _u32, _vp]),
-    "pgcn_spmm_plan_host": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i64,
+    "pgcn_spmm_csr_plan_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp,
+                                              _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),
+    "pgcn_spmm_plan_host": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp,
                                            ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                            ctypes.POINTER(_i64)]),
     "pgcn_gather_rows_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp]),

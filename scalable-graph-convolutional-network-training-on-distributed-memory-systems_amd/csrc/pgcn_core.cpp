@@ -1,7 +1,10 @@
 // pgcn_core.cpp -- error slot, ABI version, device query, host-side SpMM plan builder.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include "pgcn_internal.h"
 
@@ -37,53 +40,127 @@ extern "C" int pgcn_device_info(int32_t device, int64_t out[4]) {
     return PGCN_OK;
 }
 
-// Plan: rows with <= chunk entries become one task; longer rows are cut into
-// ceil(len/chunk) segments that write partial sums to consecutive slots and get
-// one fix-up record.  Empty rows still get a (zero-length) task so that C is
-// defined for them (C = 0, or C unchanged when accumulating).
-extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, int64_t nrows, int32_t chunk,
+// Plan.  Work is cut into TASKS = {kbeg lo, kbeg hi, length, dst}: `length` stored
+// entries starting at absolute offset kbeg; dst >= 0 is a partial-sum slot, dst < 0
+// means "write row ~dst of C directly".
+//   * nslices > 1 ("XCD-sliced"): the entries of every row are stored grouped by
+//     slice = col % nslices (slice_cnt[r*nslices + s] entries each); a task never
+//     crosses a slice, and the task list is grouped BY SLICE (seg[s]..seg[s+1]) so that
+//     the kernel can hand slice s to the workgroups that run on XCD s.  Each XCD's
+//     private L2 then only ever sees 1/nslices of the rows of B.
+//   * rows with at most `small_row` entries are NOT sliced: one task, direct write,
+//     placed round-robin over the segments (slicing them would multiply the per-task
+//     latency chain and the partial-sum traffic for a handful of entries).
+//   * pieces longer than `chunk` are cut into balanced segments.
+//   * a row with exactly one task writes C directly; a row with several tasks gets
+//     consecutive partial-sum slots and one fix-up record {row, first slot, #tasks},
+//     combined in slot order by the fix-up kernel (deterministic, no atomics).
+//   * empty rows still get one zero-length task so that C is defined for them.
+//   * inside every segment the tasks are ordered by decreasing length (stable):
+//     longest-first scheduling, and the tasks sharing a wavefront have equal trip counts.
+namespace {
+struct TaskRec { int64_t kbeg; int32_t len; int32_t dst; };
+}
+
+extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_cnt, int64_t nrows,
+                                   int32_t nslices, int32_t chunk, int32_t small_row,
                                    int32_t *tasks, int64_t cap_tasks, int32_t *fix,
-                                   int64_t cap_fix, int64_t *ntasks, int64_t *nfix,
-                                   int64_t *nslots) {
-    if (!rowptr || nrows < 0 || chunk <= 0 || !ntasks || !nfix || !nslots)
+                                   int64_t cap_fix, int64_t *seg, int64_t *ntasks,
+                                   int64_t *nfix, int64_t *nslots) {
+    if (!rowptr || nrows < 0 || chunk <= 0 || small_row < 0 || !ntasks || !nfix || !nslots || !seg ||
+        nslices < 1 || nslices > PGCN_MAX_SLICES || (nslices > 1 && !slice_cnt))
         return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: bad argument");
     if (nrows > 0x7fffffffLL) return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: nrows >= 2^31");
+    const int S = nslices;
+    if (small_row > chunk) small_row = chunk;
+    // pass 1: tasks per segment; slots per row
+    int64_t per_slice[PGCN_MAX_SLICES] = {0};
     int64_t nt = 0, nf = 0, ns = 0;
     for (int64_t r = 0; r < nrows; ++r) {
         const int64_t len = rowptr[r + 1] - rowptr[r];
         if (len < 0 || len > 0x7fffffffLL)
             return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: row pointer not monotone / row too long");
-        if (len <= chunk) {
-            if (tasks) {
-                if (nt >= cap_tasks) return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_plan_host: tasks capacity");
-                int32_t *t = tasks + 4 * nt;
-                t[0] = (int32_t)r; t[1] = 0; t[2] = (int32_t)len; t[3] = -1;
+        if (S > 1) {
+            int64_t sum = 0;
+            for (int s = 0; s < S; ++s) {
+                if (slice_cnt[r * S + s] < 0)
+                    return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: negative slice count");
+                sum += slice_cnt[r * S + s];
             }
-            ++nt;
-        } else {
-            const int64_t nseg = (len + chunk - 1) / chunk;
-            // balance the segments of one row (all within one entry of each other)
-            const int64_t seg = (len + nseg - 1) / nseg;
-            if (ns + nseg > 0x7fffffffLL) return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: too many slots");
-            if (fix) {
-                if (nf >= cap_fix) return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_plan_host: fix capacity");
-                int32_t *x = fix + 4 * nf;
-                x[0] = (int32_t)r; x[1] = (int32_t)ns; x[2] = (int32_t)nseg; x[3] = 0;
-            }
-            for (int64_t s = 0; s < nseg; ++s) {
-                const int64_t off = s * seg;
-                const int64_t l = (off + seg <= len) ? seg : (len - off);
-                if (tasks) {
-                    if (nt >= cap_tasks) return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_plan_host: tasks capacity");
-                    int32_t *t = tasks + 4 * nt;
-                    t[0] = (int32_t)r; t[1] = (int32_t)off; t[2] = (int32_t)(l > 0 ? l : 0); t[3] = (int32_t)(ns + s);
+            if (sum != len)
+                return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: slice counts do not add up to the row length");
+        }
+        if (len <= small_row || (S == 1 && len <= chunk)) {   // one unsliced task (also: empty row)
+            per_slice[r % S] += 1;
+            nt += 1;
+            continue;
+        }
+        int64_t row_tasks = 0;
+        for (int s = 0; s < S; ++s) {
+            const int64_t l = (S == 1) ? len : slice_cnt[r * S + s];
+            const int64_t k = (l + chunk - 1) / chunk;
+            per_slice[s] += k;
+            row_tasks += k;
+        }
+        nt += row_tasks;
+        if (row_tasks > 1) { ns += row_tasks; ++nf; }
+    }
+    if (ns > 0x7fffffffLL) return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: too many slots");
+    seg[0] = 0;
+    for (int s = 0; s < S; ++s) seg[s + 1] = seg[s] + per_slice[s];
+    *ntasks = nt; *nfix = nf; *nslots = ns;
+    if (!tasks) return PGCN_OK;
+    if (nt > cap_tasks) return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_plan_host: tasks capacity");
+    if (nf > 0 && (!fix || nf > cap_fix)) return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_plan_host: fix capacity");
+    // pass 2: emit into a scratch list, segment by segment
+    TaskRec *rec = (TaskRec *)malloc((size_t)(nt > 0 ? nt : 1) * sizeof(TaskRec));
+    if (!rec) return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_plan_host: out of host memory");
+    int64_t cur[PGCN_MAX_SLICES];
+    for (int s = 0; s < S; ++s) cur[s] = seg[s];
+    int64_t slot = 0, fi = 0;
+    for (int64_t r = 0; r < nrows; ++r) {
+        const int64_t len = rowptr[r + 1] - rowptr[r];
+        if (len <= small_row || (S == 1 && len <= chunk)) {
+            rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, ~(int32_t)r};
+            continue;
+        }
+        int64_t row_tasks = 0;
+        for (int s = 0; s < S; ++s) {
+            const int64_t l = (S == 1) ? len : slice_cnt[r * S + s];
+            row_tasks += (l + chunk - 1) / chunk;
+        }
+        const bool direct = row_tasks == 1;
+        if (!direct) {
+            int32_t *x = fix + 4 * fi++;
+            x[0] = (int32_t)r; x[1] = (int32_t)slot; x[2] = (int32_t)row_tasks; x[3] = 0;
+        }
+        int64_t off = 0;
+        for (int s = 0; s < S; ++s) {
+            const int64_t l = (S == 1) ? len : slice_cnt[r * S + s];
+            const int64_t k = (l + chunk - 1) / chunk;
+            if (k > 0) {
+                const int64_t piece = (l + k - 1) / k;   // balanced segments
+                for (int64_t j = 0; j < k; ++j) {
+                    const int64_t o = j * piece;
+                    const int64_t ll = (o + piece <= l) ? piece : (l - o);
+                    rec[cur[s]++] = TaskRec{rowptr[r] + off + o, (int32_t)ll,
+                                            direct ? ~(int32_t)r : (int32_t)slot++};
                 }
-                ++nt;
             }
-            ns += nseg;
-            ++nf;
+            off += l;
         }
     }
-    *ntasks = nt; *nfix = nf; *nslots = ns;
+    // longest first inside each segment
+    for (int s = 0; s < S; ++s)
+        std::stable_sort(rec + seg[s], rec + seg[s + 1],
+                         [](const TaskRec &a, const TaskRec &b) { return a.len > b.len; });
+    for (int64_t i = 0; i < nt; ++i) {
+        int32_t *t = tasks + 4 * i;
+        t[0] = (int32_t)(uint32_t)((uint64_t)rec[i].kbeg & 0xffffffffu);
+        t[1] = (int32_t)(uint32_t)((uint64_t)rec[i].kbeg >> 32);
+        t[2] = rec[i].len;
+        t[3] = rec[i].dst;
+    }
+    free(rec);
     return PGCN_OK;
 }

@@ -66,87 +66,154 @@ __device__ __forceinline__ int64_t swizzle_block(int64_t b, int64_t nb, bool on)
     return (b % 8) * per + b / 8;
 }
 
-// tasks: int4 {row, offset within row, length, slot (-1 = write C directly)}
-template <int LPR, int VEC>
-__global__ __launch_bounds__(kThreads) void spmm_tasks_kernel(
+struct SliceSeg { int64_t v[PGCN_MAX_SLICES + 1]; };
+
+template <int VEC>
+__device__ __forceinline__ void vfma(float (&acc)[VEC], float w, const float (&x)[VEC]) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, x[v], acc[v]);
+}
+
+// Row load of B.  OFF32: the caller guarantees that every byte offset into B fits 32 bits,
+// so the address is (uniform 64-bit base) + (32-bit lane offset): one v_mul_lo + v_add per
+// load and an SGPR base instead of a 64-bit multiply-add and two address VGPRs per load.
+template <int VEC, bool OFF32>
+__device__ __forceinline__ void load_row(float (&x)[VEC], const float *B, uint32_t lane_byte_off,
+                                         int32_t c, int64_t ldb) {
+    if constexpr (OFF32) {
+        const uint32_t off = (uint32_t)c * (uint32_t)(ldb * 4) + lane_byte_off;
+        vload<VEC>(x, reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off));
+    } else {
+        vload<VEC>(x, B + (int64_t)c * ldb + (lane_byte_off >> 2));
+    }
+}
+
+// tasks: int4 {kbeg low 32, kbeg high 32, length, dst}; kbeg = absolute offset of the task's
+// first entry in col/val; dst >= 0: partial-sum slot, dst < 0: write row ~dst of C directly.
+template <int LPR, int VEC, bool HAS_VAL, bool OFF32>
+__global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const int4 *__restrict__ tasks, int64_t ntasks,
     const int32_t *__restrict__ row_map, const float *__restrict__ B, int64_t ldb,
     float *__restrict__ C, int64_t ldc, int32_t f, float *__restrict__ partial,
-    int64_t nblocks, uint32_t flags) {
+    int64_t nblocks, uint32_t flags, int32_t nslices, SliceSeg seg) {
     constexpr int G = 64 / LPR;
+    constexpr int U = (LPR < kUnroll) ? LPR : kUnroll;   // gathers in flight per batch
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int grp = lane / LPR;
     const int sub = lane % LPR;
     const int gbase = grp * LPR;
 
-    const int64_t bid = swizzle_block(blockIdx.x, nblocks, (flags & PGCN_SPMM_XCD_SWIZZLE) != 0);
-    const int64_t tid = (bid * kWavesPerBlock + wave) * G + grp;
+    int64_t tid;
+    if (nslices > 1) {
+        // workgroup b runs on XCD b % 8: it takes tasks of slice b % nslices only, so
+        // this XCD's L2 sees just the rows of B with (col % nslices) == slice.
+        const int slice = blockIdx.x % nslices;
+        const int64_t sb = blockIdx.x / nslices;
+        tid = seg.v[slice] + (sb * kWavesPerBlock + wave) * G + grp;
+        ntasks = seg.v[slice + 1];
+    } else {
+        const int64_t bid = swizzle_block(blockIdx.x, nblocks, (flags & PGCN_SPMM_XCD_SWIZZLE) != 0);
+        tid = (bid * kWavesPerBlock + wave) * G + grp;
+    }
     const int fcol = (blockIdx.y * LPR + sub) * VEC;  // first feature owned by this lane
     const bool fact = fcol < f;
+    const bool tact = tid < ntasks;
+    const uint32_t lane_off = (uint32_t)fcol * 4u;
 
-    int32_t row = 0, len = 0, slot = -1;
+    int32_t len = 0, dst = -1;
     int64_t kbeg = 0;
-    if (tid < ntasks) {
+    if (tact) {
         if (tasks) {
             const int4 t = tasks[tid];
-            row = t.x; len = t.z; slot = t.w;
-            kbeg = rowptr[row] + t.y;
+            kbeg = (int64_t)(((uint64_t)(uint32_t)t.y << 32) | (uint32_t)t.x);
+            len = t.z;
+            dst = t.w;
         } else {  // one task per row
-            row = (int32_t)tid;
-            kbeg = rowptr[row];
-            len = (int32_t)(rowptr[row + 1] - kbeg);
+            kbeg = rowptr[tid];
+            len = (int32_t)(rowptr[tid + 1] - kbeg);
+            dst = ~(int32_t)tid;
         }
     }
-    const bool tact = tid < ntasks;
 
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
 
-    const float *Bl = B + fcol;
-
+    // (col,val) pairs: one per lane, streamed once -> non-temporal.  The loads are
+    // UNCONDITIONAL (index clamped into the task; an empty / inactive group reads a
+    // harmless valid word of rowptr) so that the prefetch of the next LPR pairs stays in
+    // flight behind the gathers instead of being fenced at a branch join.
+    const int32_t *cp = (len > 0) ? col + kbeg : reinterpret_cast<const int32_t *>(rowptr);
+    const float *vp = (len > 0) ? val + kbeg : reinterpret_cast<const float *>(rowptr);
+    const int last = (len > 0) ? len - 1 : 0;
+    int32_t nc;
+    float nv = 1.f;
+    {
+        const int e = (sub < last) ? sub : last;
+        nc = __builtin_nontemporal_load(cp + e);
+        if constexpr (HAS_VAL) nv = __builtin_nontemporal_load(vp + e);
+    }
     for (int base = 0; __any(base < len); base += LPR) {
-        // one (col,val) pair per lane, streamed once -> non-temporal
-        int32_t my_c = 0;
-        float my_v = 0.f;
-        const int e = base + sub;
-        if (e < len) {
-            my_c = __builtin_nontemporal_load(col + kbeg + e);
-            my_v = val ? __builtin_nontemporal_load(val + kbeg + e) : 1.f;
+        const int32_t my_c = nc;
+        const float my_v = nv;
+        {
+            int e = base + LPR + sub;
+            e = (e < last) ? e : last;
+            nc = __builtin_nontemporal_load(cp + e);
+            if constexpr (HAS_VAL) nv = __builtin_nontemporal_load(vp + e);
         }
-        const int cnt = len - base;  // edges left for this group (may be <= 0)
-        for (int k = 0; k < LPR; k += kUnroll) {
-            if (!__any(k < cnt)) break;
-            float x[kUnroll][VEC];
-            float w[kUnroll];
+        const int cnt = len - base;  // entries left for this group (may be <= 0)
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                if (k + u < LPR) {  // compile-time for LPR < kUnroll
-                    const int src = gbase + k + u;
-                    const int32_t c = __shfl(my_c, src);
-                    w[u] = __shfl(my_v, src);
-                    const bool p = fact && (k + u < cnt);
+        for (int k = 0; k < LPR; k += U) {
+            if (__all(k + U <= cnt)) {
+                // fast path: every group of the wave has U more entries.  All broadcasts
+                // first, then U independent unpredicated row loads, then the FMAs.
+                int32_t c[U];
+                float w[U];
+                float x[U][VEC];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
-                    if (p) vload<VEC>(x[u], Bl + (int64_t)c * ldb);
+                for (int u = 0; u < U; ++u) {
+                    c[u] = __shfl(my_c, gbase + k + u);
+                    w[u] = HAS_VAL ? __shfl(my_v, gbase + k + u) : 1.f;
                 }
-            }
+                if (fact) {
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                if (k + u < LPR) {
+                    for (int u = 0; u < U; ++u) load_row<VEC, OFF32>(x[u], B, lane_off, c[u], ldb);
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+                    for (int u = 0; u < U; ++u) vfma<VEC>(acc, w[u], x[u]);
+                }
+            } else if (__any(k < cnt)) {
+                // ragged tail of a task (or groups of different length): predicated loads,
+                // so rows that are not referenced are never touched (no 0 * Inf).
+#pragma unroll
+                for (int u0 = 0; u0 < U; u0 += 4) {
+                    float x[4][VEC];
+                    float w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (u0 + u < U) {
+                            const int32_t cc = __shfl(my_c, gbase + k + u0 + u);
+                            w[u] = HAS_VAL ? __shfl(my_v, gbase + k + u0 + u) : 1.f;
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
+                            if (fact && (k + u0 + u < cnt)) load_row<VEC, OFF32>(x[u], B, lane_off, cc, ldb);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u0 + u < U) vfma<VEC>(acc, w[u], x[u]);
                 }
             }
         }
     }
 
     if (tact && fact) {
-        if (slot >= 0) {
-            vstore<VEC>(partial + (int64_t)slot * f + fcol, acc);
+        if (dst >= 0) {
+            vstore<VEC>(partial + (int64_t)dst * f + fcol, acc);
         } else {
+            const int32_t row = ~dst;
             const int64_t orow = row_map ? row_map[row] : row;
             float *c = C + orow * ldc + fcol;
             if (flags & PGCN_SPMM_ACCUMULATE) {
@@ -182,9 +249,20 @@ __global__ __launch_bounds__(kThreads) void spmm_fixup_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
     if (flags & PGCN_SPMM_ACCUMULATE) vload<VEC>(acc, c);
-    for (int s = 0; s < t.z; ++s) {
+    const float *p = partial + (int64_t)t.y * f + fcol;
+    int s = 0;
+    for (; s + 4 <= t.z; s += 4) {   // four independent loads in flight, summed in slot order
+        float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
+        vload<VEC>(x0, p + (int64_t)(s + 0) * f);
+        vload<VEC>(x1, p + (int64_t)(s + 1) * f);
+        vload<VEC>(x2, p + (int64_t)(s + 2) * f);
+        vload<VEC>(x3, p + (int64_t)(s + 3) * f);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = (((acc[v] + x0[v]) + x1[v]) + x2[v]) + x3[v];
+    }
+    for (; s < t.z; ++s) {
         float x[VEC];
-        vload<VEC>(x, partial + (int64_t)(t.y + s) * f + fcol);
+        vload<VEC>(x, p + (int64_t)s * f);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] += x[v];
     }
@@ -204,23 +282,52 @@ Shape pick_shape(int32_t f, const void *B, int64_t ldb, const void *C, int64_t l
     return {lpr, vec};
 }
 
+template <int LPR, int VEC, bool HAS_VAL, bool OFF32>
+int launch_tasks(const int64_t *rowptr, const int32_t *col, const float *val, const int4 *tasks,
+                 int64_t ntasks, const int32_t *row_map, const float *B, int64_t ldb, float *C,
+                 int64_t ldc, int32_t f, float *partial, int64_t grid, int ntiles, uint32_t flags,
+                 int nslices, const SliceSeg &seg, hipStream_t s) {
+    hipLaunchKernelGGL((spmm_tasks_kernel<LPR, VEC, HAS_VAL, OFF32>), dim3((unsigned)grid, ntiles),
+                       dim3(kThreads), 0, s, rowptr, col, val, tasks, ntasks, row_map, B, ldb, C, ldc,
+                       f, partial, grid, flags, nslices, seg);
+    PGCN_HIP_CHECK(hipGetLastError());
+    return PGCN_OK;
+}
+
 template <int LPR, int VEC>
 int launch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *tasks,
-           int64_t ntasks, const int32_t *fix, int64_t nfix, const int32_t *row_map,
+           int64_t ntasks, const int64_t *seg_host, int nslices, const int32_t *fix, int64_t nfix,
+           const int32_t *row_map,
            const float *B, int64_t ldb, float *C, int64_t ldc, int32_t f, float *partial,
            uint32_t flags, hipStream_t s) {
     constexpr int G = 64 / LPR;
     const int ntiles = (f + LPR * VEC - 1) / (LPR * VEC);
     if (ntasks > 0) {
         const int64_t per_block = (int64_t)kWavesPerBlock * G;
-        int64_t nblocks = (ntasks + per_block - 1) / per_block;
-        int64_t grid = nblocks;
-        if (flags & PGCN_SPMM_XCD_SWIZZLE) grid = ((nblocks + 7) / 8) * 8;
+        SliceSeg seg{};
+        int64_t grid;
+        if (nslices > 1) {
+            int64_t longest = 0;
+            for (int i = 0; i <= nslices; ++i) seg.v[i] = seg_host[i];
+            for (int i = 0; i < nslices; ++i)
+                if (seg.v[i + 1] - seg.v[i] > longest) longest = seg.v[i + 1] - seg.v[i];
+            grid = ((longest + per_block - 1) / per_block) * nslices;
+        } else {
+            const int64_t nblocks = (ntasks + per_block - 1) / per_block;
+            grid = nblocks;
+            if (flags & PGCN_SPMM_XCD_SWIZZLE) grid = ((nblocks + 7) / 8) * 8;
+        }
         if (grid > 0x7fffffffLL) return pgcn_set_error(PGCN_EINVAL, "spmm: too many tasks for one launch");
-        hipLaunchKernelGGL((spmm_tasks_kernel<LPR, VEC>), dim3((unsigned)grid, ntiles), dim3(kThreads),
-                           0, s, rowptr, col, val, reinterpret_cast<const int4 *>(tasks), ntasks,
-                           row_map, B, ldb, C, ldc, f, partial, grid, flags);
-        PGCN_HIP_CHECK(hipGetLastError());
+        const int4 *t4 = reinterpret_cast<const int4 *>(tasks);
+        const bool off32 = (flags & PGCN_SPMM_OFFSETS32) != 0;
+        int rc;
+#define PGCN_LT(HV, O32)                                                                        \
+    rc = launch_tasks<LPR, VEC, HV, O32>(rowptr, col, val, t4, ntasks, row_map, B, ldb, C, ldc, f, \
+                                         partial, grid, ntiles, flags, nslices, seg, s)
+        if (val) { if (off32) PGCN_LT(true, true); else PGCN_LT(true, false); }
+        else     { if (off32) PGCN_LT(false, true); else PGCN_LT(false, false); }
+#undef PGCN_LT
+        if (rc != PGCN_OK) return rc;
     }
     if (nfix > 0) {
         const int64_t per_block = (int64_t)kWavesPerBlock * G;
@@ -234,14 +341,15 @@ int launch(const int64_t *rowptr, const int32_t *col, const float *val, const in
 }
 
 int dispatch(const int64_t *rowptr, const int32_t *col, const float *val, const int32_t *tasks,
-             int64_t ntasks, const int32_t *fix, int64_t nfix, const int32_t *row_map,
+             int64_t ntasks, const int64_t *seg, int nslices, const int32_t *fix, int64_t nfix,
+             const int32_t *row_map,
              const float *B, int64_t ldb, float *C, int64_t ldc, int32_t f, float *partial,
              uint32_t flags, hipStream_t s) {
     const Shape sh = pick_shape(f, B, ldb, C, ldc, partial);
 #define PGCN_CASE(L, V)                                                                       \
     if (sh.lpr == L && sh.vec == V)                                                           \
-        return launch<L, V>(rowptr, col, val, tasks, ntasks, fix, nfix, row_map, B, ldb, C,   \
-                            ldc, f, partial, flags, s);
+        return launch<L, V>(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, row_map, \
+                            B, ldb, C, ldc, f, partial, flags, s);
     PGCN_CASE(1, 4) PGCN_CASE(2, 4) PGCN_CASE(4, 4) PGCN_CASE(8, 4) PGCN_CASE(16, 4)
     PGCN_CASE(32, 4) PGCN_CASE(64, 4)
     PGCN_CASE(1, 1) PGCN_CASE(2, 1) PGCN_CASE(4, 1) PGCN_CASE(8, 1) PGCN_CASE(16, 1)
@@ -261,23 +369,27 @@ extern "C" int pgcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     if (!rowptr || !col || !B || !C)
         return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_csr_f32: null pointer");
     if (nrows > 0x7fffffffLL) return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_csr_f32: nrows >= 2^31");
-    return dispatch(rowptr, col, val, nullptr, nrows, nullptr, 0, nullptr, B, ldb, C, ldc, f,
-                    nullptr, flags, (hipStream_t)stream);
+    return dispatch(rowptr, col, val, nullptr, nrows, nullptr, 1, nullptr, 0, nullptr, B, ldb, C,
+                    ldc, f, nullptr, flags, (hipStream_t)stream);
 }
 
 extern "C" int pgcn_spmm_csr_plan_f32(const int64_t *rowptr, const int32_t *col, const float *val,
-                                      const int32_t *tasks, int64_t ntasks, const int32_t *fix,
-                                      int64_t nfix, const int32_t *row_map, const float *B,
-                                      int64_t ldb, float *C, int64_t ldc, int32_t f,
-                                      float *partial_ws, int64_t partial_ws_elems, int64_t nslots,
-                                      uint32_t flags, pgcn_stream_t stream) {
-    if (ntasks < 0 || nfix < 0 || f <= 0 || ldb < f || ldc < f)
+                                      const int32_t *tasks, int64_t ntasks, const int64_t *seg,
+                                      int32_t nslices, const int32_t *fix, int64_t nfix,
+                                      const int32_t *row_map, const float *B, int64_t ldb,
+                                      float *C, int64_t ldc, int32_t f, float *partial_ws,
+                                      int64_t partial_ws_elems, int64_t nslots, uint32_t flags,
+                                      pgcn_stream_t stream) {
+    if (ntasks < 0 || nfix < 0 || f <= 0 || ldb < f || ldc < f || nslices < 1 ||
+        nslices > PGCN_MAX_SLICES || (nslices > 1 && !seg))
         return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_csr_plan_f32: bad sizes");
+    if (nslices > 1 && (seg[0] != 0 || seg[nslices] != ntasks))
+        return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_csr_plan_f32: seg does not cover the task list");
     if (ntasks == 0) return PGCN_OK;
     if (!rowptr || !col || !B || !C || !tasks || (nfix > 0 && (!fix || !partial_ws)))
         return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_csr_plan_f32: null pointer");
     if (nslots < 0 || (nfix > 0 && partial_ws_elems < nslots * (int64_t)f))
         return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_csr_plan_f32: partial work-space too small");
-    return dispatch(rowptr, col, val, tasks, ntasks, fix, nfix, row_map, B, ldb, C, ldc, f,
-                    partial_ws, flags, (hipStream_t)stream);
+    return dispatch(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, row_map, B, ldb, C,
+                    ldc, f, partial_ws, flags, (hipStream_t)stream);
 }

@@ -24,7 +24,8 @@ import torch
 from . import _lib
 from .partition import HostCSR
 
-DEFAULT_CHUNK = int(os.environ.get("PGCN_SPMM_CHUNK", "1024"))
+DEFAULT_CHUNK = int(os.environ.get("PGCN_SPMM_CHUNK", "512"))
+DEFAULT_SMALL_ROW = int(os.environ.get("PGCN_SPMM_SMALL_ROW", "96"))
 
 
 @dataclass
@@ -42,6 +43,8 @@ class DeviceCSR:
     ntasks: int = 0
     nfix: int = 0
     nslots: int = 0
+    nslices: int = 1
+    seg: Optional[object] = None          # ctypes int64[nslices+1] (host) task segment bounds
     ws: Optional[torch.Tensor] = None     # fp32 work-space for split rows (grown on demand)
 
     def alg_bytes(self, f: int, n_cols_touched: Optional[int] = None, n_rows_out: Optional[int] = None) -> int:
@@ -52,25 +55,33 @@ class DeviceCSR:
         return 8 * self.nnz + 8 * (self.nrows + 1) + 4 * f * nc + 4 * f * nr
 
 
-def build_plan(rowptr_host: np.ndarray, chunk: int):
-    """Host-side split of long rows (pgcn_spmm_plan_host).  Returns (tasks, fix, nslots)
-    as numpy int32 arrays; tasks is None when no row exceeds ``chunk`` (the
-    one-task-per-row kernel path needs no plan)."""
+def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarray] = None,
+               small_row: int = DEFAULT_SMALL_ROW, force: bool = False):
+    """Host-side task list (pgcn_spmm_plan_host).  Returns (tasks, fix, nslots, seg) with
+    numpy int32 arrays; tasks is None when the plan is trivial (unsliced and no row
+    exceeds ``chunk``): the one-task-per-row kernel path needs no plan."""
     L = _lib.lib()
     rowptr_host = np.ascontiguousarray(rowptr_host, dtype=np.int64)
     nrows = rowptr_host.shape[0] - 1
+    S = 1
+    sc_ptr = None
+    if slice_cnt is not None:
+        slice_cnt = np.ascontiguousarray(slice_cnt, dtype=np.int32)
+        S = slice_cnt.shape[1]
+        sc_ptr = slice_cnt.ctypes.data
+    seg = (ctypes.c_int64 * (S + 1))()
     nt, nf, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, nrows, chunk, None, 0, None, 0,
-                                     ctypes.byref(nt), ctypes.byref(nf), ctypes.byref(ns)),
+    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, nrows, S, chunk, small_row, None, 0,
+                                     None, 0, seg, ctypes.byref(nt), ctypes.byref(nf), ctypes.byref(ns)),
                "pgcn_spmm_plan_host")
-    if nf.value == 0:
-        return None, None, 0
+    if nf.value == 0 and S == 1 and not force:
+        return None, None, 0, None
     tasks = np.empty((nt.value, 4), dtype=np.int32)
-    fix = np.empty((nf.value, 4), dtype=np.int32)
-    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, nrows, chunk, tasks.ctypes.data,
-                                     nt.value, fix.ctypes.data, nf.value, ctypes.byref(nt),
+    fix = np.empty((max(nf.value, 1), 4), dtype=np.int32)
+    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, nrows, S, chunk, small_row,
+                                     tasks.ctypes.data, nt.value, fix.ctypes.data, nf.value, seg, ctypes.byref(nt),
                                      ctypes.byref(nf), ctypes.byref(ns)), "pgcn_spmm_plan_host")
-    return tasks, fix, int(ns.value)
+    return tasks, fix[:nf.value], int(ns.value), seg
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -82,7 +93,8 @@ class HipKernels:
 
     name = "hip"
 
-    def __init__(self, device: torch.device, xcd_swizzle: Optional[bool] = None, chunk: int = DEFAULT_CHUNK):
+    def __init__(self, device: torch.device, xcd_swizzle: Optional[bool] = None, chunk: int = DEFAULT_CHUNK,
+                 small_row: int = DEFAULT_SMALL_ROW):
         if not torch.cuda.is_available():
             raise _lib.PgcnError("HipKernels needs a HIP device: torch.cuda.is_available() is False "
                                  "(this package has no CPU fallback)")
@@ -94,12 +106,15 @@ class HipKernels:
             xcd_swizzle = os.environ.get("PGCN_XCD_SWIZZLE", "1") != "0"
         self.base_flags = _lib.SPMM_XCD_SWIZZLE if xcd_swizzle else 0
         self.chunk = chunk
+        self.small_row = small_row
 
     # -- data placement -------------------------------------------------
     def prepare(self, csr: HostCSR, pattern_only: bool = False) -> DeviceCSR:
         dev = self.device
         rowptr_host = csr.rowptr.detach().cpu().numpy()
-        tasks, fix, nslots = build_plan(rowptr_host, self.chunk)
+        sc = None if csr.slice_cnt is None else csr.slice_cnt.detach().cpu().numpy()
+        tasks, fix, nslots, seg = build_plan(rowptr_host, self.chunk, sc, self.small_row,
+                                             force=csr.row_map is not None)
         d = DeviceCSR(
             nrows=csr.nrows, ncols=csr.ncols, nnz=csr.nnz,
             rowptr=csr.rowptr.to(dev, torch.int64).contiguous(),
@@ -108,8 +123,9 @@ class HipKernels:
             row_map=None if csr.row_map is None else csr.row_map.to(dev, torch.int32).contiguous())
         if tasks is not None:
             d.tasks = torch.from_numpy(tasks).to(dev)
-            d.fix = torch.from_numpy(fix).to(dev)
+            d.fix = torch.from_numpy(fix).to(dev) if fix.shape[0] else None
             d.ntasks, d.nfix, d.nslots = tasks.shape[0], fix.shape[0], nslots
+            d.nslices, d.seg = csr.nslices if sc is not None else 1, seg
         return d
 
     # -- kernels ----------------------------------------------------------
@@ -132,26 +148,28 @@ class HipKernels:
         if A.row_map is None and C.shape[0] < A.nrows:
             raise _lib.PgcnError("C has too few rows")
         flags = self.base_flags | (_lib.SPMM_ACCUMULATE if accumulate else 0)
+        if (A.ncols + 1) * B.stride(0) * 4 < 2 ** 32:
+            flags |= _lib.SPMM_OFFSETS32
         if A.nrows == 0:
+            return C
+        if A.nnz == 0:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
+            if not accumulate:
+                if A.row_map is None:
+                    C[:A.nrows].zero_()
+                else:
+                    C.index_fill_(0, A.row_map.long(), 0.0)
             return C
         if A.tasks is None and A.row_map is None:
             _lib.check(self.lib.pgcn_spmm_csr_f32(
                 A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.nrows, B.data_ptr(),
                 B.stride(0), C.data_ptr(), C.stride(0), f, flags, self._stream()), "pgcn_spmm_csr_f32")
             return C
-        if A.tasks is None:  # row_map without split rows: trivial plan, built once
-            t = torch.zeros((A.nrows, 4), dtype=torch.int32)
-            t[:, 0] = torch.arange(A.nrows, dtype=torch.int32)
-            rp = A.rowptr.cpu()
-            t[:, 2] = (rp[1:] - rp[:-1]).to(torch.int32)
-            t[:, 3] = -1
-            A.tasks, A.ntasks = t.to(self.device), A.nrows
         need = A.nslots * f
         if A.nfix and (A.ws is None or A.ws.numel() < need):
             A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.pgcn_spmm_csr_plan_f32(
             A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.tasks.data_ptr(), A.ntasks,
-            _ptr(A.fix), A.nfix, _ptr(A.row_map), B.data_ptr(), B.stride(0), C.data_ptr(),
+            A.seg, A.nslices, _ptr(A.fix), A.nfix, _ptr(A.row_map), B.data_ptr(), B.stride(0), C.data_ptr(),
             C.stride(0), f, _ptr(A.ws), 0 if A.ws is None else A.ws.numel(), A.nslots, flags,
             self._stream()), "pgcn_spmm_csr_plan_f32")
         return C

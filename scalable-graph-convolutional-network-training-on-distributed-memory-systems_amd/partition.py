@@ -22,6 +22,7 @@ results are bit-exact by construction (checked against the reference's maps).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -37,19 +38,35 @@ class HostCSR:
     col: torch.Tensor
     val: torch.Tensor
     row_map: Optional[torch.Tensor] = None  # compact row r -> output row row_map[r] (int32)
+    nslices: int = 1                          # entries of a row are grouped by col % nslices
+    slice_cnt: Optional[torch.Tensor] = None  # int32 [nrows, nslices] entries per (row, slice)
 
     @property
     def nnz(self) -> int:
         return int(self.col.numel())
 
 
+# XCD-sliced storage: above this many columns the dense panel no longer fits a 4 MiB L2
+# at any realistic width, so rows are stored grouped by (col % 8) -- one slice per XCD.
+SLICE_MIN_COLS = int(os.environ.get("PGCN_SLICE_MIN_COLS", "16384"))
+NSLICES = int(os.environ.get("PGCN_SLICES", "8"))
+
+
+def pick_nslices(ncols: int) -> int:
+    return NSLICES if (NSLICES > 1 and ncols >= SLICE_MIN_COLS) else 1
+
+
 def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
-                 compact_rows: bool = False) -> HostCSR:
-    """Sort (r, c) lexicographically and build CSR.  Duplicate entries are kept as
+                 compact_rows: bool = False, nslices: Optional[int] = None) -> HostCSR:
+    """Sort by (row, col % nslices, col) and build CSR.  Duplicate entries are kept as
     separate stored entries (an uncoalesced COO sums them, PGCN.py:63)."""
     dev = r.device
+    if nslices is None:
+        nslices = pick_nslices(ncols)
+    S = nslices
     if r.numel():
-        key = r.to(torch.int64) * max(ncols, 1) + c.to(torch.int64)
+        r64, c64 = r.to(torch.int64), c.to(torch.int64)
+        key = (r64 * S + c64 % S) * max(ncols, 1) + c64
         order = torch.argsort(key, stable=True)
         r, c, v = r[order], c[order], v[order]
     row_map = None
@@ -61,8 +78,24 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
         torch.zeros(nrows, dtype=torch.int64, device=dev)
     rowptr = torch.zeros(nrows + 1, dtype=torch.int64, device=dev)
     rowptr[1:] = torch.cumsum(counts, 0)
+    slice_cnt = None
+    if S > 1:
+        if r.numel():
+            slice_cnt = torch.bincount(r.to(torch.int64) * S + c.to(torch.int64) % S,
+                                       minlength=nrows * S).to(torch.int32).reshape(nrows, S)
+        else:
+            slice_cnt = torch.zeros((nrows, S), dtype=torch.int32, device=dev)
     return HostCSR(nrows, ncols, rowptr, c.to(torch.int32).contiguous(),
-                   v.to(torch.float32).contiguous(), row_map)
+                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt)
+
+
+def csr_from_scipy(A, nslices: Optional[int] = None) -> HostCSR:
+    """Convenience for tests / tools: a scipy sparse matrix -> HostCSR (optionally sliced)."""
+    import numpy as np
+    A = A.tocoo()
+    return csr_from_coo(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
+                        torch.from_numpy(A.data.astype(np.float32)), A.shape[0], A.shape[1],
+                        nslices=nslices)
 
 
 @dataclass

@@ -45,8 +45,8 @@ def _host_csr(A):
                              torch.from_numpy(A.data.astype(np.float32)))
 
 
-def _spmm_gpu(K, dev, A, B, chunk=None, accumulate_into=None):
-    h = _host_csr(A)
+def _spmm_gpu(K, dev, A, B, chunk=None, accumulate_into=None, nslices=1):
+    h = _host_csr(A) if nslices == 1 else pkg("partition").csr_from_scipy(A, nslices)
     if chunk is not None:
         old, K.chunk = K.chunk, chunk
     d = K.prepare(h)
@@ -70,13 +70,15 @@ def test_library_and_device(K):
 
 @pytest.mark.parametrize("mtx", ["karate.mtx", "gemat11.mtx", "gemat11p.A.mtx"])
 @pytest.mark.parametrize("f", [1, 2, 3, 4, 8, 16, 20, 64, 100, 128, 256, 300, 512])
-def test_spmm_matches_oracle(K, dev, mtx, f):
+@pytest.mark.parametrize("nslices", [1, 8])
+def test_spmm_matches_oracle(K, dev, mtx, f, nslices):
     A = sp.csr_matrix(mmread(gpath(mtx))).astype(np.float32)
     rng = np.random.default_rng(f)
     B = rng.random((A.shape[1], f), dtype=np.float32) * 2 - 1
-    got, _ = _spmm_gpu(K, dev, A, B)
+    got, d = _spmm_gpu(K, dev, A, B, nslices=nslices)
+    assert d.nslices == nslices
     assert rel_err(got, oracle.spmm(A, B)) < TOL
-    got_t, _ = _spmm_gpu(K, dev, sp.csr_matrix(A.T), B)          # backward operand (A^T)
+    got_t, _ = _spmm_gpu(K, dev, sp.csr_matrix(A.T), B, nslices=nslices)   # backward operand (A^T)
     assert rel_err(got_t, oracle.spmm(sp.csr_matrix(A.T), B)) < TOL
 
 
@@ -94,7 +96,8 @@ def test_spmm_unaligned_leading_dimension(K, dev):
 
 
 @pytest.mark.parametrize("f", [2, 16, 128, 260])
-def test_spmm_split_long_rows_deterministic(K, dev, f):
+@pytest.mark.parametrize("nslices", [1, 8, 3])
+def test_spmm_split_long_rows_deterministic(K, dev, f, nslices):
     """Rows longer than the plan chunk go through partial slots + the fix-up kernel."""
     synth = pkg("synth")
     n, row, col, val = synth.make_graph(4000, 400000, seed=2)
@@ -103,15 +106,15 @@ def test_spmm_split_long_rows_deterministic(K, dev, f):
     rng = np.random.default_rng(0)
     B = rng.random((n, f), dtype=np.float32) * 2 - 1
     ref = oracle.spmm(A, B)
-    got, d = _spmm_gpu(K, dev, A, B, chunk=128)
+    got, d = _spmm_gpu(K, dev, A, B, chunk=128, nslices=nslices)
     assert d.nfix > 0 and d.nslots > d.nfix
     assert rel_err(got, ref) < TOL
-    got2, _ = _spmm_gpu(K, dev, A, B, chunk=128)
+    got2, _ = _spmm_gpu(K, dev, A, B, chunk=128, nslices=nslices)
     np.testing.assert_array_equal(got, got2)                      # no atomics => bit-reproducible
     base = rng.random((n, f), dtype=np.float32)
-    acc, _ = _spmm_gpu(K, dev, A, B, chunk=128, accumulate_into=base)
+    acc, _ = _spmm_gpu(K, dev, A, B, chunk=128, accumulate_into=base, nslices=nslices)
     assert rel_err(acc, ref + base) < TOL
-    acc1, _ = _spmm_gpu(K, dev, A, B, accumulate_into=base)        # unsplit accumulate
+    acc1, _ = _spmm_gpu(K, dev, A, B, accumulate_into=base, nslices=nslices)   # unsplit accumulate
     assert rel_err(acc1, ref + base) < TOL
 
 

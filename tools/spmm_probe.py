@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""In-process A/B probe of SpMM variants on the benchmark graph (run under gpurun).
+Interleaved rounds, HIP-event timing, median / min per variant (methodology rule 24)."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd"
+pkg = lambda s: importlib.import_module(PKG + "." + s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="reddit")
+    ap.add_argument("--f", type=int, default=128)
+    ap.add_argument("--rounds", type=int, default=8)
+    ap.add_argument("--variants", default="s1c1024,s8c1024,s8c512,s8c256,s8c2048")
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--once", default=None, help="run one variant once (for rocprofv3 --pmc)")
+    args = ap.parse_args()
+    synth, partition, kernels = pkg("synth"), pkg("partition"), pkg("kernels")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    n, row, col, val = synth.make_graph(args.workload, seed=0, device=dev)
+    nnz = row.numel()
+    f = args.f
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    B = torch.rand(n, f, device=dev, generator=gen) * 2 - 1
+    K = kernels.HipKernels(dev)
+    variants = {}
+    names = [args.once] if args.once else args.variants.split(",")
+    for name in names:
+        # name: s<slices>c<chunk>[x] (x = xcd swizzle for unsliced)
+        S = int(name[1:name.index("c")])
+        rest = name[name.index("c") + 1:]
+        sw = rest.endswith("x")
+        chunk = int(rest.rstrip("x"))
+        h = partition.csr_from_coo(row, col, val, n, n, nslices=S)
+        K.chunk = chunk
+        d = K.prepare(h)
+        variants[name] = (d, sw)
+    alg = 8 * nnz + 8 * (n + 1) + 2 * 4 * f * n
+    C = torch.empty(n, f, device=dev)
+
+    def run(name):
+        d, sw = variants[name]
+        K.base_flags = 2 if sw else 0
+        K.spmm(d, B, C)
+
+    if args.once:
+        for _ in range(3):
+            run(args.once)
+        torch.cuda.synchronize()
+        return
+    ref = None
+    times = {k: [] for k in variants}
+    for name in variants:
+        run(name); run(name)
+        if args.check:
+            if ref is None:
+                ref = C.clone()
+            else:
+                print(name, "max rel diff vs first:", float((C - ref).abs().max() / ref.abs().max()))
+    torch.cuda.synchronize()
+    for r in range(args.rounds):
+        for name in variants:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(name); e1.record()
+            torch.cuda.synchronize()
+            times[name].append(e0.elapsed_time(e1))
+    out = {}
+    for name, ts in times.items():
+        med, mn = float(np.median(ts)), float(np.min(ts))
+        d = variants[name][0]
+        out[name] = {"median_ms": med, "min_ms": mn, "alg_GBs": alg / med / 1e6, "gather_TBs": 4 * f * nnz / med / 1e9,
+                     "ntasks": d.ntasks, "nslots": d.nslots}
+        print("%-12s median %.3f ms  min %.3f ms  alg %.0f GB/s (%.2f%% of 8 TB/s)  gather %.1f TB/s  tasks %d"
+              % (name, med, mn, alg / med / 1e6, 100 * alg / med / 1e6 / 8000, 4 * f * nnz / med / 1e9, d.ntasks))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "spmm_probe.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
