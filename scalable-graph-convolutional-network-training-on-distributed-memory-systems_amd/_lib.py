@@ -85,6 +85,16 @@ def lib():
     return _LIB
 
 
+def load_variant(path: str):
+    """Load ANOTHER build of the library (A/B probes: tools/ab_build.sh); typed like lib()."""
+    L = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != PGCN_OK:
         msg = lib().pgcn_last_error().decode("utf-8", "replace")

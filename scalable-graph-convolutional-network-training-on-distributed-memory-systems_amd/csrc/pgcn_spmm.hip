@@ -14,8 +14,8 @@
 //     1 KiB global_load_dwordx4 the L1 likes).  G = 64/LPR tasks per wave.
 //   * (col,val) pairs of a task are fetched LPR at a time, one pair per lane
 //     (coalesced, non-temporal: they are streamed exactly once and must not
-//     evict feature rows from the per-XCD L2), then broadcast inside the
-//     group with ds_bpermute (LDS crossbar, no LDS memory).
+//     evict feature rows from the per-XCD L2), parked in 512 B of LDS per wave
+//     and broadcast inside the group with ds_read_b128 (2 pairs per read).
 //   * the gather loop is unrolled x8 so each wave keeps eight independent
 //     row-loads in flight; fp32 FMA accumulation in registers; no atomics.
 //   * rows longer than the plan's chunk are split; segment partial sums go to
@@ -39,6 +39,10 @@ template <int VEC> struct VecT;
 template <> struct VecT<1> { using type = float; };
 template <> struct VecT<2> { using type = float2; };
 template <> struct VecT<4> { using type = float4; };
+
+#ifndef PGCN_GATHER_NT
+#define PGCN_GATHER_NT 0
+#endif
 
 template <int VEC>
 __device__ __forceinline__ void vload(float (&x)[VEC], const float *p) {
@@ -80,12 +84,21 @@ __device__ __forceinline__ void vfma(float (&acc)[VEC], float w, const float (&x
 template <int VEC, bool OFF32>
 __device__ __forceinline__ void load_row(float (&x)[VEC], const float *B, uint32_t lane_byte_off,
                                          int32_t c, int64_t ldb) {
+    const float *p;
     if constexpr (OFF32) {
         const uint32_t off = (uint32_t)c * (uint32_t)(ldb * 4) + lane_byte_off;
-        vload<VEC>(x, reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off));
+        p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
     } else {
-        vload<VEC>(x, B + (int64_t)c * ldb + (lane_byte_off >> 2));
+        p = B + (int64_t)c * ldb + (lane_byte_off >> 2);
     }
+#if PGCN_GATHER_NT
+    typedef float nvec __attribute__((ext_vector_type(VEC)));
+    const nvec v = __builtin_nontemporal_load(reinterpret_cast<const nvec *>(p));
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) x[i] = v[i];
+#else
+    vload<VEC>(x, p);
+#endif
 }
 
 // tasks: int4 {kbeg low 32, kbeg high 32, length, dst}; kbeg = absolute offset of the task's
@@ -155,9 +168,18 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
         nc = __builtin_nontemporal_load(cp + e);
         if constexpr (HAS_VAL) nv = __builtin_nontemporal_load(vp + e);
     }
+    // The wave's current LPR-batch of pairs lives in LDS (512 B per wave): a group
+    // broadcasts entry k to its lanes with ONE ds_read_b128 per two entries (all lanes of
+    // a group read the same address = conflict-free broadcast), instead of two
+    // ds_bpermute per entry -- the LDS pipe is shared by the whole CU and was the
+    // co-bottleneck of the gather loop.  Written and read by the same wave only, LDS
+    // operations of a wave execute in order => no workgroup barrier.
+    __shared__ float2 meta_lds[kWavesPerBlock][64];
+    float2 *mrow = meta_lds[wave];
     for (int base = 0; __any(base < len); base += LPR) {
-        const int32_t my_c = nc;
-        const float my_v = nv;
+        __builtin_amdgcn_wave_barrier();
+        mrow[lane] = make_float2(__int_as_float(nc), nv);
+        __builtin_amdgcn_wave_barrier();
         {
             int e = base + LPR + sub;
             e = (e < last) ? e : last;
@@ -165,6 +187,7 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
             if constexpr (HAS_VAL) nv = __builtin_nontemporal_load(vp + e);
         }
         const int cnt = len - base;  // entries left for this group (may be <= 0)
+        const float2 *mg = mrow + gbase;
 #pragma unroll
         for (int k = 0; k < LPR; k += U) {
             if (__all(k + U <= cnt)) {
@@ -173,10 +196,16 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
                 int32_t c[U];
                 float w[U];
                 float x[U][VEC];
+                if constexpr (U >= 2) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    c[u] = __shfl(my_c, gbase + k + u);
-                    w[u] = HAS_VAL ? __shfl(my_v, gbase + k + u) : 1.f;
+                    for (int u = 0; u < U; u += 2) {
+                        const float4 m = *reinterpret_cast<const float4 *>(mg + k + u);
+                        c[u] = __float_as_int(m.x); w[u] = m.y;
+                        c[u + 1] = __float_as_int(m.z); w[u + 1] = m.w;
+                    }
+                } else {
+                    const float2 m = mg[k];
+                    c[0] = __float_as_int(m.x); w[0] = m.y;
                 }
                 if (fact) {
 #pragma unroll
@@ -194,11 +223,12 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (u0 + u < U) {
-                            const int32_t cc = __shfl(my_c, gbase + k + u0 + u);
-                            w[u] = HAS_VAL ? __shfl(my_v, gbase + k + u0 + u) : 1.f;
+                            const float2 m = mg[k + u0 + u];
+                            w[u] = m.y;
 #pragma unroll
                             for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
-                            if (fact && (k + u0 + u < cnt)) load_row<VEC, OFF32>(x[u], B, lane_off, cc, ldb);
+                            if (fact && (k + u0 + u < cnt))
+                                load_row<VEC, OFF32>(x[u], B, lane_off, __float_as_int(m.x), ldb);
                         }
                     }
 #pragma unroll

@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from .partition import HostCSR
 
-DEFAULT_CHUNK = int(os.environ.get("PGCN_SPMM_CHUNK", "512"))
+DEFAULT_CHUNK = int(os.environ.get("PGCN_SPMM_CHUNK", "1024"))
 DEFAULT_SMALL_ROW = int(os.environ.get("PGCN_SPMM_SMALL_ROW", "96"))
 
 

@@ -24,12 +24,22 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--variants", default="s1c1024,s8c1024,s8c512,s8c256,s8c2048")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--libs", default="", help="comma list of variant tags (lib/libpgcn_hip.<tag>.so), A/B in one process")
     ap.add_argument("--once", default=None, help="run one variant once (for rocprofv3 --pmc)")
     args = ap.parse_args()
     synth, partition, kernels = pkg("synth"), pkg("partition"), pkg("kernels")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    n, row, col, val = synth.make_graph(args.workload, seed=0, device=dev)
+    if args.workload.startswith("uniform:"):
+        # ceiling probe: reddit-sized rows (492 entries each) whose columns are uniform in [0, K)
+        Kc = int(args.workload.split(":")[1])
+        n, deg = 232965, 492
+        g = torch.Generator(device=dev); g.manual_seed(0)
+        row = torch.arange(n, device=dev).repeat_interleave(deg)
+        col = torch.randint(0, Kc, (n * deg,), device=dev, generator=g)
+        val = torch.rand(n * deg, device=dev, generator=g)
+    else:
+        n, row, col, val = synth.make_graph(args.workload, seed=0, device=dev)
     nnz = row.numel()
     f = args.f
     gen = torch.Generator(device=dev); gen.manual_seed(1)
@@ -37,6 +47,12 @@ def main():
     K = kernels.HipKernels(dev)
     variants = {}
     names = [args.once] if args.once else args.variants.split(",")
+    _lib = pkg("_lib")
+    libs = {"": K.lib}
+    if args.libs:
+        libs = {t: _lib.load_variant(os.path.join(os.path.dirname(_lib.LIB_PATH), "libpgcn_hip.%s.so" % t))
+                for t in args.libs.split(",")}
+    prepared = {}
     for name in names:
         # name: s<slices>c<chunk>[x] (x = xcd swizzle for unsliced)
         S = int(name[1:name.index("c")])
@@ -46,13 +62,15 @@ def main():
         h = partition.csr_from_coo(row, col, val, n, n, nslices=S)
         K.chunk = chunk
         d = K.prepare(h)
-        variants[name] = (d, sw)
+        for tag, L in libs.items():
+            variants[name + ("@" + tag if tag else "")] = (d, sw, L)
     alg = 8 * nnz + 8 * (n + 1) + 2 * 4 * f * n
     C = torch.empty(n, f, device=dev)
 
     def run(name):
-        d, sw = variants[name]
+        d, sw, L = variants[name]
         K.base_flags = 2 if sw else 0
+        K.lib = L
         K.spmm(d, B, C)
 
     if args.once:
