@@ -73,9 +73,10 @@ def cpu_baseline(part, f, budget_s=20.0):
     beside the GPU kernel.  Bounded sample: as many full-graph SpMMs as fit the budget."""
     from oracle import oracle
     L = oracle.lib()
-    rp = part.A_loc.rowptr.cpu().numpy().astype(np.int64)
-    ci = part.A_loc.col.cpu().numpy().astype(np.int32)
-    va = part.A_loc.val.cpu().numpy().astype(np.float32)
+    rp, ci, va = pkg("partition").full_csr(part.A_loc)     # whole local block, core entries included
+    rp = rp.cpu().numpy().astype(np.int64)
+    ci = ci.cpu().numpy().astype(np.int32)
+    va = va.cpu().numpy().astype(np.float32)
     n = rp.shape[0] - 1
     rng = np.random.default_rng(0)
     B = rng.random((n, f), dtype=np.float32)

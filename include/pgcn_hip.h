@@ -40,7 +40,11 @@ typedef void *pgcn_stream_t; /* hipStream_t */
 #define PGCN_SPMM_ACCUMULATE 1u  /* C += A.B instead of C = A.B                      */
 #define PGCN_SPMM_XCD_SWIZZLE 2u /* unsliced plans only: give each XCD a contiguous row range */
 #define PGCN_SPMM_OFFSETS32 4u   /* caller guarantees (max col + 1) * ldb * 4 < 2^32 bytes */
+#define PGCN_SPMM_NO_FIXUP 8u    /* plan call: leave partial sums in the work-space; the caller
+                                    combines them with pgcn_spmm_fixup_f32                  */
 #define PGCN_MAX_SLICES 8        /* = XCDs of an MI355X */
+#define PGCN_CORE_TR 128         /* rows per tile of the LDS-tiled core kernel    */
+#define PGCN_CORE_TC 128         /* columns per panel of the LDS-tiled core kernel */
 
 int pgcn_abi_version(void);
 const char *pgcn_last_error(void);
@@ -84,11 +88,40 @@ int pgcn_spmm_csr_plan_f32(const int64_t *rowptr, const int32_t *col, const floa
  *        grouped by slice, longest first; seg (out, nslices+1) = segment boundaries.
  * fix:   4 x int32 per multi-task row {row, first slot, #tasks, 0}
  * Rows with <= small_row entries are not sliced (one direct task each).
+ * row_flags (optional, nrows bytes): a non-zero flag marks a row that also receives
+ * partial sums from elsewhere (the core kernel): it never writes C directly -- even a
+ * single task gets a slot and a fix record -- and gets no task at all when it is empty.
  * Call with tasks == NULL to obtain the counts, then again with buffers.      */
-int pgcn_spmm_plan_host(const int64_t *rowptr_host, const int32_t *slice_cnt, int64_t nrows,
+int pgcn_spmm_plan_host(const int64_t *rowptr_host, const int32_t *slice_cnt,
+                        const uint8_t *row_flags, int64_t nrows,
                         int32_t nslices, int32_t chunk, int32_t small_row, int32_t *tasks,
                         int64_t cap_tasks, int32_t *fix, int64_t cap_fix, int64_t *seg,
                         int64_t *ntasks, int64_t *nfix, int64_t *nslots);
+
+/* ---- LDS-tiled dense core ------------------------------------------------------
+ * Same product, for the entries that fall into DENSE 128 x 128 tiles of the block (after
+ * the rows/columns were relabelled by decreasing degree): a workgroup stages the 128
+ * feature rows of a column panel in LDS once and serves all entries of its 128 matrix
+ * rows from LDS (~4x the L1 gather rate, L2 traffic / fill factor).  Layout, all device:
+ *   work       4 x int32 per piece {tile row index, first tile, one-past-last tile, first slot}
+ *   tile_panel int32 per dense tile: panel index (column block)
+ *   tile_base  int64 per dense tile: offset of its entries in ccol / cval
+ *   seg_off    int32 (TR+1) per dense tile: segment bounds of the tile's rows, rows in
+ *              group-major order (index g*8+j  <->  row j*16+g of the tile)
+ *   ccol,cval  column inside the panel (0..127) and value of every core entry
+ * A piece writes TR partial rows to slots [first slot, first slot + TR) of partial_ws.   */
+int pgcn_spmm_core_f32(const int32_t *work, int64_t nwork, const int32_t *tile_panel,
+                       const int64_t *tile_base, const int32_t *seg_off, const int32_t *ccol,
+                       const float *cval, const float *B, int64_t ldb, int64_t ncols, int32_t f,
+                       float *partial_ws, int64_t partial_ws_elems, int64_t nslots_total,
+                       pgcn_stream_t stream);
+
+/* C[row] (+)= sum of the partial-sum slots listed for the row, in list order.
+ * fix: 4 x int32 per row {row, begin, count, 0}; slot_ids (optional): the row's slots are
+ * slot_ids[begin .. begin+count), or begin .. begin+count when slot_ids is NULL.        */
+int pgcn_spmm_fixup_f32(const int32_t *fix, int64_t nfix, const int32_t *slot_ids,
+                        const int32_t *row_map, const float *partial_ws, float *C, int64_t ldc,
+                        int32_t f, uint32_t flags, pgcn_stream_t stream);
 
 /* ---- boundary-row pack / unpack -------------------------------------------
  * out[r,:] = H[idx[r],:]                      replaces H[indices]   GPU/PGCN.py:104

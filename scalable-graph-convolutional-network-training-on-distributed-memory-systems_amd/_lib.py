@@ -22,6 +22,7 @@ PGCN_OK = 0
 SPMM_ACCUMULATE = 1
 SPMM_XCD_SWIZZLE = 2
 SPMM_OFFSETS32 = 4
+SPMM_NO_FIXUP = 8
 MAX_SLICES = 8
 
 _vp = ctypes.c_void_p
@@ -37,7 +38,10 @@ SIGNATURES = {
     "pgcn_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _u32, _vp]),
     "pgcn_spmm_csr_plan_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp,
                                               _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),
-    "pgcn_spmm_plan_host": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp,
+    "pgcn_spmm_core_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp,
+                                          _i64, _i64, _vp]),
+    "pgcn_spmm_fixup_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _u32, _vp]),
+    "pgcn_spmm_plan_host": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp,
                                            ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                            ctypes.POINTER(_i64)]),
     "pgcn_gather_rows_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp]),

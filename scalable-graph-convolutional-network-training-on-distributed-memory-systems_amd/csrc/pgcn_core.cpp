@@ -62,8 +62,8 @@ namespace {
 struct TaskRec { int64_t kbeg; int32_t len; int32_t dst; };
 }
 
-extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_cnt, int64_t nrows,
-                                   int32_t nslices, int32_t chunk, int32_t small_row,
+extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_cnt,
+                                   const uint8_t *row_flags, int64_t nrows, int32_t nslices, int32_t chunk, int32_t small_row,
                                    int32_t *tasks, int64_t cap_tasks, int32_t *fix,
                                    int64_t cap_fix, int64_t *seg, int64_t *ntasks,
                                    int64_t *nfix, int64_t *nslots) {
@@ -90,9 +90,12 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
             if (sum != len)
                 return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: slice counts do not add up to the row length");
         }
+        const bool shared = row_flags && row_flags[r];   // other kernels add into this row
+        if (shared && len == 0) continue;                // nothing of ours to add
         if (len <= small_row || (S == 1 && len <= chunk)) {   // one unsliced task (also: empty row)
             per_slice[r % S] += 1;
             nt += 1;
+            if (shared) { ns += 1; ++nf; }
             continue;
         }
         int64_t row_tasks = 0;
@@ -103,7 +106,7 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
             row_tasks += k;
         }
         nt += row_tasks;
-        if (row_tasks > 1) { ns += row_tasks; ++nf; }
+        if (row_tasks > 1 || shared) { ns += row_tasks; ++nf; }
     }
     if (ns > 0x7fffffffLL) return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: too many slots");
     seg[0] = 0;
@@ -120,8 +123,16 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
     int64_t slot = 0, fi = 0;
     for (int64_t r = 0; r < nrows; ++r) {
         const int64_t len = rowptr[r + 1] - rowptr[r];
+        const bool shared = row_flags && row_flags[r];
+        if (shared && len == 0) continue;
         if (len <= small_row || (S == 1 && len <= chunk)) {
-            rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, ~(int32_t)r};
+            if (shared) {
+                int32_t *x = fix + 4 * fi++;
+                x[0] = (int32_t)r; x[1] = (int32_t)slot; x[2] = 1; x[3] = 0;
+                rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, (int32_t)slot++};
+            } else {
+                rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, ~(int32_t)r};
+            }
             continue;
         }
         int64_t row_tasks = 0;
@@ -129,7 +140,7 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
             const int64_t l = (S == 1) ? len : slice_cnt[r * S + s];
             row_tasks += (l + chunk - 1) / chunk;
         }
-        const bool direct = row_tasks == 1;
+        const bool direct = row_tasks == 1 && !shared;
         if (!direct) {
             int32_t *x = fix + 4 * fi++;
             x[0] = (int32_t)r; x[1] = (int32_t)slot; x[2] = (int32_t)row_tasks; x[3] = 0;

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pgcn_device.h"
 #include "pgcn_internal.h"
 
 namespace {
@@ -35,31 +36,9 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * 64;
 constexpr int kUnroll = 8;
 
-template <int VEC> struct VecT;
-template <> struct VecT<1> { using type = float; };
-template <> struct VecT<2> { using type = float2; };
-template <> struct VecT<4> { using type = float4; };
-
 #ifndef PGCN_GATHER_NT
 #define PGCN_GATHER_NT 0
 #endif
-
-template <int VEC>
-__device__ __forceinline__ void vload(float (&x)[VEC], const float *p) {
-    using V = typename VecT<VEC>::type;
-    const V v = *reinterpret_cast<const V *>(p);
-    if constexpr (VEC == 1) { x[0] = v; }
-    if constexpr (VEC == 2) { x[0] = v.x; x[1] = v.y; }
-    if constexpr (VEC == 4) { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
-}
-
-template <int VEC>
-__device__ __forceinline__ void vstore(float *p, const float (&x)[VEC]) {
-    using V = typename VecT<VEC>::type;
-    if constexpr (VEC == 1) { *p = x[0]; }
-    if constexpr (VEC == 2) { *reinterpret_cast<V *>(p) = make_float2(x[0], x[1]); }
-    if constexpr (VEC == 4) { *reinterpret_cast<V *>(p) = make_float4(x[0], x[1], x[2], x[3]); }
-}
 
 __device__ __forceinline__ int64_t swizzle_block(int64_t b, int64_t nb, bool on) {
     if (!on) return b;
@@ -359,7 +338,7 @@ int launch(const int64_t *rowptr, const int32_t *col, const float *val, const in
 #undef PGCN_LT
         if (rc != PGCN_OK) return rc;
     }
-    if (nfix > 0) {
+    if (nfix > 0 && !(flags & PGCN_SPMM_NO_FIXUP)) {
         const int64_t per_block = (int64_t)kWavesPerBlock * G;
         const int64_t grid = (nfix + per_block - 1) / per_block;
         hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VEC>), dim3((unsigned)grid, ntiles), dim3(kThreads),
@@ -416,9 +395,10 @@ extern "C" int pgcn_spmm_csr_plan_f32(const int64_t *rowptr, const int32_t *col,
     if (nslices > 1 && (seg[0] != 0 || seg[nslices] != ntasks))
         return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_csr_plan_f32: seg does not cover the task list");
     if (ntasks == 0) return PGCN_OK;
-    if (!rowptr || !col || !B || !C || !tasks || (nfix > 0 && (!fix || !partial_ws)))
+    const bool own_fixup = nfix > 0 && !(flags & PGCN_SPMM_NO_FIXUP);
+    if (!rowptr || !col || !B || !C || !tasks || (own_fixup && !fix) || (nslots > 0 && !partial_ws))
         return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_csr_plan_f32: null pointer");
-    if (nslots < 0 || (nfix > 0 && partial_ws_elems < nslots * (int64_t)f))
+    if (nslots < 0 || (nslots > 0 && partial_ws_elems < nslots * (int64_t)f))
         return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_csr_plan_f32: partial work-space too small");
     return dispatch(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, row_map, B, ldb, C,
                     ldc, f, partial_ws, flags, (hipStream_t)stream);

@@ -46,6 +46,10 @@ class DeviceCSR:
     nslices: int = 1
     seg: Optional[object] = None          # ctypes int64[nslices+1] (host) task segment bounds
     ws: Optional[torch.Tensor] = None     # fp32 work-space for split rows (grown on demand)
+    core: Optional["DeviceCore"] = None   # dense-tile part (LDS-tiled kernel)
+    fix_all: Optional[torch.Tensor] = None    # int32 [nfix_all,4] combined fix list (core + gather slots)
+    slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
+    nslots_total: int = 0
 
     def alg_bytes(self, f: int, n_cols_touched: Optional[int] = None, n_rows_out: Optional[int] = None) -> int:
         """Algorithmic (compulsory) HBM bytes of one SpMM, SURVEY 8(d):
@@ -55,8 +59,21 @@ class DeviceCSR:
         return 8 * self.nnz + 8 * (self.nrows + 1) + 4 * f * nc + 4 * f * nr
 
 
+@dataclass
+class DeviceCore:
+    work: torch.Tensor
+    tile_panel: torch.Tensor
+    tile_base: torch.Tensor
+    seg_off: torch.Tensor
+    ccol: torch.Tensor
+    cval: torch.Tensor
+    npieces: int
+    nnz: int
+
+
 def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarray] = None,
-               small_row: int = DEFAULT_SMALL_ROW, force: bool = False):
+               small_row: int = DEFAULT_SMALL_ROW, force: bool = False,
+               row_flags: Optional[np.ndarray] = None):
     """Host-side task list (pgcn_spmm_plan_host).  Returns (tasks, fix, nslots, seg) with
     numpy int32 arrays; tasks is None when the plan is trivial (unsliced and no row
     exceeds ``chunk``): the one-task-per-row kernel path needs no plan."""
@@ -69,16 +86,21 @@ def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarr
         slice_cnt = np.ascontiguousarray(slice_cnt, dtype=np.int32)
         S = slice_cnt.shape[1]
         sc_ptr = slice_cnt.ctypes.data
+    rf_ptr = None
+    if row_flags is not None:
+        row_flags = np.ascontiguousarray(row_flags, dtype=np.uint8)
+        rf_ptr = row_flags.ctypes.data
+        force = True
     seg = (ctypes.c_int64 * (S + 1))()
     nt, nf, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, nrows, S, chunk, small_row, None, 0,
+    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, chunk, small_row, None, 0,
                                      None, 0, seg, ctypes.byref(nt), ctypes.byref(nf), ctypes.byref(ns)),
                "pgcn_spmm_plan_host")
     if nf.value == 0 and S == 1 and not force:
         return None, None, 0, None
     tasks = np.empty((nt.value, 4), dtype=np.int32)
     fix = np.empty((max(nf.value, 1), 4), dtype=np.int32)
-    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, nrows, S, chunk, small_row,
+    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, chunk, small_row,
                                      tasks.ctypes.data, nt.value, fix.ctypes.data, nf.value, seg, ctypes.byref(nt),
                                      ctypes.byref(nf), ctypes.byref(ns)), "pgcn_spmm_plan_host")
     return tasks, fix[:nf.value], int(ns.value), seg
@@ -113,8 +135,9 @@ class HipKernels:
         dev = self.device
         rowptr_host = csr.rowptr.detach().cpu().numpy()
         sc = None if csr.slice_cnt is None else csr.slice_cnt.detach().cpu().numpy()
+        rf = None if csr.row_flags is None else csr.row_flags.detach().cpu().numpy()
         tasks, fix, nslots, seg = build_plan(rowptr_host, self.chunk, sc, self.small_row,
-                                             force=csr.row_map is not None)
+                                             force=csr.row_map is not None, row_flags=rf)
         d = DeviceCSR(
             nrows=csr.nrows, ncols=csr.ncols, nnz=csr.nnz,
             rowptr=csr.rowptr.to(dev, torch.int64).contiguous(),
@@ -126,7 +149,48 @@ class HipKernels:
             d.fix = torch.from_numpy(fix).to(dev) if fix.shape[0] else None
             d.ntasks, d.nfix, d.nslots = tasks.shape[0], fix.shape[0], nslots
             d.nslices, d.seg = csr.nslices if sc is not None else 1, seg
+        d.nslots_total = d.nslots
+        if csr.core is not None:
+            self._attach_core(d, csr, fix if tasks is not None else None)
         return d
+
+    def _attach_core(self, d: DeviceCSR, csr: HostCSR, fix_rem: Optional[np.ndarray]) -> None:
+        """Upload the dense-tile part and build the per-row slot lists: a row's partial sums are
+        its core pieces (in work order) followed by its gather-kernel slots."""
+        from .partition import CORE_TR
+        dev = self.device
+        hc = csr.core
+        ns_rem = d.nslots
+        work = hc.work.clone()
+        work[:, 3] += ns_rem                                   # core slots live behind the gather slots
+        d.core = DeviceCore(work.to(dev).contiguous(), hc.tile_panel.to(dev), hc.tile_base.to(dev),
+                            hc.seg_off.to(dev).contiguous(), hc.ccol.to(dev), hc.cval.to(dev),
+                            hc.npieces, hc.nnz)
+        wk = work.cpu().to(torch.int64)
+        rit = torch.arange(CORE_TR, dtype=torch.int64)
+        rows = (wk[:, 0:1] * CORE_TR + rit[None, :]).reshape(-1)
+        slots = (wk[:, 3:4] + rit[None, :]).reshape(-1)
+        seq = torch.arange(wk.shape[0], dtype=torch.int64).repeat_interleave(CORE_TR)
+        ok = rows < csr.nrows
+        rows, slots, seq = rows[ok], slots[ok], seq[ok]
+        if fix_rem is not None and fix_rem.shape[0]:
+            fr = torch.from_numpy(np.ascontiguousarray(fix_rem)).to(torch.int64)
+            cnt = fr[:, 2]
+            r2 = torch.repeat_interleave(fr[:, 0], cnt)
+            first = torch.repeat_interleave(fr[:, 1], cnt)
+            start = torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
+            s2 = first + (torch.arange(int(cnt.sum()), dtype=torch.int64) - start)
+            q2 = torch.full_like(r2, 1 << 40) + s2
+            rows, slots, seq = torch.cat([rows, r2]), torch.cat([slots, s2]), torch.cat([seq, q2])
+        order = torch.argsort(rows * (1 << 42) + seq)
+        rows, slots = rows[order], slots[order]
+        urows, counts = torch.unique_consecutive(rows, return_counts=True)
+        begin = torch.cumsum(counts, 0) - counts
+        fix_all = torch.stack([urows, begin, counts, torch.zeros_like(urows)], 1).to(torch.int32)
+        d.fix_all = fix_all.to(dev).contiguous()
+        d.slot_ids = slots.to(torch.int32).to(dev).contiguous()
+        d.nslots_total = ns_rem + hc.nslots
+        d.nnz = csr.nnz
 
     # -- kernels ----------------------------------------------------------
     def _stream(self) -> int:
@@ -152,26 +216,43 @@ class HipKernels:
             flags |= _lib.SPMM_OFFSETS32
         if A.nrows == 0:
             return C
-        if A.nnz == 0:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
+        if A.nnz == 0 and A.core is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
             if not accumulate:
                 if A.row_map is None:
                     C[:A.nrows].zero_()
                 else:
                     C.index_fill_(0, A.row_map.long(), 0.0)
             return C
-        if A.tasks is None and A.row_map is None:
+        if A.tasks is None and A.row_map is None and A.core is None:
             _lib.check(self.lib.pgcn_spmm_csr_f32(
                 A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.nrows, B.data_ptr(),
                 B.stride(0), C.data_ptr(), C.stride(0), f, flags, self._stream()), "pgcn_spmm_csr_f32")
             return C
-        need = A.nslots * f
-        if A.nfix and (A.ws is None or A.ws.numel() < need):
+        need = A.nslots_total * f
+        if need and (A.ws is None or A.ws.numel() < need):
             A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.pgcn_spmm_csr_plan_f32(
-            A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.tasks.data_ptr(), A.ntasks,
-            A.seg, A.nslices, _ptr(A.fix), A.nfix, _ptr(A.row_map), B.data_ptr(), B.stride(0), C.data_ptr(),
-            C.stride(0), f, _ptr(A.ws), 0 if A.ws is None else A.ws.numel(), A.nslots, flags,
-            self._stream()), "pgcn_spmm_csr_plan_f32")
+        ws_n = 0 if A.ws is None else A.ws.numel()
+        if A.core is None:
+            _lib.check(self.lib.pgcn_spmm_csr_plan_f32(
+                A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.tasks.data_ptr(), A.ntasks,
+                A.seg, A.nslices, _ptr(A.fix), A.nfix, _ptr(A.row_map), B.data_ptr(), B.stride(0), C.data_ptr(),
+                C.stride(0), f, _ptr(A.ws), ws_n, A.nslots, flags, self._stream()), "pgcn_spmm_csr_plan_f32")
+            return C
+        # gather part (partial sums stay in the work-space) + LDS-tiled core + one combined fix-up
+        if A.ntasks:
+            _lib.check(self.lib.pgcn_spmm_csr_plan_f32(
+                A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.tasks.data_ptr(), A.ntasks,
+                A.seg, A.nslices, None, 0, _ptr(A.row_map), B.data_ptr(), B.stride(0), C.data_ptr(),
+                C.stride(0), f, _ptr(A.ws), ws_n, A.nslots, flags | _lib.SPMM_NO_FIXUP, self._stream()),
+                "pgcn_spmm_csr_plan_f32")
+        co = A.core
+        _lib.check(self.lib.pgcn_spmm_core_f32(
+            co.work.data_ptr(), co.npieces, co.tile_panel.data_ptr(), co.tile_base.data_ptr(),
+            co.seg_off.data_ptr(), co.ccol.data_ptr(), co.cval.data_ptr(), B.data_ptr(), B.stride(0),
+            A.ncols, f, A.ws.data_ptr(), ws_n, A.nslots_total, self._stream()), "pgcn_spmm_core_f32")
+        _lib.check(self.lib.pgcn_spmm_fixup_f32(
+            A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr(), _ptr(A.row_map), A.ws.data_ptr(),
+            C.data_ptr(), C.stride(0), f, flags & _lib.SPMM_ACCUMULATE, self._stream()), "pgcn_spmm_fixup_f32")
         return C
 
     def gather_rows(self, H: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:

@@ -40,10 +40,140 @@ class HostCSR:
     row_map: Optional[torch.Tensor] = None  # compact row r -> output row row_map[r] (int32)
     nslices: int = 1                          # entries of a row are grouped by col % nslices
     slice_cnt: Optional[torch.Tensor] = None  # int32 [nrows, nslices] entries per (row, slice)
+    core: Optional["HostCore"] = None         # entries of dense tiles, stored for the LDS-tiled kernel
+    row_flags: Optional[torch.Tensor] = None  # uint8 [nrows]: row also receives core partial sums
 
     @property
     def nnz(self) -> int:
-        return int(self.col.numel())
+        """Stored entries of the whole block (gather part + dense core)."""
+        return int(self.col.numel()) + (self.core.nnz if self.core is not None else 0)
+
+    def to_coo(self):
+        """(row, col, val) of the whole block, core included (tests / checker only)."""
+        counts = self.rowptr[1:] - self.rowptr[:-1]
+        r = torch.repeat_interleave(torch.arange(self.nrows, device=self.col.device), counts)
+        if self.row_map is not None:
+            r = self.row_map.to(torch.int64)[r]
+        c, v = self.col.to(torch.int64), self.val
+        if self.core is not None:
+            cr, cc, cv = self.core.to_coo()
+            r, c, v = torch.cat([r, cr]), torch.cat([c, cc]), torch.cat([v, cv])
+        return r, c, v
+
+
+def full_csr(h: "HostCSR"):
+    """(rowptr int64, col int32, val fp32) of the WHOLE block (core included), rows in output
+    numbering, columns ascending: what a CPU checker / baseline consumes."""
+    r, c, v = h.to_coo()
+    nrows = h.nrows if h.row_map is None else int(h.row_map.max()) + 1 if h.row_map.numel() else 0
+    order = torch.argsort(r * max(h.ncols, 1) + c, stable=True)
+    r, c, v = r[order], c[order], v[order]
+    rowptr = torch.zeros(nrows + 1, dtype=torch.int64, device=r.device)
+    if r.numel():
+        rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=nrows), 0)
+    return rowptr, c.to(torch.int32), v
+
+
+CORE_TR = 128      # rows per tile   (PGCN_CORE_TR in include/pgcn_hip.h)
+CORE_TC = 128      # columns per panel
+CORE_NG = 16       # 32-lane groups per workgroup
+CORE_RW = CORE_TR // CORE_NG
+CORE_ON = os.environ.get("PGCN_CORE", "1") != "0"
+CORE_TAU = float(os.environ.get("PGCN_CORE_TAU", "0.05"))        # minimum tile fill
+CORE_EMAX = int(os.environ.get("PGCN_CORE_EMAX", "65536"))       # entries per work piece
+DEGREE_SORT = os.environ.get("PGCN_DEGREE_SORT", "1") != "0"
+
+
+@dataclass
+class HostCore:
+    """Entries that fall into dense 128 x 128 tiles, laid out for pgcn_spmm_core_f32."""
+    nrows: int
+    ncols: int
+    work: torch.Tensor        # int32 [npieces, 4] {tile row, first tile, one-past-last tile, first slot (local)}
+    tile_row: torch.Tensor    # int32 [ntiles]  (host-side bookkeeping)
+    tile_panel: torch.Tensor  # int32 [ntiles]
+    tile_base: torch.Tensor   # int64 [ntiles]
+    seg_off: torch.Tensor     # int32 [ntiles, TR+1]
+    ccol: torch.Tensor        # int32 [nnz_core] column inside the panel
+    cval: torch.Tensor        # fp32  [nnz_core]
+
+    @property
+    def nnz(self) -> int:
+        return int(self.ccol.numel())
+
+    @property
+    def npieces(self) -> int:
+        return int(self.work.shape[0])
+
+    @property
+    def nslots(self) -> int:
+        return self.npieces * CORE_TR
+
+    def to_coo(self):
+        seg = self.seg_off.to(torch.int64)
+        cnt = (seg[:, 1:] - seg[:, :-1]).reshape(-1)                       # per (tile, ord)
+        ntiles = self.tile_row.numel()
+        dev = self.ccol.device
+        ordn = torch.arange(CORE_TR, device=dev).repeat(ntiles)
+        rit = (ordn % CORE_RW) * CORE_NG + ordn // CORE_RW                 # ord = g*RW + j -> row j*NG + g
+        rows_per = self.tile_row.to(torch.int64).repeat_interleave(CORE_TR) * CORE_TR + rit
+        r = torch.repeat_interleave(rows_per, cnt)
+        panel = torch.repeat_interleave(self.tile_panel.to(torch.int64).repeat_interleave(CORE_TR), cnt)
+        c = panel * CORE_TC + self.ccol.to(torch.int64)
+        return r, c, self.cval
+
+
+def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
+               tau: float = None, emax: int = None):
+    """Separate the entries of dense tiles.  Returns (keep_mask, HostCore or None)."""
+    tau = CORE_TAU if tau is None else tau
+    emax = CORE_EMAX if emax is None else emax
+    TR, TC, NG, RW = CORE_TR, CORE_TC, CORE_NG, CORE_RW
+    dev = r.device
+    if r.numel() == 0:
+        return None, None
+    r64, c64 = r.to(torch.int64), c.to(torch.int64)
+    ncp = (ncols + TC - 1) // TC
+    tkey = (r64 // TR) * ncp + c64 // TC
+    uniq, inv, cnt = torch.unique(tkey, return_inverse=True, return_counts=True)
+    dense = cnt >= max(1, int(tau * TR * TC))
+    ntiles = int(dense.sum())
+    if ntiles == 0:
+        return None, None
+    is_core = dense[inv]
+    kmap = torch.cumsum(dense.to(torch.int64), 0) - 1
+    k_e = kmap[inv[is_core]]
+    rc, cc, vc = r64[is_core], c64[is_core], v[is_core]
+    rit = rc % TR
+    ordn = (rit % NG) * RW + rit // NG
+    order = torch.argsort((k_e * TR + ordn) * TC + cc % TC, stable=True)
+    ccol = (cc % TC)[order].to(torch.int32).contiguous()
+    cval = vc[order].to(torch.float32).contiguous()
+    segcnt = torch.bincount(k_e * TR + ordn, minlength=ntiles * TR).reshape(ntiles, TR)
+    seg_off = torch.zeros((ntiles, TR + 1), dtype=torch.int32, device=dev)
+    seg_off[:, 1:] = torch.cumsum(segcnt, 1).to(torch.int32)
+    tile_tot = segcnt.sum(1)
+    tile_base = (torch.cumsum(tile_tot, 0) - tile_tot).to(torch.int64)
+    dk = uniq[dense]
+    tile_row = (dk // ncp).to(torch.int32)
+    tile_panel = (dk % ncp).to(torch.int32)
+    # pieces: runs of tiles of one row tile, cut at ~emax entries (host, a few 10k tiles)
+    ttr = tile_row.cpu().numpy()
+    tt = tile_tot.cpu().numpy()
+    import numpy as np
+    cum = np.cumsum(tt) - tt
+    run_start = np.r_[True, ttr[1:] != ttr[:-1]]
+    run_base = np.maximum.accumulate(np.where(run_start, cum, 0))
+    pid_local = (cum - run_base) // max(emax, 1)
+    newp = np.r_[True, (ttr[1:] != ttr[:-1]) | (pid_local[1:] != pid_local[:-1])]
+    kbeg = np.nonzero(newp)[0]
+    kend = np.r_[kbeg[1:], ntiles]
+    edges = np.add.reduceat(tt, kbeg)
+    lpt = np.argsort(-edges, kind="stable")          # longest piece first
+    work = np.stack([ttr[kbeg][lpt], kbeg[lpt], kend[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
+    core = HostCore(nrows, ncols, torch.from_numpy(work).to(dev), tile_row, tile_panel, tile_base,
+                    seg_off.contiguous(), ccol, cval)
+    return ~is_core, core
 
 
 # XCD-sliced storage: above this many columns the dense panel no longer fits a 4 MiB L2
@@ -57,13 +187,24 @@ def pick_nslices(ncols: int) -> int:
 
 
 def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
-                 compact_rows: bool = False, nslices: Optional[int] = None) -> HostCSR:
+                 compact_rows: bool = False, nslices: Optional[int] = None, core: bool = False,
+                 tau: float = None, emax: int = None) -> HostCSR:
     """Sort by (row, col % nslices, col) and build CSR.  Duplicate entries are kept as
-    separate stored entries (an uncoalesced COO sums them, PGCN.py:63)."""
+    separate stored entries (an uncoalesced COO sums them, PGCN.py:63).  With ``core``
+    the entries of dense 128 x 128 tiles are split off into a HostCore (LDS-tiled kernel)."""
     dev = r.device
     if nslices is None:
         nslices = pick_nslices(ncols)
     S = nslices
+    hcore, row_flags = None, None
+    if core and not compact_rows and r.numel():
+        keep, hcore = split_core(r, c, v, nrows, ncols, tau, emax)
+        if hcore is not None:
+            r, c, v = r[keep], c[keep], v[keep]
+            row_flags = torch.zeros(nrows, dtype=torch.uint8, device=dev)
+            trs = torch.unique(hcore.tile_row.to(torch.int64))
+            rows = (trs[:, None] * CORE_TR + torch.arange(CORE_TR, device=dev)[None, :]).reshape(-1)
+            row_flags[rows[rows < nrows]] = 1
     if r.numel():
         r64, c64 = r.to(torch.int64), c.to(torch.int64)
         key = (r64 * S + c64 % S) * max(ncols, 1) + c64
@@ -86,16 +227,17 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
         else:
             slice_cnt = torch.zeros((nrows, S), dtype=torch.int32, device=dev)
     return HostCSR(nrows, ncols, rowptr, c.to(torch.int32).contiguous(),
-                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt)
+                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, hcore, row_flags)
 
 
-def csr_from_scipy(A, nslices: Optional[int] = None) -> HostCSR:
+def csr_from_scipy(A, nslices: Optional[int] = None, core: bool = False, tau: float = None,
+                   emax: int = None) -> HostCSR:
     """Convenience for tests / tools: a scipy sparse matrix -> HostCSR (optionally sliced)."""
     import numpy as np
     A = A.tocoo()
     return csr_from_coo(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
                         torch.from_numpy(A.data.astype(np.float32)), A.shape[0], A.shape[1],
-                        nslices=nslices)
+                        nslices=nslices, core=core, tau=tau, emax=emax)
 
 
 @dataclass
@@ -104,7 +246,7 @@ class Partition:
     n: int                      # global number of vertices
     rank: int
     size: int
-    owned: torch.Tensor         # int64 [n_p] global ids of owned rows, ascending
+    owned: torch.Tensor         # int64 [n_p] global id of local row i (decreasing local degree)
     A_loc: HostCSR              # n_p x n_p
     A_halo: HostCSR             # compact rows x n_halo (row_map -> local row)
     A_loc_T: HostCSR            # n_p x n_p
@@ -171,6 +313,13 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     own_mask = part == rank
     owned = torch.nonzero(own_mask).reshape(-1)
     n_p = int(owned.numel())
+    if DEGREE_SORT and n_p > 1:
+        # local numbering by decreasing degree inside the local block (ties: ascending global
+        # id): the dense core of a power-law graph becomes the top-left corner of A_loc, which
+        # is what the LDS-tiled kernel feeds on.  Purely internal: `owned` records the order.
+        both = own_mask[row] & own_mask[col]
+        deg = torch.bincount(row[both], minlength=n) + torch.bincount(col[both], minlength=n)
+        owned = owned[torch.argsort(-deg[owned], stable=True)]
     g2l = torch.full((n,), -1, dtype=torch.int64, device=dev)
     g2l[owned] = torch.arange(n_p, dtype=torch.int64, device=dev)
 
@@ -183,7 +332,7 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     cp = pcol[mine]
     loc = cp == rank
 
-    A_loc = csr_from_coo(r[loc], g2l[c[loc]], v[loc], n_p, n_p)
+    A_loc = csr_from_coo(r[loc], g2l[c[loc]], v[loc], n_p, n_p, core=CORE_ON)
     # halo columns, ordered by (owner, global id)  == concatenated recv_map lists
     hkey = cp[~loc] * n + c[~loc]
     huniq, hinv = torch.unique(hkey, return_inverse=True)
@@ -195,7 +344,7 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
 
     A_loc_T = A_halo_T = None
     if with_transpose:
-        A_loc_T = csr_from_coo(g2l[c[loc]], r[loc], v[loc], n_p, n_p)
+        A_loc_T = csr_from_coo(g2l[c[loc]], r[loc], v[loc], n_p, n_p, core=CORE_ON)
         A_halo_T = csr_from_coo(hinv, r[~loc], v[~loc], n_halo, n_p)
 
     # rows of mine that other ranks need: (target rank, global id) sorted

@@ -11,12 +11,14 @@ from oracle import oracle
 
 
 class _CpuCSR:
+    """Whole block (gather part + dense core) as one scipy CSR over OUTPUT rows."""
+
     def __init__(self, csr):
+        import scipy.sparse as sp
         self.nrows, self.ncols, self.nnz = csr.nrows, csr.ncols, csr.nnz
-        self.rowptr = csr.rowptr.cpu().numpy().astype(np.int64)
-        self.col = csr.col.cpu().numpy().astype(np.int32)
-        self.val = csr.val.cpu().numpy().astype(np.float32)
-        self.row_map = None if csr.row_map is None else csr.row_map.cpu().numpy()
+        r, c, v = csr.to_coo()
+        self.r, self.c, self.v = r.cpu().numpy(), c.cpu().numpy(), v.cpu().numpy().astype(np.float32)
+        self.touched = None if csr.row_map is None else csr.row_map.cpu().numpy().astype(np.int64)
 
     def alg_bytes(self, f, a=None, b=None):
         return 0
@@ -29,21 +31,18 @@ class OracleKernels:
         return _CpuCSR(csr)
 
     def spmm(self, A, B, C, accumulate=False):
+        import scipy.sparse as sp
         if A.nrows == 0:
             return C
-        out = oracle.spmm_csr(A.rowptr, A.col, A.val, B.detach().numpy())
-        t = torch.from_numpy(out)
-        if A.row_map is None:
-            if accumulate:
-                C[:A.nrows] += t
-            else:
-                C[:A.nrows] = t
+        R = C.shape[0]
+        M = sp.csr_matrix((A.v, (A.r, A.c)), shape=(R, A.ncols))
+        M.sort_indices()
+        out = torch.from_numpy(oracle.spmm(M, B.detach().numpy()))
+        rows = torch.arange(A.nrows) if A.touched is None else torch.from_numpy(A.touched)
+        if accumulate:
+            C[rows] += out[rows]
         else:
-            idx = torch.from_numpy(A.row_map.astype(np.int64))
-            if accumulate:
-                C[idx] += t
-            else:
-                C[idx] = t
+            C[rows] = out[rows]
         return C
 
     def gather_rows(self, H, idx, out):

@@ -19,7 +19,7 @@ def _declared():
 def test_header_symbols_exported_and_bound():
     _lib = pkg("_lib")
     names = _declared()
-    assert len(names) >= 13
+    assert len(names) >= 15
     L = _lib.lib()
     for n in names:
         assert hasattr(L, n), "libpgcn_hip.so does not export %s" % n
@@ -110,7 +110,7 @@ def test_error_reporting_without_gpu():
     _lib = pkg("_lib")
     L = _lib.lib()
     nt = ctypes.c_int64()
-    rc = L.pgcn_spmm_plan_host(None, None, 4, 1, 1024, 0, None, 0, None, 0, None, ctypes.byref(nt),
+    rc = L.pgcn_spmm_plan_host(None, None, None, 4, 1, 1024, 0, None, 0, None, 0, None, ctypes.byref(nt),
                                ctypes.byref(nt), ctypes.byref(nt))
     assert rc == -1 and b"pgcn_spmm_plan_host" in L.pgcn_last_error()
     with pytest.raises(_lib.PgcnError):

@@ -21,13 +21,9 @@ def _build(mtx, pv, rank, P):
 
 
 def _dense(csr, nrows=None):
-    M = sp.csr_matrix((csr.val.numpy(), csr.col.numpy(), csr.rowptr.numpy()),
-                      shape=(csr.nrows, csr.ncols)).toarray()
-    if csr.row_map is not None:
-        full = np.zeros((nrows, csr.ncols), np.float32)
-        full[csr.row_map.numpy()] = M
-        return full
-    return M
+    r, c, v = csr.to_coo()                      # gather part + dense core, output-row numbering
+    R = csr.nrows if csr.row_map is None else nrows
+    return sp.csr_matrix((v.numpy(), (r.numpy(), c.numpy())), shape=(R, csr.ncols)).toarray()
 
 
 @pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES)
@@ -65,11 +61,16 @@ def test_pieces_reassemble_the_row_block(name, mtx, pv, P):
         assert not rest.any()
         np.testing.assert_array_equal(_dense(p.A_loc_T), loc.T)
         np.testing.assert_array_equal(_dense(p.A_halo_T), halo.T)
-        # column ids sorted inside every row
+        # inside every row: grouped by slice (col % nslices), ascending inside a slice
         for csr in (p.A_loc, p.A_halo, p.A_loc_T, p.A_halo_T):
-            rp, c = csr.rowptr.numpy(), csr.col.numpy()
+            rp, c = csr.rowptr.numpy(), csr.col.numpy().astype(np.int64)
+            key = (c % csr.nslices) * (csr.ncols + 1) + c
             for i in range(csr.nrows):
-                assert (np.diff(c[rp[i]:rp[i + 1]]) >= 0).all()
+                assert (np.diff(key[rp[i]:rp[i + 1]]) >= 0).all()
+        # local numbering = decreasing degree inside the local block
+        lr, lc, _ = p.A_loc.to_coo()                       # stored entries (explicit zeros count)
+        d = np.bincount(lr.numpy(), minlength=p.n_local) + np.bincount(lc.numpy(), minlength=p.n_local)
+        assert (np.diff(d) <= 0).all()
 
 
 def test_edge_cases():
@@ -89,6 +90,44 @@ def test_edge_cases():
     p = partition.build_partition(torch.tensor([0, 0]), torch.tensor([1, 1]), torch.tensor([1., 2.]), 2,
                                   torch.tensor([0, 0]), 0, 1)
     assert p.A_loc.nnz == 2
+
+
+def test_dense_core_split_roundtrip():
+    """Entries of dense 128x128 tiles move to the LDS-tiled layout; nothing is lost or duplicated."""
+    partition, synth, kernels = pkg("partition"), pkg("synth"), pkg("kernels")
+    n, row, col, val = synth.make_graph(3000, 300000, seed=4)
+    deg = torch.bincount(row, minlength=n)
+    rank = torch.empty(n, dtype=torch.int64)
+    rank[torch.argsort(-deg, stable=True)] = torch.arange(n)
+    r, c = rank[row], rank[col]
+    h = partition.csr_from_coo(r, c, val, n, n, nslices=8, core=True, tau=0.05, emax=5000)
+    assert h.core is not None and h.core.nnz > 0.2 * r.numel() and h.core.npieces > h.core.tile_row.unique().numel()
+    assert h.nnz == r.numel()
+    A = sp.csr_matrix((val.numpy(), (r.numpy(), c.numpy())), shape=(n, n))
+    rr, cc, vv = h.to_coo()
+    B = sp.csr_matrix((vv.numpy(), (rr.numpy(), cc.numpy())), shape=(n, n))
+    assert abs(A - B).max() == 0 and B.nnz == A.nnz
+    co = h.core
+    # every dense tile really is dense, every piece stays inside one row tile, pieces cover all tiles once
+    tot = (co.seg_off[:, -1]).numpy()
+    assert (tot >= int(0.05 * 128 * 128)).all()
+    w = co.work.numpy()
+    cover = np.zeros(len(tot), int)
+    for tr, kb, ke, sb in w:
+        assert (co.tile_row.numpy()[kb:ke] == tr).all()
+        cover[kb:ke] += 1
+    assert (cover == 1).all() and sorted(w[:, 3].tolist()) == [128 * i for i in range(len(w))]
+    edges = [tot[kb:ke].sum() for _, kb, ke, _ in w]
+    assert all(a >= b for a, b in zip(edges, edges[1:]))
+    assert (co.ccol.numpy() < 128).all() and (co.ccol.numpy() >= 0).all()
+    # flagged rows = rows of the core row tiles; the gather plan never writes them directly
+    flags = h.row_flags.numpy()
+    assert set(np.nonzero(flags)[0] // 128) == set(co.tile_row.numpy().tolist())
+    tasks, fix, nslots, seg = kernels.build_plan(h.rowptr.numpy(), 1024, h.slice_cnt.numpy(), 96, row_flags=flags)
+    dst = tasks[:, 3]
+    direct_rows = ~dst[dst < 0]
+    assert not flags[direct_rows].any()
+    assert set(fix[:, 0].tolist()) >= set(np.nonzero(flags & (np.diff(h.rowptr.numpy()) > 0))[0].tolist())
 
 
 def test_synthetic_graph_is_normalised_symmetric():

@@ -54,12 +54,23 @@ def main():
                 for t in args.libs.split(",")}
     prepared = {}
     for name in names:
-        # name: s<slices>c<chunk>[x] (x = xcd swizzle for unsliced)
+        # name: s<slices>c<chunk>[x][k[tau]] (x = xcd swizzle for unsliced; k = degree sort + LDS core)
         S = int(name[1:name.index("c")])
         rest = name[name.index("c") + 1:]
+        tau = None
+        core = "k" in rest
+        if core:
+            rest, t = rest.split("k")
+            tau = float(t) if t else None
         sw = rest.endswith("x")
         chunk = int(rest.rstrip("x"))
-        h = partition.csr_from_coo(row, col, val, n, n, nslices=S)
+        if core:
+            deg = torch.bincount(row, minlength=n) + torch.bincount(col, minlength=n)
+            rank = torch.empty(n, dtype=torch.int64, device=dev)
+            rank[torch.argsort(-deg, stable=True)] = torch.arange(n, device=dev)
+            h = partition.csr_from_coo(rank[row], rank[col], val, n, n, nslices=S, core=True, tau=tau)
+        else:
+            h = partition.csr_from_coo(row, col, val, n, n, nslices=S)
         K.chunk = chunk
         d = K.prepare(h)
         for tag, L in libs.items():
@@ -99,9 +110,11 @@ def main():
         med, mn = float(np.median(ts)), float(np.min(ts))
         d = variants[name][0]
         out[name] = {"median_ms": med, "min_ms": mn, "alg_GBs": alg / med / 1e6, "gather_TBs": 4 * f * nnz / med / 1e9,
-                     "ntasks": d.ntasks, "nslots": d.nslots}
-        print("%-12s median %.3f ms  min %.3f ms  alg %.0f GB/s (%.2f%% of 8 TB/s)  gather %.1f TB/s  tasks %d"
-              % (name, med, mn, alg / med / 1e6, 100 * alg / med / 1e6 / 8000, 4 * f * nnz / med / 1e9, d.ntasks))
+                     "ntasks": d.ntasks, "nslots": d.nslots_total,
+                     "core_nnz": d.core.nnz if d.core else 0, "core_pieces": d.core.npieces if d.core else 0}
+        print("%-14s median %.3f ms  min %.3f ms  alg %.0f GB/s (%.2f%% of 8 TB/s)  gather %.1f TB/s  tasks %d core %.1f%% pieces %d"
+              % (name, med, mn, alg / med / 1e6, 100 * alg / med / 1e6 / 8000, 4 * f * nnz / med / 1e9, d.ntasks,
+                 100.0 * (d.core.nnz if d.core else 0) / nnz, d.core.npieces if d.core else 0))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "spmm_probe.json"), "w") as fh:
         json.dump(out, fh, indent=1)
