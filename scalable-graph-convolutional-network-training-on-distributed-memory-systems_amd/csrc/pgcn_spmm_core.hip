@@ -142,13 +142,20 @@ __global__ __launch_bounds__(kCoreThreads, 4) void spmm_core_kernel(
                 __builtin_amdgcn_wave_barrier();
                 mrow[lane] = make_float2(__int_as_float(valid ? cur_c : TC), valid ? cur_v : 0.f);
                 __builtin_amdgcn_wave_barrier();
+                // software-pipelined: the pairs of batch k4+CB are read while batch k4 computes, so a
+                // batch costs one LDS round trip (rows) instead of two (pairs, then rows).
+                float4 m[CB / 2];
+#pragma unroll
+                for (int u = 0; u < CB / 2; ++u) m[u] = *reinterpret_cast<const float4 *>(mg + 2 * u);
 #pragma unroll
                 for (int k4 = 0; k4 < 32; k4 += CB) {
                     if (!__any(k4 < cnt)) break;
-                    float4 m[CB / 2];
-                    float x[CB][VEC];
+                    float4 mn[CB / 2];
+                    if (k4 + CB < 32) {
 #pragma unroll
-                    for (int u = 0; u < CB / 2; ++u) m[u] = *reinterpret_cast<const float4 *>(mg + k4 + 2 * u);
+                        for (int u = 0; u < CB / 2; ++u) mn[u] = *reinterpret_cast<const float4 *>(mg + k4 + CB + 2 * u);
+                    }
+                    float x[CB][VEC];
 #pragma unroll
                     for (int u = 0; u < CB / 2; ++u) {
                         lds_row<VEC>(x[2 * u], panel, __float_as_int(m[u].x), sub);
@@ -160,6 +167,10 @@ __global__ __launch_bounds__(kCoreThreads, 4) void spmm_core_kernel(
                         for (int v = 0; v < VEC; ++v) acc[j][v] = fmaf(m[u].y, x[2 * u][v], acc[j][v]);
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) acc[j][v] = fmaf(m[u].w, x[2 * u + 1][v], acc[j][v]);
+                    }
+                    if (k4 + CB < 32) {
+#pragma unroll
+                        for (int u = 0; u < CB / 2; ++u) m[u] = mn[u];
                     }
                 }
                 cur_c = nx_c;

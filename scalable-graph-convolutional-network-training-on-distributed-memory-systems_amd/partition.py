@@ -80,7 +80,9 @@ CORE_NG = 16       # 32-lane groups per workgroup
 CORE_RW = CORE_TR // CORE_NG
 CORE_ON = os.environ.get("PGCN_CORE", "1") != "0"
 CORE_TAU = float(os.environ.get("PGCN_CORE_TAU", "0.05"))        # minimum tile fill
-CORE_EMAX = int(os.environ.get("PGCN_CORE_EMAX", "65536"))       # entries per work piece
+CORE_EMAX = int(os.environ.get("PGCN_CORE_EMAX", "32768"))       # entries per work piece
+CORE_PG = int(os.environ.get("PGCN_CORE_PANEL_GROUP", "0"))      # >0: cut pieces at multiples of PG panels
+                                                                  # and run them panel-group-major (L2 locality)
 DEGREE_SORT = os.environ.get("PGCN_DEGREE_SORT", "1") != "0"
 
 
@@ -162,14 +164,18 @@ def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, nc
     tt = tile_tot.cpu().numpy()
     import numpy as np
     cum = np.cumsum(tt) - tt
-    run_start = np.r_[True, ttr[1:] != ttr[:-1]]
+    tpg = (tile_panel.cpu().numpy() // CORE_PG) if CORE_PG > 0 else np.zeros(ntiles, np.int64)
+    run_start = np.r_[True, (ttr[1:] != ttr[:-1]) | (tpg[1:] != tpg[:-1])]
     run_base = np.maximum.accumulate(np.where(run_start, cum, 0))
     pid_local = (cum - run_base) // max(emax, 1)
-    newp = np.r_[True, (ttr[1:] != ttr[:-1]) | (pid_local[1:] != pid_local[:-1])]
+    newp = np.r_[True, run_start[1:] | (pid_local[1:] != pid_local[:-1])]
     kbeg = np.nonzero(newp)[0]
     kend = np.r_[kbeg[1:], ntiles]
     edges = np.add.reduceat(tt, kbeg)
-    lpt = np.argsort(-edges, kind="stable")          # longest piece first
+    if CORE_PG > 0:   # panel-group-major: concurrent workgroups stage the same few panels
+        lpt = np.lexsort((-edges, tpg[kbeg]))
+    else:
+        lpt = np.argsort(-edges, kind="stable")          # longest piece first
     work = np.stack([ttr[kbeg][lpt], kbeg[lpt], kend[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
     core = HostCore(nrows, ncols, torch.from_numpy(work).to(dev), tile_row, tile_panel, tile_base,
                     seg_off.contiguous(), ccol, cval)
