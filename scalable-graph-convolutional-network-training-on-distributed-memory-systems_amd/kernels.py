@@ -129,6 +129,10 @@ class HipKernels:
         self.base_flags = _lib.SPMM_XCD_SWIZZLE if xcd_swizzle else 0
         self.chunk = chunk
         self.small_row = small_row
+        # the LDS-tiled core kernel (LDS-bound) and the gather kernel (L1/L2-bound) use different
+        # pipes of a CU: optionally run them on two streams so the hardware can co-schedule them
+        self.core_overlap = os.environ.get("PGCN_CORE_OVERLAP", "0") != "0"
+        self._side = None
 
     # -- data placement -------------------------------------------------
     def prepare(self, csr: HostCSR, pattern_only: bool = False) -> DeviceCSR:
@@ -239,6 +243,15 @@ class HipKernels:
                 C.stride(0), f, _ptr(A.ws), ws_n, A.nslots, flags, self._stream()), "pgcn_spmm_csr_plan_f32")
             return C
         # gather part (partial sums stay in the work-space) + LDS-tiled core + one combined fix-up
+        side = None
+        if self.core_overlap and A.ntasks:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            side = self._side
+            main = torch.cuda.current_stream(self.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
         if A.ntasks:
             _lib.check(self.lib.pgcn_spmm_csr_plan_f32(
                 A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.tasks.data_ptr(), A.ntasks,
@@ -246,10 +259,15 @@ class HipKernels:
                 C.stride(0), f, _ptr(A.ws), ws_n, A.nslots, flags | _lib.SPMM_NO_FIXUP, self._stream()),
                 "pgcn_spmm_csr_plan_f32")
         co = A.core
+        core_stream = side.cuda_stream if side is not None else self._stream()
         _lib.check(self.lib.pgcn_spmm_core_f32(
             co.work.data_ptr(), co.npieces, co.tile_panel.data_ptr(), co.tile_base.data_ptr(),
             co.seg_off.data_ptr(), co.ccol.data_ptr(), co.cval.data_ptr(), B.data_ptr(), B.stride(0),
-            A.ncols, f, A.ws.data_ptr(), ws_n, A.nslots_total, self._stream()), "pgcn_spmm_core_f32")
+            A.ncols, f, A.ws.data_ptr(), ws_n, A.nslots_total, core_stream), "pgcn_spmm_core_f32")
+        if side is not None:
+            done = torch.cuda.Event()
+            done.record(side)
+            torch.cuda.current_stream(self.device).wait_event(done)
         _lib.check(self.lib.pgcn_spmm_fixup_f32(
             A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr(), _ptr(A.row_map), A.ws.data_ptr(),
             C.data_ptr(), C.stride(0), f, flags & _lib.SPMM_ACCUMULATE, self._stream()), "pgcn_spmm_fixup_f32")
