@@ -147,7 +147,7 @@ def main():
     part = partition.build_partition(row, col, val, n, partvec, rank, world)
     del row, col, val
     K = kernels.HipKernels(dev)
-    exch = engine.RcclExchanger(rank, world, dev) if world > 1 else None
+    exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
     eng = engine.AggregationEngine(part, K, dev, exch)
     torch.cuda.synchronize()
     setup_s = time.time() - t0

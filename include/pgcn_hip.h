@@ -43,6 +43,7 @@ typedef void *pgcn_stream_t; /* hipStream_t */
 #define PGCN_SPMM_NO_FIXUP 8u    /* plan call: leave partial sums in the work-space; the caller
                                     combines them with pgcn_spmm_fixup_f32                  */
 #define PGCN_MAX_SLICES 8        /* = XCDs of an MI355X */
+#define PGCN_MAX_COL_GROUPS 64   /* column groups per slice (time slicing of the column space) */
 #define PGCN_CORE_TR 128         /* rows per tile of the LDS-tiled core kernel    */
 #define PGCN_CORE_TC 128         /* columns per panel of the LDS-tiled core kernel */
 
@@ -82,7 +83,10 @@ int pgcn_spmm_csr_plan_f32(const int64_t *rowptr, const int32_t *col, const floa
                            int64_t nslots, uint32_t flags, pgcn_stream_t stream);
 
 /* Host-side plan builder (pure CPU, no HIP).  rowptr_host: nrows+1 entries;
- * slice_cnt: nrows x nslices entry counts per (row, slice) or NULL when nslices == 1.
+ * slice_cnt: nrows x (nslices*ngroups) entry counts per (row, slice, column group), index
+ *        s*ngroups + g, or NULL when nslices*ngroups == 1.  ngroups > 1 additionally orders
+ *        every segment column-group-major (see the plan description in csrc/pgcn_core.cpp);
+ *        rows with fewer than group_min_row entries keep one piece per slice.
  * tasks: 4 x int32 per task {kbeg low, kbeg high, length, dst}: absolute offset of the
  *        first entry, number of entries, dst >= 0 partial slot / dst < 0 direct row ~dst;
  *        grouped by slice, longest first; seg (out, nslices+1) = segment boundaries.
@@ -94,7 +98,8 @@ int pgcn_spmm_csr_plan_f32(const int64_t *rowptr, const int32_t *col, const floa
  * Call with tasks == NULL to obtain the counts, then again with buffers.      */
 int pgcn_spmm_plan_host(const int64_t *rowptr_host, const int32_t *slice_cnt,
                         const uint8_t *row_flags, int64_t nrows,
-                        int32_t nslices, int32_t chunk, int32_t small_row, int32_t *tasks,
+                        int32_t nslices, int32_t ngroups, int32_t group_min_row, int32_t chunk,
+                        int32_t small_row, int32_t *tasks,
                         int64_t cap_tasks, int32_t *fix, int64_t cap_fix, int64_t *seg,
                         int64_t *ntasks, int64_t *nfix, int64_t *nslots);
 

@@ -109,12 +109,7 @@ def get_partitiont_of_adjacency_matrix(A, partvec, rank):
     exch = None
     if size > 1:
         if _exchanger is None:
-            dev = torch.device(device)
-            backend = dist.get_backend()
-            use_rccl = (_exchange_impl == "rccl") or (_exchange_impl == "auto" and dev.type == "cuda"
-                                                      and backend == "nccl")
-            _exchanger = (_engine.RcclExchanger(rank, size, dev) if use_rccl
-                          else _engine.TorchDistExchanger(rank, size))
+            _exchanger = _engine.make_exchanger(rank, size, torch.device(device), _exchange_impl)
         exch = _exchanger
     _engine_current = _engine.AggregationEngine(p, _provider(), torch.device(device), exch)
     return _engine_current

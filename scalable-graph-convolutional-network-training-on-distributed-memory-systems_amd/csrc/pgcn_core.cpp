@@ -51,6 +51,11 @@ extern "C" int pgcn_device_info(int32_t device, int64_t out[4]) {
 //   * rows with at most `small_row` entries are NOT sliced: one task, direct write,
 //     placed round-robin over the segments (slicing them would multiply the per-task
 //     latency chain and the partial-sum traffic for a handful of entries).
+//   * ngroups > 1 ("column groups"): inside a slice the entries are further grouped by
+//     column range g (slice_cnt has nslices*ngroups columns, index s*ngroups + g); a task
+//     never crosses a group and every segment is ordered group-major, so at any time the
+//     tasks resident on an XCD read one column group: (XCD, time) slicing makes the L2
+//     working set 1/(8*ngroups) of B.
 //   * pieces longer than `chunk` are cut into balanced segments.
 //   * a row with exactly one task writes C directly; a row with several tasks gets
 //     consecutive partial-sum slots and one fix-up record {row, first slot, #tasks},
@@ -59,19 +64,34 @@ extern "C" int pgcn_device_info(int32_t device, int64_t out[4]) {
 //   * inside every segment the tasks are ordered by decreasing length (stable):
 //     longest-first scheduling, and the tasks sharing a wavefront have equal trip counts.
 namespace {
-struct TaskRec { int64_t kbeg; int32_t len; int32_t dst; };
+struct TaskRec { int64_t kbeg; int32_t len; int32_t dst; int32_t grp; };
 }
 
 extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_cnt,
-                                   const uint8_t *row_flags, int64_t nrows, int32_t nslices, int32_t chunk, int32_t small_row,
+                                   const uint8_t *row_flags, int64_t nrows, int32_t nslices,
+                                   int32_t ngroups, int32_t group_min_row, int32_t chunk,
+                                   int32_t small_row,
                                    int32_t *tasks, int64_t cap_tasks, int32_t *fix,
                                    int64_t cap_fix, int64_t *seg, int64_t *ntasks,
                                    int64_t *nfix, int64_t *nslots) {
     if (!rowptr || nrows < 0 || chunk <= 0 || small_row < 0 || !ntasks || !nfix || !nslots || !seg ||
-        nslices < 1 || nslices > PGCN_MAX_SLICES || (nslices > 1 && !slice_cnt))
+        nslices < 1 || nslices > PGCN_MAX_SLICES || ngroups < 1 || ngroups > PGCN_MAX_COL_GROUPS ||
+        (nslices * ngroups > 1 && !slice_cnt))
         return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: bad argument");
     if (nrows > 0x7fffffffLL) return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: nrows >= 2^31");
-    const int S = nslices;
+    const int S = nslices;           // XCD slices = task segments
+    const int G = ngroups;           // column groups inside a slice (time-ordered)
+    const int V = S * G;             // "virtual slices": entries of a row are grouped by v = s*G + g
+    // rows shorter than group_min_row are cut per slice only: their column groups are merged
+    // back (cutting a medium row 8*G ways would only multiply tiny tasks and partial sums)
+    auto piece_len = [&](int64_t r, int64_t len, int v) -> int64_t {
+        if (V == 1) return len;
+        if (G == 1 || len >= group_min_row) return slice_cnt[r * V + v];
+        if (v % G != 0) return 0;
+        int64_t l = 0;
+        for (int g = 0; g < G; ++g) l += slice_cnt[r * V + v + g];
+        return l;
+    };
     if (small_row > chunk) small_row = chunk;
     // pass 1: tasks per segment; slots per row
     int64_t per_slice[PGCN_MAX_SLICES] = {0};
@@ -80,29 +100,29 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
         const int64_t len = rowptr[r + 1] - rowptr[r];
         if (len < 0 || len > 0x7fffffffLL)
             return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: row pointer not monotone / row too long");
-        if (S > 1) {
+        if (V > 1) {
             int64_t sum = 0;
-            for (int s = 0; s < S; ++s) {
-                if (slice_cnt[r * S + s] < 0)
+            for (int v = 0; v < V; ++v) {
+                if (slice_cnt[r * V + v] < 0)
                     return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: negative slice count");
-                sum += slice_cnt[r * S + s];
+                sum += slice_cnt[r * V + v];
             }
             if (sum != len)
                 return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_plan_host: slice counts do not add up to the row length");
         }
         const bool shared = row_flags && row_flags[r];   // other kernels add into this row
         if (shared && len == 0) continue;                // nothing of ours to add
-        if (len <= small_row || (S == 1 && len <= chunk)) {   // one unsliced task (also: empty row)
+        if (len <= small_row || (V == 1 && len <= chunk)) {   // one unsliced task (also: empty row)
             per_slice[r % S] += 1;
             nt += 1;
             if (shared) { ns += 1; ++nf; }
             continue;
         }
         int64_t row_tasks = 0;
-        for (int s = 0; s < S; ++s) {
-            const int64_t l = (S == 1) ? len : slice_cnt[r * S + s];
+        for (int v = 0; v < V; ++v) {
+            const int64_t l = piece_len(r, len, v);
             const int64_t k = (l + chunk - 1) / chunk;
-            per_slice[s] += k;
+            per_slice[v / G] += k;
             row_tasks += k;
         }
         nt += row_tasks;
@@ -125,19 +145,19 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
         const int64_t len = rowptr[r + 1] - rowptr[r];
         const bool shared = row_flags && row_flags[r];
         if (shared && len == 0) continue;
-        if (len <= small_row || (S == 1 && len <= chunk)) {
+        if (len <= small_row || (V == 1 && len <= chunk)) {
             if (shared) {
                 int32_t *x = fix + 4 * fi++;
                 x[0] = (int32_t)r; x[1] = (int32_t)slot; x[2] = 1; x[3] = 0;
-                rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, (int32_t)slot++};
+                rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, (int32_t)slot++, 0};
             } else {
-                rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, ~(int32_t)r};
+                rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, ~(int32_t)r, 0};
             }
             continue;
         }
         int64_t row_tasks = 0;
-        for (int s = 0; s < S; ++s) {
-            const int64_t l = (S == 1) ? len : slice_cnt[r * S + s];
+        for (int v = 0; v < V; ++v) {
+            const int64_t l = piece_len(r, len, v);
             row_tasks += (l + chunk - 1) / chunk;
         }
         const bool direct = row_tasks == 1 && !shared;
@@ -146,25 +166,28 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
             x[0] = (int32_t)r; x[1] = (int32_t)slot; x[2] = (int32_t)row_tasks; x[3] = 0;
         }
         int64_t off = 0;
-        for (int s = 0; s < S; ++s) {
-            const int64_t l = (S == 1) ? len : slice_cnt[r * S + s];
+        for (int v = 0; v < V; ++v) {
+            const int64_t l = piece_len(r, len, v);
             const int64_t k = (l + chunk - 1) / chunk;
             if (k > 0) {
                 const int64_t piece = (l + k - 1) / k;   // balanced segments
                 for (int64_t j = 0; j < k; ++j) {
                     const int64_t o = j * piece;
                     const int64_t ll = (o + piece <= l) ? piece : (l - o);
-                    rec[cur[s]++] = TaskRec{rowptr[r] + off + o, (int32_t)ll,
-                                            direct ? ~(int32_t)r : (int32_t)slot++};
+                    rec[cur[v / G]++] = TaskRec{rowptr[r] + off + o, (int32_t)ll,
+                                                direct ? ~(int32_t)r : (int32_t)slot++, v % G};
                 }
             }
             off += l;
         }
     }
-    // longest first inside each segment
+    // inside each segment: column group by column group (the workgroups of an XCD sweep the
+    // column space together, so their common working set is one group = a few MB of B), longest
+    // first inside a group
     for (int s = 0; s < S; ++s)
-        std::stable_sort(rec + seg[s], rec + seg[s + 1],
-                         [](const TaskRec &a, const TaskRec &b) { return a.len > b.len; });
+        std::stable_sort(rec + seg[s], rec + seg[s + 1], [](const TaskRec &a, const TaskRec &b) {
+            return a.grp != b.grp ? a.grp < b.grp : a.len > b.len;
+        });
     for (int64_t i = 0; i < nt; ++i) {
         int32_t *t = tasks + 4 * i;
         t[0] = (int32_t)(uint32_t)((uint64_t)rec[i].kbeg & 0xffffffffu);

@@ -22,6 +22,7 @@
 // no atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pgcn_device.h"
 #include "pgcn_internal.h"
@@ -272,7 +273,10 @@ extern "C" int pgcn_spmm_core_f32(const int32_t *work, int64_t nwork, const int3
     hipStream_t s = (hipStream_t)stream;
     const bool v4 = aligned16(B, partial_ws, ldb, 4, f);
     if (v4) {
-        const size_t smem = (size_t)(TC + 1) * 32 * 4 * 4 + (kCoreThreads / 64) * 512;
+        size_t smem = (size_t)(TC + 1) * 32 * 4 * 4 + (kCoreThreads / 64) * 512;
+        static long pad = -1;   // experiment knob: extra dynamic LDS => one workgroup per CU
+        if (pad < 0) { const char *e = getenv("PGCN_CORE_LDS_PAD"); pad = e ? atol(e) : 0; }
+        smem += (size_t)pad;
         static bool attr_set = false;
         if (!attr_set) {
             PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_core_kernel<4>,

@@ -109,6 +109,42 @@ class RcclExchanger:
             self.comm = None
 
 
+def make_exchanger(rank: int, size: int, device: torch.device, impl: str = "auto", group=None):
+    """Pick the boundary-row transport.  'rccl' = libpgcn_hip.so's own communicator (C ABI),
+    'torch' = torch.distributed all_to_all_single (RCCL under backend nccl, gloo otherwise).
+    'auto' uses the C-ABI communicator on GPUs under nccl after a self-test against
+    torch.distributed (both are RCCL: this is a choice of API, not a CPU fallback)."""
+    device = torch.device(device)
+    backend = dist.get_backend(group)
+    if impl == "torch" or device.type != "cuda" or backend != "nccl":
+        return TorchDistExchanger(rank, size, group)
+    try:
+        ex = RcclExchanger(rank, size, device, group)
+        f = 4
+        send_off = [0]
+        recv_off = [0]
+        for q in range(size):
+            send_off.append(send_off[-1] + (0 if q == rank else 1 + (rank + q) % 3))
+            recv_off.append(recv_off[-1] + (0 if q == rank else 1 + (rank + q) % 3))
+        send = (torch.arange(send_off[-1] * f, device=device, dtype=torch.float32) + 1000 * rank).view(-1, f)
+        got = torch.full((max(recv_off[-1], 1), f), -1.0, device=device)
+        ref = torch.full((max(recv_off[-1], 1), f), -2.0, device=device)
+        ex.alltoallv(send, send_off, got, recv_off, f)
+        TorchDistExchanger(rank, size, group).alltoallv(send, send_off, ref, recv_off, f)
+        torch.cuda.synchronize(device)
+        ok = torch.tensor([1.0 if torch.equal(got[:recv_off[-1]], ref[:recv_off[-1]]) else 0.0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if float(ok) == 1.0:
+            return ex
+        ex.close()
+    except _lib.PgcnError:
+        if impl == "rccl":
+            raise
+    if impl == "rccl":
+        raise _lib.PgcnError("C-ABI RCCL exchanger failed its self-test")
+    return TorchDistExchanger(rank, size, group)
+
+
 # --------------------------------------------------------------------------
 
 

@@ -26,6 +26,7 @@ from .partition import HostCSR
 
 DEFAULT_CHUNK = int(os.environ.get("PGCN_SPMM_CHUNK", "1024"))
 DEFAULT_SMALL_ROW = int(os.environ.get("PGCN_SPMM_SMALL_ROW", "96"))
+GROUP_MIN_ROW = int(os.environ.get("PGCN_GROUP_MIN_ROW", "4096"))
 
 
 @dataclass
@@ -73,7 +74,8 @@ class DeviceCore:
 
 def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarray] = None,
                small_row: int = DEFAULT_SMALL_ROW, force: bool = False,
-               row_flags: Optional[np.ndarray] = None):
+               row_flags: Optional[np.ndarray] = None, ngroups: int = 1,
+               group_min_row: int = GROUP_MIN_ROW):
     """Host-side task list (pgcn_spmm_plan_host).  Returns (tasks, fix, nslots, seg) with
     numpy int32 arrays; tasks is None when the plan is trivial (unsliced and no row
     exceeds ``chunk``): the one-task-per-row kernel path needs no plan."""
@@ -84,7 +86,8 @@ def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarr
     sc_ptr = None
     if slice_cnt is not None:
         slice_cnt = np.ascontiguousarray(slice_cnt, dtype=np.int32)
-        S = slice_cnt.shape[1]
+        S = slice_cnt.shape[1] // ngroups
+        assert S * ngroups == slice_cnt.shape[1]
         sc_ptr = slice_cnt.ctypes.data
     rf_ptr = None
     if row_flags is not None:
@@ -93,14 +96,14 @@ def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarr
         force = True
     seg = (ctypes.c_int64 * (S + 1))()
     nt, nf, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, chunk, small_row, None, 0,
+    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row, None, 0,
                                      None, 0, seg, ctypes.byref(nt), ctypes.byref(nf), ctypes.byref(ns)),
                "pgcn_spmm_plan_host")
     if nf.value == 0 and S == 1 and not force:
         return None, None, 0, None
     tasks = np.empty((nt.value, 4), dtype=np.int32)
     fix = np.empty((max(nf.value, 1), 4), dtype=np.int32)
-    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, chunk, small_row,
+    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row,
                                      tasks.ctypes.data, nt.value, fix.ctypes.data, nf.value, seg, ctypes.byref(nt),
                                      ctypes.byref(nf), ctypes.byref(ns)), "pgcn_spmm_plan_host")
     return tasks, fix[:nf.value], int(ns.value), seg
@@ -141,7 +144,8 @@ class HipKernels:
         sc = None if csr.slice_cnt is None else csr.slice_cnt.detach().cpu().numpy()
         rf = None if csr.row_flags is None else csr.row_flags.detach().cpu().numpy()
         tasks, fix, nslots, seg = build_plan(rowptr_host, self.chunk, sc, self.small_row,
-                                             force=csr.row_map is not None, row_flags=rf)
+                                             force=csr.row_map is not None, row_flags=rf,
+                                             ngroups=csr.ngroups)
         d = DeviceCSR(
             nrows=csr.nrows, ncols=csr.ncols, nnz=csr.nnz,
             rowptr=csr.rowptr.to(dev, torch.int64).contiguous(),

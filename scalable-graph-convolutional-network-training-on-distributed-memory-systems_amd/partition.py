@@ -38,8 +38,9 @@ class HostCSR:
     col: torch.Tensor
     val: torch.Tensor
     row_map: Optional[torch.Tensor] = None  # compact row r -> output row row_map[r] (int32)
-    nslices: int = 1                          # entries of a row are grouped by col % nslices
-    slice_cnt: Optional[torch.Tensor] = None  # int32 [nrows, nslices] entries per (row, slice)
+    nslices: int = 1                          # entries of a row are grouped by col % nslices ...
+    slice_cnt: Optional[torch.Tensor] = None  # int32 [nrows, nslices*ngroups] entries per (row, slice, group)
+    ngroups: int = 1                          # ... then by column group = col // group_width
     core: Optional["HostCore"] = None         # entries of dense tiles, stored for the LDS-tiled kernel
     row_flags: Optional[torch.Tensor] = None  # uint8 [nrows]: row also receives core partial sums
 
@@ -192,9 +193,23 @@ def pick_nslices(ncols: int) -> int:
     return NSLICES if (NSLICES > 1 and ncols >= SLICE_MIN_COLS) else 1
 
 
+# column groups: the share of the feature panel one XCD sees during one group should fit its
+# 4 MiB L2 with room for the streams (nominal row width 512 B = 128 fp32 features)
+COL_GROUPS = os.environ.get("PGCN_COL_GROUPS", "1")   # measured: no gain on the benchmark graph (r01)
+GROUP_L2_BYTES = float(os.environ.get("PGCN_GROUP_L2_MB", "2.5")) * (1 << 20)
+
+
+def pick_ngroups(ncols: int, nslices: int) -> int:
+    if nslices <= 1:
+        return 1
+    if COL_GROUPS != "auto":
+        return max(1, min(64, int(COL_GROUPS)))
+    return max(1, min(64, int(-(-(ncols * 512) // int(nslices * GROUP_L2_BYTES)))))
+
+
 def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
                  compact_rows: bool = False, nslices: Optional[int] = None, core: bool = False,
-                 tau: float = None, emax: int = None) -> HostCSR:
+                 tau: float = None, emax: int = None, ngroups: Optional[int] = None) -> HostCSR:
     """Sort by (row, col % nslices, col) and build CSR.  Duplicate entries are kept as
     separate stored entries (an uncoalesced COO sums them, PGCN.py:63).  With ``core``
     the entries of dense 128 x 128 tiles are split off into a HostCore (LDS-tiled kernel)."""
@@ -202,6 +217,8 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     if nslices is None:
         nslices = pick_nslices(ncols)
     S = nslices
+    G = pick_ngroups(ncols, S) if ngroups is None else (ngroups if S > 1 else 1)
+    gw = max(1, -(-ncols // G))          # columns per group
     hcore, row_flags = None, None
     if core and not compact_rows and r.numel():
         keep, hcore = split_core(r, c, v, nrows, ncols, tau, emax)
@@ -213,7 +230,7 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
             row_flags[rows[rows < nrows]] = 1
     if r.numel():
         r64, c64 = r.to(torch.int64), c.to(torch.int64)
-        key = (r64 * S + c64 % S) * max(ncols, 1) + c64
+        key = (r64 * S + c64 % S) * max(ncols, 1) + c64      # (row, slice, col): col order = group order
         order = torch.argsort(key, stable=True)
         r, c, v = r[order], c[order], v[order]
     row_map = None
@@ -227,23 +244,28 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     rowptr[1:] = torch.cumsum(counts, 0)
     slice_cnt = None
     if S > 1:
+        V = S * G
         if r.numel():
-            slice_cnt = torch.bincount(r.to(torch.int64) * S + c.to(torch.int64) % S,
-                                       minlength=nrows * S).to(torch.int32).reshape(nrows, S)
+            c64 = c.to(torch.int64)
+            vs = (c64 % S) * G + torch.clamp(c64 // gw, max=G - 1)
+            slice_cnt = torch.bincount(r.to(torch.int64) * V + vs,
+                                       minlength=nrows * V).to(torch.int32).reshape(nrows, V)
         else:
-            slice_cnt = torch.zeros((nrows, S), dtype=torch.int32, device=dev)
+            slice_cnt = torch.zeros((nrows, V), dtype=torch.int32, device=dev)
+    else:
+        G = 1
     return HostCSR(nrows, ncols, rowptr, c.to(torch.int32).contiguous(),
-                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, hcore, row_flags)
+                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, G, hcore, row_flags)
 
 
 def csr_from_scipy(A, nslices: Optional[int] = None, core: bool = False, tau: float = None,
-                   emax: int = None) -> HostCSR:
+                   emax: int = None, ngroups: Optional[int] = None) -> HostCSR:
     """Convenience for tests / tools: a scipy sparse matrix -> HostCSR (optionally sliced)."""
     import numpy as np
     A = A.tocoo()
     return csr_from_coo(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
                         torch.from_numpy(A.data.astype(np.float32)), A.shape[0], A.shape[1],
-                        nslices=nslices, core=core, tau=tau, emax=emax)
+                        nslices=nslices, core=core, tau=tau, emax=emax, ngroups=ngroups)
 
 
 @dataclass

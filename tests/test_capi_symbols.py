@@ -33,15 +33,14 @@ def _decode(tasks):
     return kbeg, tasks[:, 2].astype(np.int64), tasks[:, 3].astype(np.int64)
 
 
-def _check_plan(rowptr, tasks, fix, nslots, seg, chunk, cnt=None, small_row=0):
+def _check_plan(rowptr, tasks, fix, nslots, seg, chunk, cnt=None, small_row=0, ngroups=1):
     """Every stored entry is covered exactly once, by a task of its own row; slots of a row
     are consecutive; segments are sorted longest-first; sliced tasks stay inside a slice."""
     kbeg, ln, dst = _decode(tasks)
     nrows = rowptr.shape[0] - 1
     seg = list(seg)
     assert seg[0] == 0 and seg[-1] == tasks.shape[0]
-    for a, b in zip(seg, seg[1:]):
-        assert (np.diff(ln[a:b]) <= 0).all()
+    grp_of = np.zeros(tasks.shape[0], np.int64)
     assert (ln <= chunk).all()
     cover = np.zeros(rowptr[-1], np.int32)
     slot_row = {}
@@ -59,9 +58,15 @@ def _check_plan(rowptr, tasks, fix, nslots, seg, chunk, cnt=None, small_row=0):
         cover[kbeg[i]:kbeg[i] + ln[i]] += 1
         if cnt is not None and cnt[row].sum() > small_row and ln[i]:
             bounds = rowptr[row] + np.concatenate([[0], np.cumsum(cnt[row])])
-            s = np.searchsorted(bounds, kbeg[i], side="right") - 1
-            assert kbeg[i] + ln[i] <= bounds[s + 1]              # never crosses its slice
+            v = np.searchsorted(bounds, kbeg[i], side="right") - 1
+            assert kbeg[i] + ln[i] <= bounds[v + 1]              # never crosses its (slice, group)
+            s = v // ngroups
+            grp_of[i] = v % ngroups
             assert seg[s] <= i < seg[s + 1]                      # and sits in that slice's segment
+    for a, b in zip(seg, seg[1:]):                               # group-major, longest first inside a group
+        g, l = grp_of[a:b], ln[a:b]
+        assert (np.diff(g) >= 0).all()
+        assert (np.diff(l)[np.diff(g) == 0] <= 0).all()
     assert (cover == 1).all()
     assert sorted(direct_rows + [r for r, _, _ in fix]) == list(range(nrows))   # each row written once
 
@@ -97,6 +102,15 @@ def test_plan_host_sliced():
     for small in (0, 96):
         tasks, fix, nslots, seg = kernels.build_plan(rowptr, 256, cnt, small_row=small)
         _check_plan(rowptr, tasks, fix[:, :3], nslots, seg, 256, cnt, small)
+        # the same counts read as 4 slices x 2 column groups
+        t2, f2, n2, seg2 = kernels.build_plan(rowptr, 256, cnt, small_row=small, ngroups=2, group_min_row=0)
+        assert len(list(seg2)) == 5
+        _check_plan(rowptr, t2, f2[:, :3], n2, seg2, 256, cnt, small, ngroups=2)
+        # with a large group_min_row every row is cut per slice only (groups merged)
+        t3, f3, n3, seg3 = kernels.build_plan(rowptr, 256, cnt, small_row=small, ngroups=2, group_min_row=10**6)
+        merged = cnt.reshape(nrows, 4, 2).sum(2)
+        _check_plan(rowptr, t3, f3[:, :3], n3, seg3, 256, merged, small)
+        assert t3.shape[0] < t2.shape[0]
         kbeg, ln, dst = _decode(tasks)
         assert ((dst == ~5) & (ln == 0)).sum() == 1
         assert ((dst == ~6) & (ln == 150)).sum() == 1
@@ -110,7 +124,7 @@ def test_error_reporting_without_gpu():
     _lib = pkg("_lib")
     L = _lib.lib()
     nt = ctypes.c_int64()
-    rc = L.pgcn_spmm_plan_host(None, None, None, 4, 1, 1024, 0, None, 0, None, 0, None, ctypes.byref(nt),
+    rc = L.pgcn_spmm_plan_host(None, None, None, 4, 1, 1, 0, 1024, 0, None, 0, None, 0, None, ctypes.byref(nt),
                                ctypes.byref(nt), ctypes.byref(nt))
     assert rc == -1 and b"pgcn_spmm_plan_host" in L.pgcn_last_error()
     with pytest.raises(_lib.PgcnError):

@@ -130,8 +130,9 @@ def test_spmm_dense_core_lds_kernel(K, dev, f, nslices):
     rank[torch.argsort(-deg, stable=True)] = torch.arange(n)
     r, c = rank[row], rank[col]
     A = sp.csr_matrix((val.numpy(), (r.numpy(), c.numpy())), shape=(n, n))
-    h = partition.csr_from_coo(r, c, val, n, n, nslices=nslices, core=True, tau=0.05, emax=6000)
-    assert h.core is not None and h.core.nnz > 0.2 * A.nnz
+    h = partition.csr_from_coo(r, c, val, n, n, nslices=nslices, core=True, tau=0.05, emax=6000,
+                               ngroups=3 if nslices > 1 else None)
+    assert h.core is not None and h.core.nnz > 0.2 * A.nnz and h.ngroups == (3 if nslices > 1 else 1)
     d = K.prepare(h)
     assert d.core is not None and d.nslots_total == d.nslots + h.core.nslots
     rng = np.random.default_rng(f)

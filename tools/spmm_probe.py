@@ -54,8 +54,14 @@ def main():
                 for t in args.libs.split(",")}
     prepared = {}
     for name in names:
-        # name: s<slices>c<chunk>[x][k[tau]] (x = xcd swizzle for unsliced; k = degree sort + LDS core)
-        S = int(name[1:name.index("c")])
+        # name: s<slices>[g<groups>]c<chunk>[x][k[tau]] (g = column groups; x = xcd swizzle for
+        # unsliced; k = degree sort + LDS core)
+        head = name[1:name.index("c")]
+        G = None
+        if "g" in head:
+            head, gs = head.split("g")
+            G = int(gs)
+        S = int(head)
         rest = name[name.index("c") + 1:]
         tau = None
         core = "k" in rest
@@ -68,9 +74,9 @@ def main():
             deg = torch.bincount(row, minlength=n) + torch.bincount(col, minlength=n)
             rank = torch.empty(n, dtype=torch.int64, device=dev)
             rank[torch.argsort(-deg, stable=True)] = torch.arange(n, device=dev)
-            h = partition.csr_from_coo(rank[row], rank[col], val, n, n, nslices=S, core=True, tau=tau)
+            h = partition.csr_from_coo(rank[row], rank[col], val, n, n, nslices=S, core=True, tau=tau, ngroups=G)
         else:
-            h = partition.csr_from_coo(row, col, val, n, n, nslices=S)
+            h = partition.csr_from_coo(row, col, val, n, n, nslices=S, ngroups=G)
         K.chunk = chunk
         d = K.prepare(h)
         for tag, L in libs.items():
