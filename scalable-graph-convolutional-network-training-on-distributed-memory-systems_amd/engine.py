@@ -118,11 +118,11 @@ def make_exchanger(rank: int, size: int, device: torch.device, impl: str = "auto
     backend = dist.get_backend(group)
     if impl == "torch" or device.type != "cuda" or backend != "nccl":
         return TorchDistExchanger(rank, size, group)
+    ex, good = None, 0.0
     try:
         ex = RcclExchanger(rank, size, device, group)
         f = 4
-        send_off = [0]
-        recv_off = [0]
+        send_off, recv_off = [0], [0]
         for q in range(size):
             send_off.append(send_off[-1] + (0 if q == rank else 1 + (rank + q) % 3))
             recv_off.append(recv_off[-1] + (0 if q == rank else 1 + (rank + q) % 3))
@@ -132,14 +132,15 @@ def make_exchanger(rank: int, size: int, device: torch.device, impl: str = "auto
         ex.alltoallv(send, send_off, got, recv_off, f)
         TorchDistExchanger(rank, size, group).alltoallv(send, send_off, ref, recv_off, f)
         torch.cuda.synchronize(device)
-        ok = torch.tensor([1.0 if torch.equal(got[:recv_off[-1]], ref[:recv_off[-1]]) else 0.0], device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if float(ok) == 1.0:
-            return ex
-        ex.close()
+        good = 1.0 if torch.equal(got[:recv_off[-1]], ref[:recv_off[-1]]) else 0.0
     except _lib.PgcnError:
-        if impl == "rccl":
-            raise
+        good = 0.0
+    ok = torch.tensor([good], device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # every rank takes the same decision
+    if float(ok) == 1.0:
+        return ex
+    if ex is not None:
+        ex.close()
     if impl == "rccl":
         raise _lib.PgcnError("C-ABI RCCL exchanger failed its self-test")
     return TorchDistExchanger(rank, size, group)
