@@ -11,11 +11,13 @@ aggregations A.H through the HIP engine.  Metric: edges aggregated per second
 = 2.L.nnz / t_epoch, whole job; ms_per_step = ms/epoch.
 
 Extra objects in the JSON line:
-  roofline     dominant kernel = the local CSR SpMM (spmm_tasks_kernel): algorithmic bytes
-               (8.nnz + 8.(n_r+1) + 4.f.n_c + 4.f.n_r) / its average launch
-               duration, measured live with HIP events on the launch stream inside the
-               timed region; peak 8 TB/s.  `traffic` comes from separate rocprofv3 --pmc
-               passes (profiles/*.json) when present, else null.
+  roofline     dominant kernel = the local-block SpMM A_loc.H, which is one launch GROUP:
+               spmm_tasks_kernel (XCD-sliced gather part) + spmm_core_kernel (LDS-tiled dense
+               core) + the fix-up that adds their partial sums.  achieved = algorithmic bytes
+               (8.nnz + 8.(n_r+1) + 4.f.n_c + 4.f.n_r) / the group's average
+               duration, measured live with HIP events on the launch stream inside the timed
+               region; peak 8 TB/s.  `traffic` comes from separate rocprofv3 --pmc passes
+               (profiles/pmc_traffic.json, summed over the group) when present, else null.
   cpu_baseline the CPU oracle (GraphBLAS-free restatement of Parallel-GCN's SpMM, OpenMP)
                timed on this host on a bounded sample: rank 0, N = 1 only.
 """
@@ -215,7 +217,12 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "spmm_tasks_kernel<32,4> (A_loc . H, forward)",
+        kname = "A_loc.H forward SpMM = spmm_tasks_kernel<32,4,1,1> (gather part)"
+        if eng.A_loc.core is not None:
+            kname += " + spmm_core_kernel<4> (LDS-tiled dense core, %.0f%% of the entries)" % (
+                100.0 * eng.A_loc.core.nnz / max(eng.A_loc.nnz, 1))
+        kname += " + fix-up; one launch group, timed as a whole"
+        roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK, "traffic": traffic,
                     "alg_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": launches,

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
     float2 *mrow = meta_lds[wave];
     for (int base = 0; __any(base < len); base += LPR) {
         __builtin_amdgcn_wave_barrier();
-        mrow[lane] = make_float2(__int_as_float(nc), nv);
+        mrow[lane] = make_float2(__int_as_float(len > 0 ? nc : 0), nv);
         __builtin_amdgcn_wave_barrier();
         {
             int e = base + LPR + sub;
@@ -169,51 +169,40 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
         const float2 *mg = mrow + gbase;
 #pragma unroll
         for (int k = 0; k < LPR; k += U) {
-            if (__all(k + U <= cnt)) {
-                // fast path: every group of the wave has U more entries.  All broadcasts
-                // first, then U independent unpredicated row loads, then the FMAs.
-                int32_t c[U];
-                float w[U];
-                float x[U][VEC];
-                if constexpr (U >= 2) {
+            if (!__any(k < cnt)) break;
+            // U independent row loads, all unpredicated and issued back to back (a branch per
+            // load serialises them behind the broadcasts).  In a ragged batch the surplus
+            // slots re-read the task's LAST referenced row (the clamped pair parked above; row 0
+            // for an empty group) and are zeroed by a select before the FMA, so no row the task
+            // does not reference is ever combined into the result (no 0 * Inf).
+            const bool full = __all(k + U <= cnt);
+            int32_t c[U];
+            float w[U];
+            float x[U][VEC];
+            if constexpr (U >= 2) {
 #pragma unroll
-                    for (int u = 0; u < U; u += 2) {
-                        const float4 m = *reinterpret_cast<const float4 *>(mg + k + u);
-                        c[u] = __float_as_int(m.x); w[u] = m.y;
-                        c[u + 1] = __float_as_int(m.z); w[u + 1] = m.w;
+                for (int u = 0; u < U; u += 2) {
+                    const float4 m = *reinterpret_cast<const float4 *>(mg + k + u);
+                    c[u] = __float_as_int(m.x); w[u] = m.y;
+                    c[u + 1] = __float_as_int(m.z); w[u + 1] = m.w;
+                }
+            } else {
+                const float2 m = mg[k];
+                c[0] = __float_as_int(m.x); w[0] = m.y;
+            }
+            if (fact) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) load_row<VEC, OFF32>(x[u], B, lane_off, c[u], ldb);
+                if (!full) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const bool keep = k + u < cnt;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) x[u][v] = keep ? x[u][v] : 0.f;
                     }
-                } else {
-                    const float2 m = mg[k];
-                    c[0] = __float_as_int(m.x); w[0] = m.y;
                 }
-                if (fact) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) load_row<VEC, OFF32>(x[u], B, lane_off, c[u], ldb);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) vfma<VEC>(acc, w[u], x[u]);
-                }
-            } else if (__any(k < cnt)) {
-                // ragged tail of a task (or groups of different length): predicated loads,
-                // so rows that are not referenced are never touched (no 0 * Inf).
-#pragma unroll
-                for (int u0 = 0; u0 < U; u0 += 4) {
-                    float x[4][VEC];
-                    float w[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (u0 + u < U) {
-                            const float2 m = mg[k + u0 + u];
-                            w[u] = m.y;
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
-                            if (fact && (k + u0 + u < cnt))
-                                load_row<VEC, OFF32>(x[u], B, lane_off, __float_as_int(m.x), ldb);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (u0 + u < U) vfma<VEC>(acc, w[u], x[u]);
-                }
+                for (int u = 0; u < U; ++u) vfma<VEC>(acc, w[u], x[u]);
             }
         }
     }
