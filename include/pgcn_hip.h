@@ -33,6 +33,7 @@ extern "C" {
 #define PGCN_EHIP (-2)    /* a HIP runtime call / kernel launch failed              */
 #define PGCN_ERCCL (-3)   /* an RCCL call failed                                    */
 #define PGCN_ENOMEM (-4)  /* caller-provided capacity / work-space too small        */
+#define PGCN_EUNSUPPORTED (-5) /* valid input of a kind this library does not handle  */
 
 typedef void *pgcn_stream_t; /* hipStream_t */
 
@@ -53,6 +54,16 @@ const char *pgcn_last_error(void);
 /* ---- device query (plumbing for the bench / tests) ---------------------- */
 /* out[0]=#CUs, out[1]=wavefront size, out[2]=gcnArch number (950), out[3]=L2 bytes */
 int pgcn_device_info(int32_t device, int64_t out[4]);
+
+/* ---- MatrixMarket ingest (host only, multi-threaded) -----------------------------
+ * replaces scipy.io.mmread(path_A)             GPU/PGCN.py:171   ("next" row N1)
+ * out[0..2] = rows, cols, stored entries; out[3] = bit0 pattern | bit1 symmetric |
+ * bit2 skew-symmetric | bit3 integer.  pgcn_mtx_read_coo fills 0-based COO arrays of
+ * capacity `cap` (>= 2 x stored entries is always enough); symmetric / skew-symmetric
+ * files are expanded like mmread does.  nthreads <= 0: all hardware threads.         */
+int pgcn_mtx_info(const char *path, int64_t out[4]);
+int pgcn_mtx_read_coo(const char *path, int64_t cap, int64_t *row, int64_t *col, float *val,
+                      int64_t *nnz_out, int32_t nthreads);
 
 /* ---- CSR SpMM ------------------------------------------------------------
  * C[nrows x f] (+)= A[nrows x *] . B[* x f]

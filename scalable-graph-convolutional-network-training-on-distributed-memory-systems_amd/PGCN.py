@@ -36,6 +36,7 @@ import torch.nn.functional as F
 from scipy.io import mmread
 
 from . import engine as _engine
+from . import ingest as _ingest
 from . import kernels as _kernels
 from . import partition as _partition
 
@@ -221,13 +222,25 @@ class PGCN(nn.Module):
         return H
 
 
+def _all_reduce(t, op=dist.ReduceOp.SUM):
+    """dist.all_reduce that also works for device tensors under the gloo backend (the transport
+    then stages through the host, like the boundary-row exchange does)."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def average_gradients(model):
     """PGCN.py:150-154, as ONE fused all-reduce of all layers' gradients."""
     if world_size <= 1:
         return
     grads = [p.grad.data for p in model.parameters()]
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _all_reduce(flat)
     flat /= world_size
     o = 0
     for g in grads:
@@ -240,7 +253,7 @@ def initiliaze_parameters(model):
     if world_size <= 1:
         return
     for param in model.parameters():
-        dist.all_reduce(param.data, op=dist.ReduceOp.SUM)
+        _all_reduce(param.data)
         param.data /= world_size
 
 
@@ -271,7 +284,7 @@ def run(rank, size, nlayers, nfeatures, path_A, path_partvec, backend):
         raise _kernels._lib.PgcnError("no HIP device visible: refusing to run (no CPU fallback); "
                                       "backend=%s only selects the transport" % backend)
 
-    A = mmread(path_A)
+    A = _ingest.mmread(path_A)          # C++ multi-threaded reader, same result as scipy's mmread
     with open(path_partvec) as f:
         partvec = list(map(int, f.readline().split()))
     n = A.shape[0]
@@ -321,15 +334,15 @@ def run(rank, size, nlayers, nfeatures, path_A, path_partvec, backend):
     elapsed = time.time() - start
     elapsed = torch.tensor([elapsed], device=device)
     if size > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        _all_reduce(elapsed, dist.ReduceOp.MAX)
 
     _sync_stats(A)
     print(stats, flush=True)
     total_vol = stats["send_volume"].to(device)
     total_nmsg = stats["send_nmsg"].to(device)
     if size > 1:
-        dist.all_reduce(total_vol, op=dist.ReduceOp.SUM)
-        dist.all_reduce(total_nmsg, op=dist.ReduceOp.SUM)
+        _all_reduce(total_vol)
+        _all_reduce(total_nmsg)
 
     if myrank == 0:
         print("Elapsed time {:.4f}".format(elapsed.item()), flush=True)

@@ -35,6 +35,8 @@ SIGNATURES = {
     "pgcn_abi_version": (ctypes.c_int, []),
     "pgcn_last_error": (ctypes.c_char_p, []),
     "pgcn_device_info": (ctypes.c_int, [_i32, ctypes.POINTER(_i64)]),
+    "pgcn_mtx_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64)]),
+    "pgcn_mtx_read_coo": (ctypes.c_int, [ctypes.c_char_p, _i64, _vp, _vp, _vp, ctypes.POINTER(_i64), _i32]),
     "pgcn_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _u32, _vp]),
     "pgcn_spmm_csr_plan_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp,
                                               _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),

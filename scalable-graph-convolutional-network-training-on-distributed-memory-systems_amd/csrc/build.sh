@@ -17,8 +17,9 @@ for src in pgcn_spmm.hip pgcn_spmm_core.hip pgcn_rows.hip; do
 done
 "$HIPCC" $FLAGS -c "$HERE/pgcn_core.cpp" -o "$OUT/pgcn_core.o" & pids+=($!)
 "$HIPCC" $FLAGS -c "$HERE/pgcn_exchange.cpp" -o "$OUT/pgcn_exchange.o" & pids+=($!)
+"$HIPCC" $FLAGS -c "$HERE/pgcn_mtx.cpp" -o "$OUT/pgcn_mtx.o" & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpgcn_hip.so" \
-  "$OUT/pgcn_spmm.o" "$OUT/pgcn_spmm_core.o" "$OUT/pgcn_rows.o" "$OUT/pgcn_core.o" "$OUT/pgcn_exchange.o" \
-  -L"$ROCM/lib" -lrccl
+  "$OUT/pgcn_spmm.o" "$OUT/pgcn_spmm_core.o" "$OUT/pgcn_rows.o" "$OUT/pgcn_core.o" "$OUT/pgcn_exchange.o" "$OUT/pgcn_mtx.o" \
+  -L"$ROCM/lib" -lrccl -lpthread
 echo "built $OUT/libpgcn_hip.so"

@@ -100,3 +100,22 @@ def pargcn_worker(rank, P, port, path_A, path_pv, d, seed, q):
            "Hl": Hl.numpy(), "stats": dict(eng.stats)})
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_worker_gpu(rank, P, port, path_A, path_pv, nlayers, f, seed, q):
+    """run() with the REAL HIP kernels: P processes share the one GPU, gloo as transport
+    (RCCL refuses two ranks on one device; everything else is the production path)."""
+    _init(rank, P, port)
+    from conftest import pkg
+    M = pkg("PGCN")
+    M._kernel_provider = None
+    M._exchanger = None
+    torch.manual_seed(seed)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        model = M.run(rank, P, nlayers, f, path_A, path_pv, "gloo")
+    q.put({"rank": rank, "stdout": buf.getvalue(), "provider": type(M._kernel_provider).__name__,
+           "overlap": bool(M._engine_current.overlap),
+           "weights": [m.linear.weight.detach().cpu().numpy() for m in model]})
+    dist.barrier()
+    dist.destroy_process_group()

@@ -411,3 +411,40 @@ def test_rccl_single_rank_comm(dev):
     torch.cuda.synchronize()
     assert torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float32))
     _lib.check(L.pgcn_comm_destroy(comm), "comm_destroy")
+
+
+@pytest.mark.parametrize("mtx,pv,P,L,f", [("karate.A.mtx", "karate.mtx.3.hp", 3, 3, 16),
+                                          ("gemat11p.A.mtx", "gemat11.mtx.2.rp", 2, 3, 32)])
+def test_run_multi_rank_on_one_gpu(dev, mtx, pv, P, L, f):
+    """N > 1 with the real kernels: P processes on the one GPU, gloo transport (host-staged),
+    comm-stream overlap on.  Checked against the oracle's restatement of run()."""
+    import torch.multiprocessing as mp
+    import torch.nn as nn
+    import _workers
+    seed = 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_workers.run_worker_gpu, args=(r, P, 29931 + P, gpath(mtx), gpath(pv), L, f, seed, q))
+             for r in range(P)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=600) for _ in range(P)], key=lambda r: r["rank"])
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    A = sp.csr_matrix(mmread(gpath(mtx))).astype(np.float32)
+    n = A.shape[0]
+    part = read_partvec(gpath(pv))
+    torch.manual_seed(seed)
+    w0 = [nn.Linear(f, f, bias=False).weight.detach().numpy() for _ in range(L)]
+    H0 = np.repeat(np.arange(n, dtype=np.float32)[:, None], f, axis=1)
+    losses, Ws = oracle.pgcn_train_np(A, part, P, w0, H0, np.arange(n) % f, epochs=5)
+    printed = [float(x) for x in re.findall(r"Epoch \d{5} \| Loss ([0-9.]+)", res[0]["stdout"])]
+    np.testing.assert_allclose(printed, losses[1:], rtol=1e-4, atol=1e-4)
+    for r in res:
+        assert r["provider"] == "HipKernels" and r["overlap"]
+        for i, w in enumerate(r["weights"]):
+            assert rel_err(w, Ws[i]) < 5e-4
+    rows = sum(v.size for r in range(P) for v in oracle.communication_maps(A, part, r, P)[0].values())
+    m = re.search(r"total_vol: (\d+) total_nmsg: (\d+)", res[0]["stdout"])
+    assert int(m.group(1)) == rows * 5 * L * 2 and int(m.group(2)) == P * (P - 1) * 5 * L * 2
