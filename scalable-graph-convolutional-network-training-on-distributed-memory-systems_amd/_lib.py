@@ -95,9 +95,10 @@ def load_variant(path: str):
     """Load ANOTHER build of the library (A/B probes: tools/ab_build.sh); typed like lib()."""
     L = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(L, name)
-        fn.restype = res
-        fn.argtypes = args
+        fn = getattr(L, name, None)       # an older variant build may lack newer entry points
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     return L
 
 

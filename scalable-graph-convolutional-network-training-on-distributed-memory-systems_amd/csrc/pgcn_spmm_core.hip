@@ -38,6 +38,9 @@ constexpr int RW = TR / NG;             // rows per group
 #define PGCN_CORE_BATCH 4
 #endif
 constexpr int CB = PGCN_CORE_BATCH;     // LDS row reads in flight per batch
+#ifndef PGCN_CORE_STAGE_BATCH
+#define PGCN_CORE_STAGE_BATCH 4
+#endif
 static_assert(TR % NG == 0, "tile rows must divide over the groups");
 
 template <int VEC>
@@ -111,16 +114,36 @@ __global__ __launch_bounds__(kCoreThreads, 4) void spmm_core_kernel(
             pv[j] = __builtin_nontemporal_load(vb + idx);
         }
         __syncthreads();   // everyone is done reading the previous panel
-        // stage B[col0 .. col0+TC) x [fcol0 .. fcol0+32*VEC) : one contiguous-row copy
+        // stage B[col0 .. col0+TC) x [fcol0 .. fcol0+32*VEC) : one contiguous-row copy.  All
+        // loads are issued before the first LDS write (clamped addresses, no branches: a
+        // per-iteration bounds branch serialises the eight round trips); out-of-range
+        // rows / features are zeroed by a select.
+        {
+            constexpr int NIT = TC * 32 / kCoreThreads;   // 8 row-vectors per thread
+            constexpr int HB = PGCN_CORE_STAGE_BATCH;     // loads in flight per thread
+            const int64_t lastrow = ncols - 1;
+            const int lastf = f - VEC;
 #pragma unroll
-        for (int it = 0; it < TC * 32 / kCoreThreads; ++it) {
-            const int idx = it * kCoreThreads + threadIdx.x;
-            const int r = idx >> 5, s = idx & 31;
-            float x[VEC];
+            for (int h = 0; h < NIT; h += HB) {
+                float xs[HB][VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) x[v] = 0.f;
-            if (col0 + r < ncols && fcol0 + s * VEC < f) vload<VEC>(x, B + (col0 + r) * ldb + fcol0 + s * VEC);
-            vstore<VEC>(panel + (size_t)idx * VEC, x);
+                for (int it = 0; it < HB; ++it) {
+                    const int idx = (h + it) * kCoreThreads + threadIdx.x;
+                    const int r = idx >> 5, s = idx & 31;
+                    const int64_t rr = (col0 + r < ncols) ? col0 + r : lastrow;
+                    const int cc = (fcol0 + s * VEC < f) ? fcol0 + s * VEC : lastf;
+                    vload<VEC>(xs[it], B + rr * ldb + cc);
+                }
+#pragma unroll
+                for (int it = 0; it < HB; ++it) {
+                    const int idx = (h + it) * kCoreThreads + threadIdx.x;
+                    const int r = idx >> 5, s = idx & 31;
+                    const bool ok = (col0 + r < ncols) && (fcol0 + s * VEC < f);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) xs[it][v] = ok ? xs[it][v] : 0.f;
+                    vstore<VEC>(panel + (size_t)idx * VEC, xs[it]);
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
