@@ -4,15 +4,15 @@ Host-side (plumbing) restatement of what ``GPU/PGCN.py`` does in
 ``compute_communication_maps`` (:37-51) and ``get_partitiont_of_adjacency_matrix``
 (:53-64), but producing the MI355X data layout instead of an n x n COO:
 
-* rank p keeps only its owned rows; rows are numbered 0..n_p-1 in ascending
-  global id (the reference keeps the global n x n index space, which is what
-  stops it from scaling -- SURVEY 5 "long-context" row);
+* rank p keeps only its owned rows, numbered 0..n_p-1 by decreasing global degree
+  (the reference keeps the global n x n index space, which is what stops it
+  from scaling -- SURVEY 5 "long-context" row);
 * the columns are split the way ``Parallel-GCN/main.c`` splits the product:
   ``A_loc`` (columns owned by p, re-indexed to local ids; main.c:271) and
   ``A_halo`` (columns owned by others, re-indexed to the position of that row in
   the receive slab; main.c:295).  The receive slab is ordered by (owner rank,
-  global id): exactly the concatenation of the reference's ``recv_map[q]``
-  lists, so the sender's ``send_map[q]`` order matches with no index exchange;
+  global degree rank): per owner the same SET as the reference's ``recv_map[q]``,
+  in an order both sides derive from the matrix alone, so no index exchange;
 * the transposed pieces (CSR of ``A_loc^T`` and ``A_halo^T``) serve
   ``PSpMM.backward`` (PGCN.py:132 ``A.t()``) without atomics.
 
@@ -305,12 +305,13 @@ class Partition:
         return self.A_loc.nnz + self.A_halo.nnz
 
     def send_map(self) -> Dict[int, torch.Tensor]:
-        """peer -> sorted global ids I send (== reference send_map, PGCN.py:47-50)."""
-        return {q: self.send_global[self.send_off[q]:self.send_off[q + 1]]
+        """peer -> sorted global ids I send (== reference send_map, PGCN.py:47-50).  The slab
+        itself is in degree-rank order (`send_global`); this is the API view."""
+        return {q: torch.sort(self.send_global[self.send_off[q]:self.send_off[q + 1]]).values
                 for q in range(self.size) if q != self.rank}
 
     def recv_map(self) -> Dict[int, torch.Tensor]:
-        return {q: self.halo_global[self.recv_off[q]:self.recv_off[q + 1]]
+        return {q: torch.sort(self.halo_global[self.recv_off[q]:self.recv_off[q + 1]]).values
                 for q in range(self.size) if q != self.rank}
 
 
@@ -341,13 +342,20 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     own_mask = part == rank
     owned = torch.nonzero(own_mask).reshape(-1)
     n_p = int(owned.numel())
-    if DEGREE_SORT and n_p > 1:
-        # local numbering by decreasing degree inside the local block (ties: ascending global
-        # id): the dense core of a power-law graph becomes the top-left corner of A_loc, which
-        # is what the LDS-tiled kernel feeds on.  Purely internal: `owned` records the order.
-        both = own_mask[row] & own_mask[col]
-        deg = torch.bincount(row[both], minlength=n) + torch.bincount(col[both], minlength=n)
-        owned = owned[torch.argsort(-deg[owned], stable=True)]
+    # One global degree ranking, identical on every rank (every rank scans the whole COO, as in
+    # the reference): grank[v] = position of vertex v in the order (degree descending, id
+    # ascending).  It numbers the local rows AND orders the boundary-row slabs, so that the
+    # dense core of a power-law graph is the top-left corner of A_loc and the head of every
+    # owner segment of A_halo -- what the LDS-tiled kernel feeds on.  Purely internal: `owned`,
+    # `send_global` and `halo_global` record the orders; sender and receiver agree by construction.
+    if DEGREE_SORT and n > 1:
+        gdeg = torch.bincount(row, minlength=n) + torch.bincount(col, minlength=n)
+        gorder = torch.argsort(-gdeg, stable=True)
+    else:
+        gorder = torch.arange(n, dtype=torch.int64, device=dev)
+    grank = torch.empty(n, dtype=torch.int64, device=dev)
+    grank[gorder] = torch.arange(n, dtype=torch.int64, device=dev)
+    owned = owned[torch.argsort(grank[owned])]
     g2l = torch.full((n,), -1, dtype=torch.int64, device=dev)
     g2l[owned] = torch.arange(n_p, dtype=torch.int64, device=dev)
 
@@ -361,25 +369,27 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     loc = cp == rank
 
     A_loc = csr_from_coo(r[loc], g2l[c[loc]], v[loc], n_p, n_p, core=CORE_ON)
-    # halo columns, ordered by (owner, global id)  == concatenated recv_map lists
-    hkey = cp[~loc] * n + c[~loc]
+    # halo columns, ordered by (owner, degree rank): the receive slab.  As a SET per owner this
+    # is the reference's recv_map[q] (PGCN.py:44-48)
+    hkey = cp[~loc] * n + grank[c[~loc]]
     huniq, hinv = torch.unique(hkey, return_inverse=True)
-    halo_global = huniq % n
+    halo_global = gorder[huniq % n]
     halo_owner = huniq // n
     n_halo = int(huniq.numel())
     recv_off = _offsets(halo_owner.cpu(), size)
-    A_halo = csr_from_coo(r[~loc], hinv, v[~loc], n_p, n_halo, compact_rows=True)
+    halo_core = CORE_ON and size > 1
+    A_halo = csr_from_coo(r[~loc], hinv, v[~loc], n_p, n_halo, compact_rows=not halo_core, core=halo_core)
 
     A_loc_T = A_halo_T = None
     if with_transpose:
         A_loc_T = csr_from_coo(g2l[c[loc]], r[loc], v[loc], n_p, n_p, core=CORE_ON)
-        A_halo_T = csr_from_coo(hinv, r[~loc], v[~loc], n_halo, n_p)
+        A_halo_T = csr_from_coo(hinv, r[~loc], v[~loc], n_halo, n_p, core=halo_core)
 
-    # rows of mine that other ranks need: (target rank, global id) sorted
+    # rows of mine that other ranks need: (target rank, degree rank) sorted = the peer's slab order
     theirs = (pcol == rank) & (prow != rank)
-    skey = prow[theirs] * n + col[theirs]
+    skey = prow[theirs] * n + grank[col[theirs]]
     suniq = torch.unique(skey)
-    send_global = suniq % n
+    send_global = gorder[suniq % n]
     send_owner = suniq // n
     send_off = _offsets(send_owner.cpu(), size)
     send_idx = g2l[send_global].to(torch.int32)

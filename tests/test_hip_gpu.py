@@ -241,17 +241,11 @@ class _PrecomputedExchanger:
         pass
 
 
-@pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES)
-def test_engine_forward_backward_vs_reference_golden(K, dev, name, mtx, pv, P):
-    """Every rank's engine on the one GPU, checked against the reference's PSpMM outputs."""
+def _virtual_ranks_fwd_bwd(K, dev, A, part, P, Hfull, Gfull):
+    """Every rank's engine on the one GPU (the exchange is emulated from the global matrices the
+    test holds).  Returns (forward A.H, backward A^T.G, engines) in GLOBAL row numbering."""
     partition, engine = pkg("partition"), pkg("engine")
-    arrays, meta = golden(name)
-    A = sp.coo_matrix(mmread(gpath(mtx)))
-    n, f = A.shape[0], meta["f"]
-    part = torch.tensor(read_partvec(gpath(pv)))
-    Hfull, Gfull = golden_inputs(n, f, meta["seed"])
-    At = sp.csr_matrix(A.T).astype(np.float32)
-    bwd_exact = oracle.spmm(At, Gfull)
+    n, f = Hfull.shape
     row, col, val = (torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
                      torch.from_numpy(A.data.astype(np.float32)))
     fwd = np.zeros((n, f), np.float32)
@@ -266,10 +260,9 @@ def test_engine_forward_backward_vs_reference_golden(K, dev, name, mtx, pv, P):
         out = eng.forward(torch.from_numpy(Hfull[own]).to(dev))
         torch.cuda.synchronize()
         fwd[own] = out.cpu().numpy()
-        if P > 1:   # what was packed for the peers is exactly H[send_map rows]
+        if P > 1:   # what was packed for the peers is exactly H[send rows], in the peer's slab order
             np.testing.assert_array_equal(ex.sent.cpu().numpy(), Hfull[p.send_global.numpy()])
         engines.append((eng, ex, p))
-    assert rel_err(fwd, arrays["fwd"]) < TOL
     # backward: first pass collects every rank's halo partials, second pass delivers them
     partials = {}
     for eng, ex, p in engines:
@@ -289,15 +282,47 @@ def test_engine_forward_backward_vs_reference_golden(K, dev, name, mtx, pv, P):
                 hg, slab, roff = partials[q]
                 seg = slice(roff[p.rank], roff[p.rank + 1])       # what q computed for my rows
                 a, b = p.send_off[q], p.send_off[q + 1]
-                np.testing.assert_array_equal(hg[seg], p.send_global.numpy()[a:b])
+                np.testing.assert_array_equal(hg[seg], p.send_global.numpy()[a:b])   # same slab order
                 back[a:b] = slab[seg]
             ex.next_recv = torch.from_numpy(back).to(dev)
         out = eng.backward(torch.from_numpy(Gfull[p.owned.numpy()]).to(dev))
         torch.cuda.synchronize()
         bwd[p.owned.numpy()] = out.cpu().numpy()
-    assert rel_err(bwd, bwd_exact) < TOL
+    return fwd, bwd, engines
+
+
+@pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES)
+def test_engine_forward_backward_vs_reference_golden(K, dev, name, mtx, pv, P):
+    """Every rank's engine on the one GPU, checked against the reference's PSpMM outputs."""
+    arrays, meta = golden(name)
+    A = sp.coo_matrix(mmread(gpath(mtx)))
+    n, f = A.shape[0], meta["f"]
+    part = torch.tensor(read_partvec(gpath(pv)))
+    Hfull, Gfull = golden_inputs(n, f, meta["seed"])
+    fwd, bwd, _ = _virtual_ranks_fwd_bwd(K, dev, A, part, P, Hfull, Gfull)
+    assert rel_err(fwd, arrays["fwd"]) < TOL
+    assert rel_err(bwd, oracle.spmm(sp.csr_matrix(A.T).astype(np.float32), Gfull)) < TOL
     if "bwd" in arrays:
         assert rel_err(bwd, arrays["bwd"]) < TOL
+
+
+@pytest.mark.parametrize("P,f", [(2, 128), (3, 64)])
+def test_engine_halo_dense_core(K, dev, P, f):
+    """Multi-rank partition of a power-law graph: the degree-ordered receive slab gives A_halo and
+    A_halo^T dense tiles too, so the LDS-tiled kernel runs on the halo pass as well."""
+    synth = pkg("synth")
+    n, row, col, val = synth.make_graph(6000, 900000, seed=3)
+    A = sp.coo_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n, n))
+    part = synth.random_partvec(n, P, seed=1)
+    rng = np.random.default_rng(5)
+    Hfull = rng.random((n, f), dtype=np.float32) * 2 - 1
+    Gfull = rng.random((n, f), dtype=np.float32) * 2 - 1
+    fwd, bwd, engines = _virtual_ranks_fwd_bwd(K, dev, A, part, P, Hfull, Gfull)
+    assert any(e.A_halo.core is not None for e, _, _ in engines)
+    assert any(e.A_halo_T.core is not None for e, _, _ in engines)
+    Ac = sp.csr_matrix(A)
+    assert rel_err(fwd, oracle.spmm(Ac, Hfull)) < TOL
+    assert rel_err(bwd, oracle.spmm(sp.csr_matrix(A.T), Gfull)) < TOL
 
 
 @pytest.mark.parametrize("name,mtx,pv", TRAIN_CASES)

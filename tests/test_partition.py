@@ -67,10 +67,12 @@ def test_pieces_reassemble_the_row_block(name, mtx, pv, P):
             key = (c % csr.nslices) * (csr.ncols + 1) + c
             for i in range(csr.nrows):
                 assert (np.diff(key[rp[i]:rp[i + 1]]) >= 0).all()
-        # local numbering = decreasing degree inside the local block
-        lr, lc, _ = p.A_loc.to_coo()                       # stored entries (explicit zeros count)
-        d = np.bincount(lr.numpy(), minlength=p.n_local) + np.bincount(lc.numpy(), minlength=p.n_local)
-        assert (np.diff(d) <= 0).all()
+        # local numbering and slab orders = decreasing GLOBAL degree (stored entries, row + column)
+        gd = np.bincount(A.row, minlength=A.shape[0]) + np.bincount(A.col, minlength=A.shape[0])
+        assert (np.diff(gd[own]) <= 0).all()
+        for q in range(P):
+            assert (np.diff(gd[p.halo_global.numpy()[p.recv_off[q]:p.recv_off[q + 1]]]) <= 0).all()
+            assert (np.diff(gd[p.send_global.numpy()[p.send_off[q]:p.send_off[q + 1]]]) <= 0).all()
 
 
 def test_edge_cases():
