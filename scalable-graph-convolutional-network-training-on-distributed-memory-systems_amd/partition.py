@@ -81,7 +81,8 @@ CORE_NG = 16       # 32-lane groups per workgroup
 CORE_RW = CORE_TR // CORE_NG
 CORE_ON = os.environ.get("PGCN_CORE", "1") != "0"
 CORE_TAU = float(os.environ.get("PGCN_CORE_TAU", "0.05"))        # minimum tile fill
-CORE_EMAX = int(os.environ.get("PGCN_CORE_EMAX", "32768"))       # entries per work piece
+CORE_EMAX = int(os.environ.get("PGCN_CORE_EMAX", "0"))           # entries per work piece; 0 = adaptive:
+                                                                  # ~1024 pieces, between 4096 and 32768 entries
 CORE_PG = int(os.environ.get("PGCN_CORE_PANEL_GROUP", "0"))      # >0: cut pieces at multiples of PG panels
                                                                   # and run them panel-group-major (L2 locality)
 DEGREE_SORT = os.environ.get("PGCN_DEGREE_SORT", "1") != "0"
@@ -144,6 +145,8 @@ def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, nc
     if ntiles == 0:
         return None, None
     is_core = dense[inv]
+    if not emax:   # enough pieces to fill 2 workgroups x 256 CUs twice over, but no confetti
+        emax = int(min(32768, max(4096, int(cnt[dense].sum()) // 1024)))
     kmap = torch.cumsum(dense.to(torch.int64), 0) - 1
     k_e = kmap[inv[is_core]]
     rc, cc, vc = r64[is_core], c64[is_core], v[is_core]

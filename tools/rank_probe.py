@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-rank compute of an N-GPU run, measured on ONE GPU: build rank r's partition of the benchmark
+graph for world size P and time its forward / backward aggregation with a no-op exchanger (the halo
+slab holds random rows).  Shows what the compute side of bench.py --gpus P costs per rank."""
+import argparse, importlib, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+PKG = "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd"
+pkg = lambda s: importlib.import_module(PKG + "." + s)
+
+class NoExchange:
+    name = "none"
+    def alltoallv(self, *a): pass
+    def allreduce_sum(self, b): pass
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--world", type=int, default=8); ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--f", type=int, default=128); ap.add_argument("--rounds", type=int, default=10)
+    a = ap.parse_args()
+    synth, partition, engine, kernels = pkg("synth"), pkg("partition"), pkg("engine"), pkg("kernels")
+    dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+    n, row, col, val = synth.make_graph("reddit", seed=0, device=dev)
+    pv = synth.random_partvec(n, a.world, seed=0)
+    t0 = time.time(); p = partition.build_partition(row, col, val, n, pv, a.rank, a.world); torch.cuda.synchronize(); tb = time.time() - t0
+    K = kernels.HipKernels(dev)
+    t0 = time.time(); eng = engine.AggregationEngine(p, K, dev, NoExchange() if a.world > 1 else None); torch.cuda.synchronize(); tp = time.time() - t0
+    def frac(d): return 100.0 * d.core.nnz / max(d.nnz, 1) if d is not None and d.core is not None else 0.0
+    print("P=%d rank=%d n_local=%d n_halo=%d n_send=%d nnz_loc=%d nnz_halo=%d | build %.2fs prepare %.2fs | core%%: loc %.0f halo %.0f locT %.0f haloT %.0f"
+          % (a.world, a.rank, p.n_local, p.n_halo, p.n_send, p.A_loc.nnz, p.A_halo.nnz if a.world > 1 else 0, tb, tp,
+             frac(eng.A_loc), frac(eng.A_halo), frac(eng.A_loc_T), frac(eng.A_halo_T)))
+    H = torch.rand(p.n_local, a.f, device=dev)
+    if a.world > 1:
+        eng._slab("halo", eng.n_halo, a.f).uniform_(); eng._slab("send", eng.n_send, a.f).uniform_()
+    for name, fn in (("forward", eng.forward), ("backward", eng.backward)):
+        fn(H); fn(H); torch.cuda.synchronize(); ts = []
+        for _ in range(a.rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(H); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+        nnz = p.A_loc.nnz + (p.A_halo.nnz if a.world > 1 else 0)
+        print("  %-8s median %.3f ms  (%.1f G edges/s on this rank; x%d ranks = %.1f G edges/s)" % (name, np.median(ts), nnz / np.median(ts) / 1e6, a.world, a.world * nnz / np.median(ts) / 1e6))
+
+if __name__ == "__main__":
+    main()
