@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Launcher with the command line of the reference's CPU engine (Parallel-GCN/main.c):
+
+    python pargcn.py -p DATA_DIR -c CONFIG [-t nthreads]         (the reference: mpirun -n P grbgcn ...)
+
+DATA_DIR holds A.k H.k Y.k conn.k buff.k config as written by the reference's GCN-HP tool."""
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+_impl = importlib.import_module(
+    "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd.pargcn")
+
+if __name__ == "__main__":
+    _impl.main(sys.argv[1:])

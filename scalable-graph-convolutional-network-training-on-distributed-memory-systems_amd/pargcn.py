@@ -9,8 +9,13 @@ north-star parity clause names ("outputs match the reference Parallel-GCN CPU pa
 """
 from __future__ import annotations
 
+import getopt
+import os
+import sys
+import time
 from typing import Dict, Sequence
 
+import numpy as np
 import torch
 
 
@@ -55,3 +60,103 @@ def train(engine, d: Sequence[int], W: Dict[int, torch.Tensor], H0: torch.Tensor
             if l != 1:
                 G = Gn
     return errs, W, H[L - 1]
+
+
+def init_weights(d: Sequence[int], seed: int = 0) -> Dict[int, np.ndarray]:
+    """main.c:578-595: W[l] ~ U(-sd, sd), sd = sqrt(6 / (ni + no)).  The reference seeds rand()
+    with time(NULL) on every rank (unreproducible, replicas may differ); here: a seeded stream."""
+    rng = np.random.default_rng(seed)
+    L = len(d) - 1
+    return {l: ((rng.random((d[l], d[l + 1]), dtype=np.float32) * 2 - 1) *
+                np.float32(np.sqrt(6.0 / (d[l] + d[l + 1])))) for l in range(1, L)}
+
+
+def main(argv, kernels=None, out=None):
+    """Drop-in for the CPU engine's command line  ``grbgcn -p DATA_DIR -c CONFIG -t nthreads``
+    (Parallel-GCN/main.c:99-164, README.md:57-81) on the HIP engine.  Prints what rank 0 of the
+    reference prints: the config echo (main.c:699-704), ``err:%g`` per epoch (:323),
+    ``time : %f secs`` (:445) and the 8 communication statistics (:519-522).  Rank / world size
+    from the launcher's RANK / WORLD_SIZE (mpirun in the reference); WORLD_SIZE must be 1 or the
+    number of parts in DATA_DIR.  Returns (errs, W, output rows, partition)."""
+    import torch.distributed as dist
+
+    from . import engine as _engine
+    from . import kernels as _kernels
+    from . import pargcn_io as _io
+    from . import partition as _partition
+    out = out or sys.stdout
+    path, config_path = None, None
+    opts, _ = getopt.getopt(argv, "p:t:c:")
+    for o, a in opts:
+        if o == "-p":
+            path = a
+        elif o == "-c":
+            config_path = a
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    prob = _io.load_directory(path, config_path)
+    L, d, n = prob["L"], prob["d"], prob["d"][0]
+    if world not in (1, prob["k"]):
+        raise ValueError("%s holds %d parts; run with 1 or %d ranks" % (path, prob["k"], prob["k"]))
+    if rank == 0:
+        print("nlayers:%d" % L, file=out)
+        print(" ".join(str(x) for x in d) + " ", file=out)
+    if kernels is None:
+        if not torch.cuda.is_available():
+            raise _kernels._lib.PgcnError("no HIP device visible: refusing to run (no CPU fallback)")
+        dev = torch.device("cuda:%d" % (int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()))
+        torch.cuda.set_device(dev)
+        kernels = _kernels.HipKernels(dev)
+    else:
+        dev = torch.device("cpu")
+    A = prob["A"]
+    partvec = torch.from_numpy(prob["part"] if world > 1 else np.zeros(n, dtype=np.int64))
+    part = _partition.build_partition(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
+                                      torch.from_numpy(A.data.astype(np.float32)), n, partvec, rank, world)
+    exch = _engine.make_exchanger(rank, world, dev) if world > 1 else None
+    eng = _engine.AggregationEngine(part, kernels, dev, exch)
+    own = part.owned.numpy()
+    W = {l: torch.from_numpy(w).to(dev) for l, w in init_weights(d, int(os.environ.get("PGCN_SEED", "0"))).items()}
+    H0 = torch.ones((own.size, d[1]), device=dev)                                  # main.c:650-685
+    Y = torch.from_numpy(prob["Y"][own]).to(dev)
+    Ym = torch.from_numpy(prob["Ymask"][own]).to(dev)
+    allreduce = None
+    if world > 1:
+        def allreduce(t):
+            if t.is_cuda and dist.get_backend() == "gloo":
+                h = t.cpu(); dist.all_reduce(h); t.copy_(h)
+            else:
+                dist.all_reduce(t)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    tic = time.time()
+    errs, Wn, Hout = train(eng, d, W, H0, Y, Ym, epochs=3, alpha=0.01, allreduce=allreduce)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    elapsed = torch.tensor([time.time() - tic], dtype=torch.float64)
+    # statistics(), main.c:506-524: volumes in SCALARS (rows x width, :264), per rank
+    widths = [d[l] for l in range(1, L)] + [d[l + 1] for l in range(L - 1, 0, -1)]     # per epoch
+    rows_out = sum(part.send_off[q + 1] - part.send_off[q] for q in range(world))
+    rows_in = sum(part.recv_off[q + 1] - part.recv_off[q] for q in range(world))
+    nz_t = sum(1 for q in range(world) if part.send_off[q + 1] > part.send_off[q])
+    nz_s = sum(1 for q in range(world) if part.recv_off[q + 1] > part.recv_off[q])
+    st = torch.tensor([rows_out * sum(widths) * 3, rows_in * sum(widths) * 3, nz_t * len(widths) * 3,
+                       nz_s * len(widths) * 3], dtype=torch.float64)
+    if world > 1:
+        tot, mx = st.clone(), st.clone()
+        dist.all_reduce(tot)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    else:
+        tot, mx = st, st
+    if rank == 0:
+        for e in errs:
+            print("err:%g" % e, file=out)
+        print("time : %f secs" % float(elapsed), file=out)
+        print("%d %d %d %d %d %d %d %d" % (tot[0], tot[0] // world, mx[0], mx[1], tot[2], tot[2] // world,
+                                           mx[2], mx[3]), file=out)
+    return errs, Wn, Hout, part
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

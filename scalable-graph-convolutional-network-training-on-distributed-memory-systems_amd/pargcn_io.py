@@ -1,0 +1,113 @@
+"""On-disk inputs of the reference's CPU engine.
+
+Readers for the per-rank files GCN-HP writes and Parallel-GCN/main.c consumes, so the SAME
+directories feed the oracle and the HIP engine:
+
+  config   "L n d1 .. d(L-1) 2"                          main.c:687-714  (GCN-HP/main.cpp:117-131)
+  A.k Y.k  "nvtx nnz" then "i j value" (0-based, global)   main.c:609-648  (GCN-HP/main.cpp:213-249, %.2f)
+  H.k      "nrows" then one owned global row id per line  main.c:650-685  (GCN-HP/main.cpp:251-282)
+  conn.k   "ntargets nsources" then "target count ids.."  main.c:526-551  (GCN-HP/main.cpp:178-191)
+  buff.k   "ntargets (target rows)*" / "nsources (source rows)*"   main.c:456-504
+
+Host-side text parsing: plumbing, no GPU."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def read_config(path: str) -> Tuple[int, List[int]]:
+    """main.c:687-714: nlayers then nlayers+1 widths (d[0] = number of vertices)."""
+    tok = open(path).read().split()
+    L = int(tok[0])
+    d = [int(t) for t in tok[1:L + 2]]
+    if len(d) != L + 1:
+        raise ValueError("config %s: expected %d widths, found %d" % (path, L + 1, len(d)))
+    return L, d
+
+
+def read_matrix(path: str) -> Tuple[int, np.ndarray, np.ndarray, np.ndarray]:
+    """main.c:609-648: header "nvtx nedges", then nedges triples "i j x"."""
+    with open(path) as f:
+        nvtx, nedges = (int(t) for t in f.readline().split())
+        a = np.loadtxt(f, dtype=np.float64, ndmin=2) if nedges else np.zeros((0, 3))
+    if a.shape[0] != nedges:
+        raise ValueError("%s: header says %d entries, file holds %d" % (path, nedges, a.shape[0]))
+    return nvtx, a[:, 0].astype(np.int64), a[:, 1].astype(np.int64), a[:, 2].astype(np.float32)
+
+
+def read_rows(path: str) -> np.ndarray:
+    """main.c:650-685 (H.k): count, then the owned global row ids (features are all ones)."""
+    tok = open(path).read().split()
+    n = int(tok[0])
+    ids = np.asarray(tok[1:1 + n], dtype=np.int64)
+    if ids.size != n:
+        raise ValueError("%s: header says %d rows, file holds %d" % (path, n, ids.size))
+    return ids
+
+
+def read_connectivity(path: str) -> Tuple[Dict[int, np.ndarray], int]:
+    """main.c:526-551: {target rank: global ids of my rows it needs}, number of sources."""
+    tok = open(path).read().split()
+    ntargets, nrecvs = int(tok[0]), int(tok[1])
+    out, p = {}, 2
+    for _ in range(ntargets):
+        target, cnt = int(tok[p]), int(tok[p + 1])
+        out[target] = np.asarray(tok[p + 2:p + 2 + cnt], dtype=np.int64)
+        p += 2 + cnt
+    return out, nrecvs
+
+
+def read_buffer_sizes(path: str) -> Tuple[Dict[int, int], Dict[int, int]]:
+    """main.c:456-504: rows to send per target, rows to receive per source."""
+    lines = open(path).read().split("\n")
+    def parse(line):
+        tok = line.split()
+        k = int(tok[0]) if tok else 0
+        return {int(tok[1 + 2 * i]): int(tok[2 + 2 * i]) for i in range(k)}
+    return parse(lines[0]), parse(lines[1] if len(lines) > 1 else "")
+
+
+def count_parts(directory: str) -> int:
+    k = 0
+    while os.path.exists(os.path.join(directory, "A.%d" % k)):
+        k += 1
+    return k
+
+
+def load_directory(directory: str, config_path: str = None):
+    """Assemble the global problem from all per-rank files: (L, d, A coo, partvec, Y dense,
+    Ymask, conn[k] dicts, buff[k] pairs)."""
+    L, d = read_config(config_path or os.path.join(directory, "config"))
+    n = d[0]
+    k = count_parts(directory)
+    if k == 0:
+        raise FileNotFoundError("no A.0 in %s" % directory)
+    rows, cols, vals = [], [], []
+    part = np.full(n, -1, dtype=np.int64)
+    Y = np.zeros((n, d[L]), dtype=np.float32)
+    Ymask = np.zeros((n, d[L]), dtype=np.uint8)
+    conn, buff = [], []
+    for p in range(k):
+        nv, r, c, v = read_matrix(os.path.join(directory, "A.%d" % p))
+        if nv != n:
+            raise ValueError("A.%d: %d vertices, config says %d" % (p, nv, n))
+        rows.append(r); cols.append(c); vals.append(v)
+        own = read_rows(os.path.join(directory, "H.%d" % p))
+        if (part[own] != -1).any():
+            raise ValueError("row owned twice (H.%d)" % p)
+        part[own] = p
+        _, yr, yc, yv = read_matrix(os.path.join(directory, "Y.%d" % p))
+        Y[yr, yc] = yv
+        Ymask[yr, yc] = 1
+        conn.append(read_connectivity(os.path.join(directory, "conn.%d" % p)))
+        buff.append(read_buffer_sizes(os.path.join(directory, "buff.%d" % p)))
+    if (part < 0).any():
+        raise ValueError("%d vertices are owned by no part" % int((part < 0).sum()))
+    A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    if not (part[A.row] == np.repeat(np.arange(k), [len(r) for r in rows])).all():
+        raise ValueError("an A.k file holds rows of another part")
+    return {"L": L, "d": d, "A": A, "part": part, "Y": Y, "Ymask": Ymask, "conn": conn, "buff": buff, "k": k}
