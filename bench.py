@@ -234,7 +234,8 @@ def main():
             roofline["avg_launch_ms_backward_AT"] = bavg
 
     out = {
-        "metric": "edges aggregated/sec (Reddit-shaped 3-layer GCN f=128, full training epoch)",
+        "metric": "edges aggregated/sec (%s-shaped %d-layer GCN f=%d, full training epoch)" % (
+            args.workload.capitalize(), L, f),
         "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

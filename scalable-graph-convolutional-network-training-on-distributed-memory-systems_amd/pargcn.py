@@ -94,6 +94,12 @@ def main(argv, kernels=None, out=None):
             config_path = a
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    own_group = False
+    if world > 1 and not dist.is_initialized():      # the reference is started by mpirun; here: torchrun
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(os.environ.get("PGCN_BACKEND", "nccl"), rank=rank, world_size=world)
+        own_group = True
     prob = _io.load_directory(path, config_path)
     L, d, n = prob["L"], prob["d"], prob["d"][0]
     if world not in (1, prob["k"]):
@@ -155,6 +161,10 @@ def main(argv, kernels=None, out=None):
         print("time : %f secs" % float(elapsed), file=out)
         print("%d %d %d %d %d %d %d %d" % (tot[0], tot[0] // world, mx[0], mx[1], tot[2], tot[2] // world,
                                            mx[2], mx[3]), file=out)
+    if own_group:
+        if exch is not None:
+            exch.close()
+        dist.destroy_process_group()
     return errs, Wn, Hout, part
 
 

@@ -7,6 +7,7 @@ the only difference is FMA contraction + the fixed segment-combine order of spli
 import contextlib
 import ctypes
 import io
+import os
 import re
 
 import numpy as np
@@ -473,3 +474,26 @@ def test_run_multi_rank_on_one_gpu(dev, mtx, pv, P, L, f):
     rows = sum(v.size for r in range(P) for v in oracle.communication_maps(A, part, r, P)[0].values())
     m = re.search(r"total_vol: (\d+) total_nmsg: (\d+)", res[0]["stdout"])
     assert int(m.group(1)) == rows * 5 * L * 2 and int(m.group(2)) == P * (P - 1) * 5 * L * 2
+
+
+def test_pargcn_cli_on_reference_inputs(dev, tmp_path):
+    """`pargcn.py -p DIR -c CONFIG` on a directory written by the reference's GCN-HP tool, real kernels."""
+    import tarfile
+    from conftest import GOLDEN
+    pargcn, io_ = pkg("pargcn"), pkg("pargcn_io")
+    with tarfile.open(os.path.join(GOLDEN, "pargcn", "gemat11p_k3.tar.gz")) as tf:
+        tf.extractall(tmp_path)
+    d_ = str(tmp_path / "out_gemat11p_k3")
+    os.environ["PGCN_SEED"] = "5"
+    buf = io.StringIO()
+    errs, Wn, Hout, part = pargcn.main(["-p", d_, "-c", os.path.join(d_, "config")], out=buf)
+    prob = io_.load_directory(d_)
+    d = prob["d"]
+    n = d[0]
+    err, Wc, Hl, _ = oracle.pargcn_train(sp.csr_matrix(prob["A"]), [0] * n, 1, d, pargcn.init_weights(d, 5),
+                                         np.ones((n, d[1]), np.float32), prob["Y"], prob["Ymask"])
+    np.testing.assert_allclose(errs, err, rtol=1e-5)
+    for l in Wc:
+        assert rel_err(Wn[l].cpu().numpy(), Wc[l]) < TOL
+    assert rel_err(Hout.cpu().numpy(), Hl[part.owned.numpy()]) < TOL
+    assert buf.getvalue().startswith("nlayers:3") and "time :" in buf.getvalue()
