@@ -133,9 +133,9 @@ def _sync_stats(eng):
 
 def communicate_fgm(H, backward=False):
     """PGCN.py:85-119.  Forward: packs my boundary rows of H (owned rows, n_p x f), runs
-    the all-to-all-v and returns the received halo rows (n_halo x f, ordered by owner
-    then global id).  Backward: H is the halo-shaped slab of partial sums; returns the
-    partials received for my boundary rows (n_send x f, in send_map order)."""
+    the all-to-all-v and returns the received halo rows (n_halo x f, in halo-slab order:
+    ``part.halo_global`` / ``part.halo_owner``).  Backward: H is the halo-shaped slab of partial
+    sums; returns the partials received for my boundary rows (n_send x f, send-slab order)."""
     eng = _engine_current
     f = H.shape[1]
     if eng.size == 1:
@@ -144,11 +144,13 @@ def communicate_fgm(H, backward=False):
         send = eng._slab("send", eng.n_send, f)
         halo = eng._slab("halo", eng.n_halo, f)
         eng.k.gather_rows(H.contiguous(), eng.send_idx, send)
-        eng._exchange(send, eng.send_off, halo, eng.recv_off, f)()
+        for w in eng._exchange_all(send, eng.round_send_off, halo, eng.round_recv_off, f):
+            w()
         out = halo[:eng.n_halo]
     else:
         back = eng._slab("send", eng.n_send, f)
-        eng._exchange(H.contiguous(), eng.recv_off, back, eng.send_off, f)()
+        for w in eng._exchange_all(H.contiguous(), eng.round_recv_off, back, eng.round_send_off, f):
+            w()
         out = back[:eng.n_send]
     _sync_stats(eng)
     return out

@@ -5,11 +5,16 @@ This is the MI355X-native re-design of ``communicate_fgm`` + ``torch.sparse.mm``
 (Parallel-GCN/main.c:238-299):
 
     forward   pack boundary rows        (gather kernel, compute stream)
-              all-to-all-v              (RCCL, comm stream)      ||  C  = A_loc  . H      (compute stream)
-              wait                                                   C += A_halo . halo
-    backward  P = A_halo^T . G          (partials for rows owned by peers)
-              reverse all-to-all-v      (comm stream)            ||  dH = A_loc^T . G
+              all-to-all-v round 0      (RCCL, comm stream)      ||  C  = A_loc    . H    (compute stream)
+              all-to-all-v round 1                               ||  C += A_halo[0] . halo   (after round 0 landed)
+                                                                     C += A_halo[1] . halo   (after round 1 landed)
+    backward  P[r] = A_halo[r]^T . G    (partials for rows owned by peers, round by round)
+              reverse all-to-all-v r    (comm stream, as soon as P[r] exists)  ||  P[r+1], dH = A_loc^T . G
               wait                                                   dH[send rows] += received partials
+
+Every peer's boundary list is cut into `rounds` parts (partition.Partition): each round is one
+all-to-all-v over ALL peers (all xGMI links busy) on a contiguous sub-slab, and the halo pass of
+round r overlaps the transfer of round r+1.
 
 The received slab IS the halo panel: ``A_halo``'s column ids index it directly,
 so the reference's n x f scratch ``X``, the ``H + X`` add and the n x n index
@@ -162,11 +167,13 @@ class AggregationEngine:
         if self.size > 1 and exchanger is None:
             raise ValueError("a multi-rank partition needs an exchanger")
         self.A_loc = kernels.prepare(part.A_loc)
-        self.A_halo = kernels.prepare(part.A_halo) if self.size > 1 else None
+        self.A_halo = [kernels.prepare(a) for a in part.A_halo]
         self.A_loc_T = kernels.prepare(part.A_loc_T) if part.A_loc_T is not None else None
-        self.A_halo_T = kernels.prepare(part.A_halo_T) if (self.size > 1 and part.A_halo_T is not None) else None
+        self.A_halo_T = [kernels.prepare(a) for a in part.A_halo_T]
         self.send_idx = part.send_idx.to(self.device)
-        self.send_off, self.recv_off = list(part.send_off), list(part.recv_off)
+        self.rounds = part.rounds
+        self.round_send_off = [list(o) for o in part.round_send_off]
+        self.round_recv_off = [list(o) for o in part.round_recv_off]
         self.n_local, self.n_halo, self.n_send = part.n_local, part.n_halo, part.n_send
         self._buf: Dict = {}
         self.on_gpu = self.device.type == "cuda"
@@ -186,24 +193,41 @@ class AggregationEngine:
             self._buf[key] = t
         return t
 
-    def _exchange(self, send, send_off, recv, recv_off, f):
-        """Start the all-to-all-v (on the comm stream when overlapping); returns a waiter."""
-        self.stats["send_volume"] += send_off[-1]
-        self.stats["recv_volume"] += recv_off[-1]
+    def _count(self, rows_out: int, rows_in: int) -> None:
+        self.stats["send_volume"] += rows_out
+        self.stats["recv_volume"] += rows_in
         self.stats["send_nmsg"] += self.size - 1   # PGCN.py:106 counts every peer, empty or not
         self.stats["recv_nmsg"] += self.size - 1
+
+    def _exchange_round(self, src, src_off, dst, dst_off, f):
+        """One all-to-all-v on the sub-slabs [off[0], off[size]) of src / dst (current stream)."""
+        a0, a1 = src_off[0], src_off[-1]
+        b0, b1 = dst_off[0], dst_off[-1]
+        self.exch.alltoallv(src[a0:a1], [o - a0 for o in src_off], dst[b0:b1], [o - b0 for o in dst_off], f)
+
+    def _exchange_all(self, src, src_offs, dst, dst_offs, f, ready=None):
+        """All rounds of one boundary-row exchange.  ``ready[r]`` (optional) is an event after which
+        round r's source rows exist.  Returns one waiter per round (call it on the compute stream
+        before touching that round's destination rows)."""
+        self._count(src_offs[-1][-1], dst_offs[-1][-1])
         if not self.overlap:
-            self.exch.alltoallv(send, send_off, recv, recv_off, f)
-            return lambda: None
+            for r in range(self.rounds):
+                self._exchange_round(src, src_offs[r], dst, dst_offs[r], f)
+            return [lambda: None] * self.rounds
         main = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        done = torch.cuda.Event()
+        if ready is None:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            ready = [ev] * self.rounds
+        waiters = []
         with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(ready)
-            self.exch.alltoallv(send, send_off, recv, recv_off, f)
-            done.record(self.comm_stream)
-        return lambda: main.wait_event(done)
+            for r in range(self.rounds):
+                self.comm_stream.wait_event(ready[r])
+                self._exchange_round(src, src_offs[r], dst, dst_offs[r], f)
+                done = torch.cuda.Event()
+                done.record(self.comm_stream)
+                waiters.append(lambda d=done: main.wait_event(d))
+        return waiters
 
     # ------------------------------------------------------------------
     def forward(self, H: torch.Tensor) -> torch.Tensor:
@@ -218,10 +242,11 @@ class AggregationEngine:
         send = self._slab("send", self.n_send, f)
         halo = self._slab("halo", self.n_halo, f)
         self.k.gather_rows(H, self.send_idx, send)
-        wait = self._exchange(send, self.send_off, halo, self.recv_off, f)
+        waits = self._exchange_all(send, self.round_send_off, halo, self.round_recv_off, f)
         self.k.spmm(self.A_loc, H, C)            # overlaps the exchange (main.c:271)
-        wait()
-        self.k.spmm(self.A_halo, halo, C, accumulate=True)   # main.c:295
+        for r in range(self.rounds):
+            waits[r]()
+            self.k.spmm(self.A_halo[r], halo, C, accumulate=True)   # main.c:295; overlaps round r+1
         return C
 
     def backward(self, G: torch.Tensor) -> torch.Tensor:
@@ -235,14 +260,24 @@ class AggregationEngine:
             return self.k.spmm(self.A_loc_T, G, dH)
         partial = self._slab("halo", self.n_halo, f)
         back = self._slab("send", self.n_send, f)
-        self.k.spmm(self.A_halo_T, G, partial)
-        wait = self._exchange(partial, self.recv_off, back, self.send_off, f)
+        ready = []
+        for r in range(self.rounds):             # round r's partial rows, then hand them to the wire
+            b0, b1 = self.round_recv_off[r][0], self.round_recv_off[r][-1]
+            self.k.spmm(self.A_halo_T[r], G, partial[b0:b1])
+            if self.overlap:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                ready.append(ev)
+        waits = self._exchange_all(partial, self.round_recv_off, back, self.round_send_off, f,
+                                   ready if self.overlap else None)
         self.k.spmm(self.A_loc_T, G, dH)
-        wait()
-        for q in range(self.size):                 # per peer: indices unique within a message
-            a, b = self.send_off[q], self.send_off[q + 1]
-            if b > a:
-                self.k.scatter_rows(dH, self.send_idx[a:b], back[a:b], accumulate=True)
+        for r in range(self.rounds):
+            waits[r]()
+            off = self.round_send_off[r]
+            for q in range(self.size):           # per (round, peer): indices unique within a message
+                a, b = off[q], off[q + 1]
+                if b > a:
+                    self.k.scatter_rows(dH, self.send_idx[a:b], back[a:b], accumulate=True)
         return dH
 
     def forward_symmetric_backward(self, G: torch.Tensor) -> torch.Tensor:
@@ -255,6 +290,6 @@ class AggregationEngine:
         """Compulsory HBM bytes of one forward aggregation on this rank."""
         b = self.A_loc.alg_bytes(f)
         if self.size > 1:
-            b += 8 * self.A_halo.nnz + 8 * (self.A_halo.nrows + 1) + 4 * f * self.n_halo
+            b += sum(8 * a.nnz + 8 * (a.nrows + 1) for a in self.A_halo) + 4 * f * self.n_halo
             b += 2 * 4 * f * self.n_send   # pack: read rows + write slab
         return b

@@ -142,10 +142,9 @@ def main(argv, kernels=None, out=None):
     elapsed = torch.tensor([time.time() - tic], dtype=torch.float64)
     # statistics(), main.c:506-524: volumes in SCALARS (rows x width, :264), per rank
     widths = [d[l] for l in range(1, L)] + [d[l + 1] for l in range(L - 1, 0, -1)]     # per epoch
-    rows_out = sum(part.send_off[q + 1] - part.send_off[q] for q in range(world))
-    rows_in = sum(part.recv_off[q + 1] - part.recv_off[q] for q in range(world))
-    nz_t = sum(1 for q in range(world) if part.send_off[q + 1] > part.send_off[q])
-    nz_s = sum(1 for q in range(world) if part.recv_off[q + 1] > part.recv_off[q])
+    rows_out, rows_in = part.n_send, part.n_halo
+    nz_t = int(torch.unique(part.send_owner).numel())      # targets I really send to (Hsend != NULL, main.c:247)
+    nz_s = int(torch.unique(part.halo_owner).numel())      # sources (Hrecv != -1, main.c:239)
     st = torch.tensor([rows_out * sum(widths) * 3, rows_in * sum(widths) * 3, nz_t * len(widths) * 3,
                        nz_s * len(widths) * 3], dtype=torch.float64)
     if world > 1:

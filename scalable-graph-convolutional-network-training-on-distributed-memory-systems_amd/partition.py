@@ -273,23 +273,36 @@ def csr_from_scipy(A, nslices: Optional[int] = None, core: bool = False, tau: fl
 
 @dataclass
 class Partition:
-    """Everything rank ``rank`` needs for the aggregation path."""
+    """Everything rank ``rank`` needs for the aggregation path.
+
+    Boundary slabs.  The rows a rank receives (``halo``) and sends (``send``) live in two slabs
+    laid out round-major: position order = (round, peer rank, global degree rank).  Each peer's
+    list (degree order) is cut into ``rounds`` consecutive parts; round r of the exchange moves
+    part r of every peer's list -- one contiguous all-to-all-v on the sub-slab
+    [round_*_off[r][0], round_*_off[r][size]) -- so that the halo pass on round r can run while
+    round r+1 is still on the wire.  Sender and receiver cut identical lists identically."""
     n: int                      # global number of vertices
     rank: int
     size: int
-    owned: torch.Tensor         # int64 [n_p] global id of local row i (decreasing local degree)
+    owned: torch.Tensor         # int64 [n_p] global id of local row i (decreasing global degree)
     A_loc: HostCSR              # n_p x n_p
-    A_halo: HostCSR             # compact rows x n_halo (row_map -> local row)
+    A_halo: List[HostCSR]       # per round: n_p x n_halo, only the columns of that round's sub-slab
     A_loc_T: HostCSR            # n_p x n_p
-    A_halo_T: HostCSR           # n_halo x n_p   (all halo rows kept: every one is referenced)
-    send_idx: torch.Tensor      # int32 [n_send] LOCAL row ids, concatenated by target rank
-    send_off: List[int]         # size+1 offsets into send_idx (own segment empty)
-    recv_off: List[int]         # size+1 offsets into the receive slab (own segment empty)
-    halo_global: torch.Tensor   # int64 [n_halo] global ids of the receive slab rows
-    send_global: torch.Tensor   # int64 [n_send] global ids of send_idx
+    A_halo_T: List[HostCSR]     # per round: (rows of that round's sub-slab) x n_p
+    send_idx: torch.Tensor      # int32 [n_send] LOCAL row ids, in send-slab order
+    send_owner: torch.Tensor    # int64 [n_send] target rank of every send-slab row
+    halo_owner: torch.Tensor    # int64 [n_halo] owner rank of every halo-slab row
+    round_send_off: List[List[int]]   # rounds x (size+1) absolute offsets into the send slab
+    round_recv_off: List[List[int]]   # rounds x (size+1) absolute offsets into the halo slab
+    halo_global: torch.Tensor   # int64 [n_halo] global ids of the halo slab rows
+    send_global: torch.Tensor   # int64 [n_send] global ids of the send slab rows
     nnz_global: int = 0
     symmetric: Optional[bool] = None
     extra: Dict = field(default_factory=dict)
+
+    @property
+    def rounds(self) -> int:
+        return len(self.round_send_off)
 
     @property
     def n_local(self) -> int:
@@ -305,17 +318,55 @@ class Partition:
 
     @property
     def nnz_local(self) -> int:
-        return self.A_loc.nnz + self.A_halo.nnz
+        return self.A_loc.nnz + sum(a.nnz for a in self.A_halo)
+
+    @property
+    def send_off(self) -> List[int]:
+        """size+1 offsets of the per-peer segments -- only meaningful with one round."""
+        if self.rounds != 1:
+            raise ValueError("per-peer segments are contiguous only with a single exchange round")
+        return self.round_send_off[0]
+
+    @property
+    def recv_off(self) -> List[int]:
+        if self.rounds != 1:
+            raise ValueError("per-peer segments are contiguous only with a single exchange round")
+        return self.round_recv_off[0]
 
     def send_map(self) -> Dict[int, torch.Tensor]:
         """peer -> sorted global ids I send (== reference send_map, PGCN.py:47-50).  The slab
-        itself is in degree-rank order (`send_global`); this is the API view."""
-        return {q: torch.sort(self.send_global[self.send_off[q]:self.send_off[q + 1]]).values
+        itself is in (round, peer, degree-rank) order; this is the API view."""
+        return {q: torch.sort(self.send_global[self.send_owner == q]).values
                 for q in range(self.size) if q != self.rank}
 
     def recv_map(self) -> Dict[int, torch.Tensor]:
-        return {q: torch.sort(self.halo_global[self.recv_off[q]:self.recv_off[q + 1]]).values
+        return {q: torch.sort(self.halo_global[self.halo_owner == q]).values
                 for q in range(self.size) if q != self.rank}
+
+
+EXCHANGE_ROUNDS = int(os.environ.get("PGCN_EXCHANGE_ROUNDS", "2"))
+
+
+def _round_major(owner: torch.Tensor, size: int, rounds: int):
+    """``owner`` lists, in slab order, the peer of every row of a (peer, degree-rank)-sorted slab.
+    Returns (order, round_off): ``order`` permutes the slab into (round, peer, degree-rank) order
+    and ``round_off[r]`` are the size+1 absolute offsets of round r's per-peer segments."""
+    dev = owner.device
+    m = int(owner.numel())
+    cnt = torch.bincount(owner, minlength=size) if m else torch.zeros(size, dtype=torch.int64, device=dev)
+    start = torch.cumsum(cnt, 0) - cnt
+    idx = torch.arange(m, dtype=torch.int64, device=dev) - start[owner]
+    rnd = torch.clamp(idx * rounds // torch.clamp(cnt[owner], min=1), max=rounds - 1)
+    order = torch.argsort(rnd * size + owner, stable=True)
+    seg = torch.bincount(rnd * size + owner, minlength=rounds * size).cpu().tolist() if m else [0] * (rounds * size)
+    round_off, pos = [], 0
+    for r in range(rounds):
+        off = [pos]
+        for q in range(size):
+            pos += int(seg[r * size + q])
+            off.append(pos)
+        round_off.append(off)
+    return order, rnd[order], round_off
 
 
 def _offsets(owner: torch.Tensor, size: int) -> List[int]:
@@ -329,7 +380,7 @@ def _offsets(owner: torch.Tensor, size: int) -> List[int]:
 
 def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: int,
                     partvec: torch.Tensor, rank: int, size: int,
-                    with_transpose: bool = True) -> Partition:
+                    with_transpose: bool = True, rounds: Optional[int] = None) -> Partition:
     """Build rank ``rank``'s pieces from the GLOBAL COO (row, col, val) of A.
 
     Mirrors the reference, where every rank parses the whole matrix (PGCN.py:171)
@@ -372,34 +423,47 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     loc = cp == rank
 
     A_loc = csr_from_coo(r[loc], g2l[c[loc]], v[loc], n_p, n_p, core=CORE_ON)
-    # halo columns, ordered by (owner, degree rank): the receive slab.  As a SET per owner this
-    # is the reference's recv_map[q] (PGCN.py:44-48)
+    R = max(1, (EXCHANGE_ROUNDS if rounds is None else rounds)) if size > 1 else 1
+    # halo columns: per owner the reference's recv_map[q] as a SET (PGCN.py:44-48), ordered
+    # (round, owner, degree rank)
     hkey = cp[~loc] * n + grank[c[~loc]]
     huniq, hinv = torch.unique(hkey, return_inverse=True)
-    halo_global = gorder[huniq % n]
-    halo_owner = huniq // n
+    h_order, h_round, round_recv_off = _round_major(huniq // n, size, R)
+    newpos = torch.empty_like(h_order)
+    newpos[h_order] = torch.arange(h_order.numel(), dtype=torch.int64, device=dev)
+    hcol = newpos[hinv]                                   # halo-slab position of every halo entry
+    halo_global = gorder[huniq % n][h_order]
+    halo_owner = (huniq // n)[h_order]
     n_halo = int(huniq.numel())
-    recv_off = _offsets(halo_owner.cpu(), size)
     halo_core = CORE_ON and size > 1
-    A_halo = csr_from_coo(r[~loc], hinv, v[~loc], n_p, n_halo, compact_rows=not halo_core, core=halo_core)
+    ecol_round = h_round[hcol] if n_halo else hcol
+    rr, vv = r[~loc], v[~loc]
+    A_halo, A_halo_T = [], []
+    for k in range(R if size > 1 else 0):
+        sel = ecol_round == k
+        A_halo.append(csr_from_coo(rr[sel], hcol[sel], vv[sel], n_p, n_halo, compact_rows=not halo_core,
+                                   core=halo_core))
+        if with_transpose:
+            base, end = round_recv_off[k][0], round_recv_off[k][size]
+            A_halo_T.append(csr_from_coo(hcol[sel] - base, rr[sel], vv[sel], end - base, n_p, core=halo_core))
 
-    A_loc_T = A_halo_T = None
+    A_loc_T = None
     if with_transpose:
         A_loc_T = csr_from_coo(g2l[c[loc]], r[loc], v[loc], n_p, n_p, core=CORE_ON)
-        A_halo_T = csr_from_coo(hinv, r[~loc], v[~loc], n_halo, n_p, core=halo_core)
 
-    # rows of mine that other ranks need: (target rank, degree rank) sorted = the peer's slab order
+    # rows of mine that other ranks need, in the peers' slab order (round, target rank, degree rank)
     theirs = (pcol == rank) & (prow != rank)
     skey = prow[theirs] * n + grank[col[theirs]]
     suniq = torch.unique(skey)
-    send_global = gorder[suniq % n]
-    send_owner = suniq // n
-    send_off = _offsets(send_owner.cpu(), size)
+    s_order, _, round_send_off = _round_major(suniq // n, size, R)
+    send_global = gorder[suniq % n][s_order]
+    send_owner = (suniq // n)[s_order]
     send_idx = g2l[send_global].to(torch.int32)
 
     return Partition(n=n, rank=rank, size=size, owned=owned, A_loc=A_loc, A_halo=A_halo,
                      A_loc_T=A_loc_T, A_halo_T=A_halo_T, send_idx=send_idx.contiguous(),
-                     send_off=send_off, recv_off=recv_off, halo_global=halo_global,
+                     send_owner=send_owner, halo_owner=halo_owner, round_send_off=round_send_off,
+                     round_recv_off=round_recv_off, halo_global=halo_global,
                      send_global=send_global, nnz_global=int(row.numel()))
 
 

@@ -233,10 +233,21 @@ class _PrecomputedExchanger:
 
     def __init__(self):
         self.next_recv = None
+        self.sent_parts, self.cursor = [], 0
 
-    def alltoallv(self, send, send_off, recv, recv_off, f):
-        self.sent = send[:send_off[-1]].clone()
-        recv[:recv_off[-1]] = self.next_recv
+    def begin(self, recv_rows):
+        """Arm one exchange: `recv_rows` is the whole slab the rank should receive (all rounds)."""
+        self.next_recv, self.sent_parts, self.cursor = recv_rows, [], 0
+
+    @property
+    def sent(self):
+        return torch.cat(self.sent_parts) if self.sent_parts else None
+
+    def alltoallv(self, send, send_off, recv, recv_off, f):   # called once per round, sub-slabs
+        self.sent_parts.append(send[:send_off[-1]].clone())
+        k = recv_off[-1]
+        recv[:k] = self.next_recv[self.cursor:self.cursor + k]
+        self.cursor += k
 
     def allreduce_sum(self, buf):
         pass
@@ -256,7 +267,7 @@ def _virtual_ranks_fwd_bwd(K, dev, A, part, P, Hfull, Gfull):
         ex = _PrecomputedExchanger() if P > 1 else None
         eng = engine.AggregationEngine(p, K, dev, ex)
         if P > 1:
-            ex.next_recv = torch.from_numpy(Hfull[p.halo_global.numpy()]).to(dev)
+            ex.begin(torch.from_numpy(Hfull[p.halo_global.numpy()]).to(dev))
         own = p.owned.numpy()
         out = eng.forward(torch.from_numpy(Hfull[own]).to(dev))
         torch.cuda.synchronize()
@@ -268,24 +279,25 @@ def _virtual_ranks_fwd_bwd(K, dev, A, part, P, Hfull, Gfull):
     partials = {}
     for eng, ex, p in engines:
         if P > 1:
-            ex.next_recv = torch.zeros((p.n_send, f), device=dev)
+            ex.begin(torch.zeros((p.n_send, f), device=dev))
         eng.backward(torch.from_numpy(Gfull[p.owned.numpy()]).to(dev))
         torch.cuda.synchronize()
-        if P > 1:
-            partials[p.rank] = (p.halo_global.numpy(), ex.sent.cpu().numpy(), list(p.recv_off))
+        if P > 1:   # what this rank computed for rows owned by others: (owner, global id) -> partial row
+            partials[p.rank] = (p.halo_owner.numpy(), p.halo_global.numpy(), ex.sent.cpu().numpy())
     bwd = np.zeros((n, f), np.float32)
     for eng, ex, p in engines:
         if P > 1:
             back = np.zeros((p.n_send, f), np.float32)
+            tgt, gid = p.send_owner.numpy(), p.send_global.numpy()
             for q in range(P):
                 if q == p.rank:
                     continue
-                hg, slab, roff = partials[q]
-                seg = slice(roff[p.rank], roff[p.rank + 1])       # what q computed for my rows
-                a, b = p.send_off[q], p.send_off[q + 1]
-                np.testing.assert_array_equal(hg[seg], p.send_global.numpy()[a:b])   # same slab order
-                back[a:b] = slab[seg]
-            ex.next_recv = torch.from_numpy(back).to(dev)
+                ho, hg, slab = partials[q]
+                mine = ho == p.rank                                # what q computed for my rows, q's slab order
+                pos = np.nonzero(tgt == q)[0]                      # where q's rows sit in my send slab
+                np.testing.assert_array_equal(hg[mine], gid[pos])  # same (round, degree-rank) order on both sides
+                back[pos] = slab[mine]
+            ex.begin(torch.from_numpy(back).to(dev))
         out = eng.backward(torch.from_numpy(Gfull[p.owned.numpy()]).to(dev))
         torch.cuda.synchronize()
         bwd[p.owned.numpy()] = out.cpu().numpy()
@@ -319,8 +331,9 @@ def test_engine_halo_dense_core(K, dev, P, f):
     Hfull = rng.random((n, f), dtype=np.float32) * 2 - 1
     Gfull = rng.random((n, f), dtype=np.float32) * 2 - 1
     fwd, bwd, engines = _virtual_ranks_fwd_bwd(K, dev, A, part, P, Hfull, Gfull)
-    assert any(e.A_halo.core is not None for e, _, _ in engines)
-    assert any(e.A_halo_T.core is not None for e, _, _ in engines)
+    assert any(a.core is not None for e, _, _ in engines for a in e.A_halo)
+    assert any(a.core is not None for e, _, _ in engines for a in e.A_halo_T)
+    assert all(e.rounds == 2 for e, _, _ in engines)
     Ac = sp.csr_matrix(A)
     assert rel_err(fwd, oracle.spmm(Ac, Hfull)) < TOL
     assert rel_err(bwd, oracle.spmm(sp.csr_matrix(A.T), Gfull)) < TOL

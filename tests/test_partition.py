@@ -9,15 +9,26 @@ from scipy.io import mmread
 from conftest import SPMM_CASES, golden, gpath, pkg, read_partvec
 
 
-def _build(mtx, pv, rank, P):
+def _build(mtx, pv, rank, P, rounds=None):
     partition = pkg("partition")
     A = sp.coo_matrix(mmread(gpath(mtx)))
     part = read_partvec(gpath(pv))
     p = partition.build_partition(torch.from_numpy(A.row.astype(np.int64)),
                                   torch.from_numpy(A.col.astype(np.int64)),
                                   torch.from_numpy(A.data.astype(np.float32)), A.shape[0],
-                                  torch.tensor(part), rank, P)
+                                  torch.tensor(part), rank, P, rounds=rounds)
     return A, np.asarray(part), p
+
+
+def _sum_dense(csrs, nrows, ncols, row_base=None):
+    out = np.zeros((nrows, ncols), np.float32)
+    for k, c in enumerate(csrs):
+        d = _dense(c, nrows if row_base is None else None)
+        if row_base is None:
+            out += d
+        else:
+            out[row_base[k]:row_base[k] + d.shape[0]] += d
+    return out
 
 
 def _dense(csr, nrows=None):
@@ -38,20 +49,37 @@ def test_maps_and_counts_match_reference(name, mtx, pv, P):
         for q in smap:
             np.testing.assert_array_equal(smap[q].numpy(), arrays["send_%d_%d" % (r, q)])
             np.testing.assert_array_equal(rmap[q].numpy(), arrays["recv_%d_%d" % (r, q)])
-        assert p.send_off[r] == p.send_off[r + 1] and p.recv_off[r] == p.recv_off[r + 1]
-        # send_idx are LOCAL ids of the send_map rows
+        for off in p.round_send_off + p.round_recv_off:          # own-rank segments are empty
+            assert off[r] == off[r + 1]
+        assert not (p.send_owner == r).any() and not (p.halo_owner == r).any()
+        # send_idx are LOCAL ids of the send slab rows
         np.testing.assert_array_equal(p.owned.numpy()[p.send_idx.numpy()], p.send_global.numpy())
+        # the rounds tile both slabs without gaps, peers ascending inside a round
+        for offs, owner, total in ((p.round_send_off, p.send_owner, p.n_send), (p.round_recv_off, p.halo_owner, p.n_halo)):
+            pos = 0
+            for off in offs:
+                assert off[0] == pos and all(a <= b for a, b in zip(off, off[1:]))
+                for q in range(P):
+                    assert (owner.numpy()[off[q]:off[q + 1]] == q).all()
+                pos = off[-1]
+            assert pos == total
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 3])
 @pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES[:1] + SPMM_CASES[4:6])
-def test_pieces_reassemble_the_row_block(name, mtx, pv, P):
+def test_pieces_reassemble_the_row_block(name, mtx, pv, P, rounds):
     for r in range(P):
-        A, part, p = _build(mtx, pv, r, P)
+        A, part, p = _build(mtx, pv, r, P, rounds)
+        assert p.rounds == rounds
         Ad = A.toarray().astype(np.float32)
         own = p.owned.numpy()
         block = Ad[own]                                    # rows of rank r, global columns
         loc = _dense(p.A_loc)
-        halo = _dense(p.A_halo, p.n_local)
+        halo = _sum_dense(p.A_halo, p.n_local, p.n_halo)
+        # round k's matrix only touches round k's sub-slab
+        for k, a in enumerate(p.A_halo):
+            cols = a.to_coo()[1].numpy()
+            assert ((cols >= p.round_recv_off[k][0]) & (cols < p.round_recv_off[k][-1])).all()
         np.testing.assert_array_equal(loc, block[:, own])
         np.testing.assert_array_equal(halo, block[:, p.halo_global.numpy()])
         # nothing else in the block
@@ -60,9 +88,10 @@ def test_pieces_reassemble_the_row_block(name, mtx, pv, P):
         rest[:, p.halo_global.numpy()] = 0
         assert not rest.any()
         np.testing.assert_array_equal(_dense(p.A_loc_T), loc.T)
-        np.testing.assert_array_equal(_dense(p.A_halo_T), halo.T)
+        np.testing.assert_array_equal(
+            _sum_dense(p.A_halo_T, p.n_halo, p.n_local, [o[0] for o in p.round_recv_off]), halo.T)
         # inside every row: grouped by slice (col % nslices), ascending inside a slice
-        for csr in (p.A_loc, p.A_halo, p.A_loc_T, p.A_halo_T):
+        for csr in [p.A_loc, p.A_loc_T] + p.A_halo + p.A_halo_T:
             rp, c = csr.rowptr.numpy(), csr.col.numpy().astype(np.int64)
             key = (c % csr.nslices) * (csr.ncols + 1) + c
             for i in range(csr.nrows):
@@ -70,9 +99,12 @@ def test_pieces_reassemble_the_row_block(name, mtx, pv, P):
         # local numbering and slab orders = decreasing GLOBAL degree (stored entries, row + column)
         gd = np.bincount(A.row, minlength=A.shape[0]) + np.bincount(A.col, minlength=A.shape[0])
         assert (np.diff(gd[own]) <= 0).all()
-        for q in range(P):
-            assert (np.diff(gd[p.halo_global.numpy()[p.recv_off[q]:p.recv_off[q + 1]]]) <= 0).all()
-            assert (np.diff(gd[p.send_global.numpy()[p.send_off[q]:p.send_off[q + 1]]]) <= 0).all()
+        for k in range(p.rounds):
+            for q in range(P):
+                a, b = p.round_recv_off[k][q], p.round_recv_off[k][q + 1]
+                assert (np.diff(gd[p.halo_global.numpy()[a:b]]) <= 0).all()
+                a, b = p.round_send_off[k][q], p.round_send_off[k][q + 1]
+                assert (np.diff(gd[p.send_global.numpy()[a:b]]) <= 0).all()
 
 
 def test_edge_cases():
@@ -81,7 +113,7 @@ def test_edge_cases():
     # a rank that owns nothing, and an empty matrix
     p = partition.build_partition(torch.tensor([0, 1]), torch.tensor([1, 0]), torch.ones(2), 2,
                                   torch.tensor([0, 0]), 1, 2)
-    assert p.n_local == 0 and p.n_halo == 0 and p.n_send == 0 and p.A_loc.nnz == 0
+    assert p.n_local == 0 and p.n_halo == 0 and p.n_send == 0 and p.A_loc.nnz == 0 and p.rounds == 2
     p = partition.build_partition(z, z, torch.zeros(0), 3, torch.tensor([0, 1, 0]), 0, 2)
     assert p.n_local == 2 and p.A_loc.rowptr.tolist() == [0, 0, 0]
     with pytest.raises(ValueError):

@@ -24,9 +24,13 @@ def main():
     t0 = time.time(); p = partition.build_partition(row, col, val, n, pv, a.rank, a.world); torch.cuda.synchronize(); tb = time.time() - t0
     K = kernels.HipKernels(dev)
     t0 = time.time(); eng = engine.AggregationEngine(p, K, dev, NoExchange() if a.world > 1 else None); torch.cuda.synchronize(); tp = time.time() - t0
-    def frac(d): return 100.0 * d.core.nnz / max(d.nnz, 1) if d is not None and d.core is not None else 0.0
+    def frac(d):
+        ds = d if isinstance(d, list) else [d]
+        tot = sum(x.nnz for x in ds if x is not None)
+        return 100.0 * sum(x.core.nnz for x in ds if x is not None and x.core is not None) / max(tot, 1)
+    print("rounds=%d " % p.rounds, end="")
     print("P=%d rank=%d n_local=%d n_halo=%d n_send=%d nnz_loc=%d nnz_halo=%d | build %.2fs prepare %.2fs | core%%: loc %.0f halo %.0f locT %.0f haloT %.0f"
-          % (a.world, a.rank, p.n_local, p.n_halo, p.n_send, p.A_loc.nnz, p.A_halo.nnz if a.world > 1 else 0, tb, tp,
+          % (a.world, a.rank, p.n_local, p.n_halo, p.n_send, p.A_loc.nnz, sum(x.nnz for x in p.A_halo), tb, tp,
              frac(eng.A_loc), frac(eng.A_halo), frac(eng.A_loc_T), frac(eng.A_halo_T)))
     H = torch.rand(p.n_local, a.f, device=dev)
     if a.world > 1:
@@ -36,7 +40,7 @@ def main():
         for _ in range(a.rounds):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); fn(H); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
-        nnz = p.A_loc.nnz + (p.A_halo.nnz if a.world > 1 else 0)
+        nnz = p.A_loc.nnz + sum(x.nnz for x in p.A_halo)
         print("  %-8s median %.3f ms  (%.1f G edges/s on this rank; x%d ranks = %.1f G edges/s)" % (name, np.median(ts), nnz / np.median(ts) / 1e6, a.world, a.world * nnz / np.median(ts) / 1e6))
 
 if __name__ == "__main__":
