@@ -10,7 +10,7 @@ This is the MI355X-native re-design of ``communicate_fgm`` + ``torch.sparse.mm``
                                                                      C += A_halo[1] . halo   (after round 1 landed)
     backward  P[r] = A_halo[r]^T . G    (partials for rows owned by peers, round by round)
               reverse all-to-all-v r    (comm stream, as soon as P[r] exists)  ||  P[r+1], dH = A_loc^T . G
-              wait                                                   dH[send rows] += received partials
+              wait                                                   dH[send rows] += received partials (pattern SpMM)
 
 Every peer's boundary list is cut into `rounds` parts (partition.Partition): each round is one
 all-to-all-v over ALL peers (all xGMI links busy) on a contiguous sub-slab, and the halo pass of
@@ -171,6 +171,7 @@ class AggregationEngine:
         self.A_loc_T = kernels.prepare(part.A_loc_T) if part.A_loc_T is not None else None
         self.A_halo_T = [kernels.prepare(a) for a in part.A_halo_T]
         self.send_idx = part.send_idx.to(self.device)
+        self.unpack = [kernels.prepare(u, pattern_only=True) for u in part.unpack]
         self.rounds = part.rounds
         self.round_send_off = [list(o) for o in part.round_send_off]
         self.round_recv_off = [list(o) for o in part.round_recv_off]
@@ -273,11 +274,9 @@ class AggregationEngine:
         self.k.spmm(self.A_loc_T, G, dH)
         for r in range(self.rounds):
             waits[r]()
-            off = self.round_send_off[r]
-            for q in range(self.size):           # per (round, peer): indices unique within a message
-                a, b = off[q], off[q + 1]
-                if b > a:
-                    self.k.scatter_rows(dH, self.send_idx[a:b], back[a:b], accumulate=True)
+            # dH[row] += the partial rows that came back for it in this round: one pattern SpMM
+            # (deterministic; the reference ASSIGNS here and loses partials for P >= 3, quirk Q3)
+            self.k.spmm(self.unpack[r], back, dH, accumulate=True)
         return dH
 
     def forward_symmetric_backward(self, G: torch.Tensor) -> torch.Tensor:

@@ -85,6 +85,8 @@ CORE_EMAX = int(os.environ.get("PGCN_CORE_EMAX", "0"))           # entries per w
                                                                   # ~1024 pieces, between 4096 and 32768 entries
 CORE_PG = int(os.environ.get("PGCN_CORE_PANEL_GROUP", "0"))      # >0: cut pieces at multiples of PG panels
                                                                   # and run them panel-group-major (L2 locality)
+CORE_MIN_NNZ = int(os.environ.get("PGCN_CORE_MIN_NNZ", "262144"))  # smaller cores are not worth two more launches
+CORE_MIN_FRAC = float(os.environ.get("PGCN_CORE_MIN_FRAC", "0.1"))
 DEGREE_SORT = os.environ.get("PGCN_DEGREE_SORT", "1") != "0"
 
 
@@ -225,6 +227,8 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     hcore, row_flags = None, None
     if core and not compact_rows and r.numel():
         keep, hcore = split_core(r, c, v, nrows, ncols, tau, emax)
+        if hcore is not None and tau is None and (hcore.nnz < CORE_MIN_NNZ or hcore.nnz < CORE_MIN_FRAC * r.numel()):
+            hcore = None          # a small core does not pay for the extra kernel + fix-up launches
         if hcore is not None:
             r, c, v = r[keep], c[keep], v[keep]
             row_flags = torch.zeros(nrows, dtype=torch.uint8, device=dev)
@@ -290,6 +294,8 @@ class Partition:
     A_loc_T: HostCSR            # n_p x n_p
     A_halo_T: List[HostCSR]     # per round: (rows of that round's sub-slab) x n_p
     send_idx: torch.Tensor      # int32 [n_send] LOCAL row ids, in send-slab order
+    unpack: List[HostCSR]       # per round: pattern matrix (boundary rows x n_send) that adds the rows
+                                # received back in round r onto their local rows (reverse exchange)
     send_owner: torch.Tensor    # int64 [n_send] target rank of every send-slab row
     halo_owner: torch.Tensor    # int64 [n_halo] owner rank of every halo-slab row
     round_send_off: List[List[int]]   # rounds x (size+1) absolute offsets into the send slab
@@ -459,9 +465,19 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     send_global = gorder[suniq % n][s_order]
     send_owner = (suniq // n)[s_order]
     send_idx = g2l[send_global].to(torch.int32)
+    # reverse-exchange unpack as ONE pattern SpMM per round: local row i += sum of the slab rows that
+    # came back for it (a row sent to several peers comes back several times) -- replaces one
+    # scatter-add launch per (round, peer), same deterministic result
+    unpack = []
+    pos_all = torch.arange(send_idx.numel(), dtype=torch.int64, device=dev)
+    for k in range(R if size > 1 else 0):
+        a, b = round_send_off[k][0], round_send_off[k][size]
+        unpack.append(csr_from_coo(send_idx[a:b].to(torch.int64), pos_all[a:b],
+                                   torch.ones(b - a, dtype=torch.float32, device=dev), n_p,
+                                   int(send_idx.numel()), compact_rows=True, nslices=1))
 
     return Partition(n=n, rank=rank, size=size, owned=owned, A_loc=A_loc, A_halo=A_halo,
-                     A_loc_T=A_loc_T, A_halo_T=A_halo_T, send_idx=send_idx.contiguous(),
+                     A_loc_T=A_loc_T, A_halo_T=A_halo_T, send_idx=send_idx.contiguous(), unpack=unpack,
                      send_owner=send_owner, halo_owner=halo_owner, round_send_off=round_send_off,
                      round_recv_off=round_recv_off, halo_global=halo_global,
                      send_global=send_global, nnz_global=int(row.numel()))

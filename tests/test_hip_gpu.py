@@ -320,10 +320,12 @@ def test_engine_forward_backward_vs_reference_golden(K, dev, name, mtx, pv, P):
 
 
 @pytest.mark.parametrize("P,f", [(2, 128), (3, 64)])
-def test_engine_halo_dense_core(K, dev, P, f):
+def test_engine_halo_dense_core(K, dev, P, f, monkeypatch):
     """Multi-rank partition of a power-law graph: the degree-ordered receive slab gives A_halo and
     A_halo^T dense tiles too, so the LDS-tiled kernel runs on the halo pass as well."""
-    synth = pkg("synth")
+    synth, partition = pkg("synth"), pkg("partition")
+    monkeypatch.setattr(partition, "CORE_MIN_NNZ", 0)            # keep the (small) cores of this small graph
+    monkeypatch.setattr(partition, "CORE_MIN_FRAC", 0.0)
     n, row, col, val = synth.make_graph(6000, 900000, seed=3)
     A = sp.coo_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n, n))
     part = synth.random_partvec(n, P, seed=1)
