@@ -51,6 +51,11 @@ class DeviceCSR:
     fix_all: Optional[torch.Tensor] = None    # int32 [nfix_all,4] combined fix list (core + gather slots)
     slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
     nslots_total: int = 0
+    launch_cache: dict = None                 # bound C-ABI calls per (ldb, ldc, f, accumulate)
+
+    def __post_init__(self):
+        if self.launch_cache is None:
+            self.launch_cache = {}
 
     def alg_bytes(self, f: int, n_cols_touched: Optional[int] = None, n_rows_out: Optional[int] = None) -> int:
         """Algorithmic (compulsory) HBM bytes of one SpMM, SURVEY 8(d):
@@ -211,71 +216,97 @@ class HipKernels:
             raise _lib.PgcnError("%s has %d rows, need %d" % (what, t.shape[0], rows))
 
     def spmm(self, A: DeviceCSR, B: torch.Tensor, C: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
-        """C (+)= A.B on the current stream.  C rows are addressed through A.row_map if set."""
+        """C (+)= A.B on the current stream.  C rows are addressed through A.row_map if set.
+
+        The argument lists of the C-ABI calls only change in three pointers from call to call, so
+        they are bound once per (leading dimensions, width, accumulate) and replayed: an epoch on
+        8 GPUs is ~120 launches of ~30 us of device time each, the Python side must stay out of
+        the way."""
+        if not (B.is_cuda and C.is_cuda and B.dtype is torch.float32 and C.dtype is torch.float32):
+            raise _lib.PgcnError("B and C must be fp32 CUDA matrices")
+        if B.shape[0] < A.ncols or (A.row_map is None and C.shape[0] < A.nrows):
+            raise _lib.PgcnError("B or C has too few rows")
+        key = (B.stride(0), C.stride(0), B.shape[1], accumulate, C.shape[1], B.stride(1), C.stride(1))
+        fn = A.launch_cache.get(key)
+        if fn is None:
+            fn = self._bind_spmm(A, B, C, accumulate)
+            A.launch_cache[key] = fn
+        fn(B, C)
+        return C
+
+    def _bind_spmm(self, A: DeviceCSR, B: torch.Tensor, C: torch.Tensor, accumulate: bool):
         f = B.shape[1]
         self._check_dense(B, A.ncols, "B")
         self._check_dense(C, 0, "C")
         if C.shape[1] != f:
             raise _lib.PgcnError("B and C widths differ")
-        if A.row_map is None and C.shape[0] < A.nrows:
-            raise _lib.PgcnError("C has too few rows")
+        ldb, ldc = B.stride(0), C.stride(0)
         flags = self.base_flags | (_lib.SPMM_ACCUMULATE if accumulate else 0)
-        if (A.ncols + 1) * B.stride(0) * 4 < 2 ** 32:
+        if (A.ncols + 1) * ldb * 4 < 2 ** 32:
             flags |= _lib.SPMM_OFFSETS32
+        lib, check, stream = self.lib, _lib.check, self._stream
         if A.nrows == 0:
-            return C
+            return lambda B, C: None
         if A.nnz == 0 and A.core is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
-            if not accumulate:
-                if A.row_map is None:
-                    C[:A.nrows].zero_()
-                else:
-                    C.index_fill_(0, A.row_map.long(), 0.0)
-            return C
+            if accumulate:
+                return lambda B, C: None
+            if A.row_map is None:
+                return lambda B, C: C[:A.nrows].zero_()
+            rows = A.row_map.long()
+            return lambda B, C: C.index_fill_(0, rows, 0.0)
+        rowptr, col, val, rmap = A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), _ptr(A.row_map)
         if A.tasks is None and A.row_map is None and A.core is None:
-            _lib.check(self.lib.pgcn_spmm_csr_f32(
-                A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.nrows, B.data_ptr(),
-                B.stride(0), C.data_ptr(), C.stride(0), f, flags, self._stream()), "pgcn_spmm_csr_f32")
-            return C
+            nrows = A.nrows
+            def simple(B, C):
+                check(lib.pgcn_spmm_csr_f32(rowptr, col, val, nrows, B.data_ptr(), ldb, C.data_ptr(), ldc, f,
+                                            flags, stream()), "pgcn_spmm_csr_f32")
+            return simple
         need = A.nslots_total * f
         if need and (A.ws is None or A.ws.numel() < need):
             A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
-        ws_n = 0 if A.ws is None else A.ws.numel()
+            A.launch_cache.clear()              # other bindings hold the old work-space pointer
+        ws, ws_n = _ptr(A.ws), (0 if A.ws is None else A.ws.numel())
+        tasks, ntasks, seg, nslices = A.tasks.data_ptr(), A.ntasks, A.seg, A.nslices
+        nslots = A.nslots
         if A.core is None:
-            _lib.check(self.lib.pgcn_spmm_csr_plan_f32(
-                A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.tasks.data_ptr(), A.ntasks,
-                A.seg, A.nslices, _ptr(A.fix), A.nfix, _ptr(A.row_map), B.data_ptr(), B.stride(0), C.data_ptr(),
-                C.stride(0), f, _ptr(A.ws), ws_n, A.nslots, flags, self._stream()), "pgcn_spmm_csr_plan_f32")
-            return C
+            fix, nfix = _ptr(A.fix), A.nfix
+            def planned(B, C):
+                check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, rmap,
+                                                 B.data_ptr(), ldb, C.data_ptr(), ldc, f, ws, ws_n, nslots, flags,
+                                                 stream()), "pgcn_spmm_csr_plan_f32")
+            return planned
         # gather part (partial sums stay in the work-space) + LDS-tiled core + one combined fix-up
-        side = None
-        if self.core_overlap and A.ntasks:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            side = self._side
-            main = torch.cuda.current_stream(self.device)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-        if A.ntasks:
-            _lib.check(self.lib.pgcn_spmm_csr_plan_f32(
-                A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), A.tasks.data_ptr(), A.ntasks,
-                A.seg, A.nslices, None, 0, _ptr(A.row_map), B.data_ptr(), B.stride(0), C.data_ptr(),
-                C.stride(0), f, _ptr(A.ws), ws_n, A.nslots, flags | _lib.SPMM_NO_FIXUP, self._stream()),
-                "pgcn_spmm_csr_plan_f32")
         co = A.core
-        core_stream = side.cuda_stream if side is not None else self._stream()
-        _lib.check(self.lib.pgcn_spmm_core_f32(
-            co.work.data_ptr(), co.npieces, co.tile_panel.data_ptr(), co.tile_base.data_ptr(),
-            co.seg_off.data_ptr(), co.ccol.data_ptr(), co.cval.data_ptr(), B.data_ptr(), B.stride(0),
-            A.ncols, f, A.ws.data_ptr(), ws_n, A.nslots_total, core_stream), "pgcn_spmm_core_f32")
-        if side is not None:
-            done = torch.cuda.Event()
-            done.record(side)
-            torch.cuda.current_stream(self.device).wait_event(done)
-        _lib.check(self.lib.pgcn_spmm_fixup_f32(
-            A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr(), _ptr(A.row_map), A.ws.data_ptr(),
-            C.data_ptr(), C.stride(0), f, flags & _lib.SPMM_ACCUMULATE, self._stream()), "pgcn_spmm_fixup_f32")
-        return C
+        cw, cn, ctp, ctb, cso, ccol, cval = (co.work.data_ptr(), co.npieces, co.tile_panel.data_ptr(),
+                                             co.tile_base.data_ptr(), co.seg_off.data_ptr(), co.ccol.data_ptr(),
+                                             co.cval.data_ptr())
+        ncols, nst = A.ncols, A.nslots_total
+        fixp, nfa, slots = A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr()
+        gflags, fflags = flags | _lib.SPMM_NO_FIXUP, flags & _lib.SPMM_ACCUMULATE
+        overlap = self.core_overlap and ntasks
+
+        def hybrid(B, C):
+            b, c, s = B.data_ptr(), C.data_ptr(), stream()
+            cs = s
+            if overlap:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                main = torch.cuda.current_stream(self.device)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._side.wait_event(ev)
+                cs = self._side.cuda_stream
+            if ntasks:
+                check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, None, 0, rmap, b, ldb,
+                                                 c, ldc, f, ws, ws_n, nslots, gflags, s), "pgcn_spmm_csr_plan_f32")
+            check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, cs),
+                  "pgcn_spmm_core_f32")
+            if overlap:
+                done = torch.cuda.Event()
+                done.record(self._side)
+                torch.cuda.current_stream(self.device).wait_event(done)
+            check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, c, ldc, f, fflags, s), "pgcn_spmm_fixup_f32")
+        return hybrid
 
     def gather_rows(self, H: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         n = idx.numel()

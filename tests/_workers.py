@@ -46,6 +46,7 @@ def pspmm_worker(rank, P, port, path_A, path_pv, f, seed, q):
     Hfull, Gfull = golden_inputs(A.shape[0], f, seed)
     H = torch.tensor(Hfull[own], requires_grad=True)
     out = M.PSpMM.apply(eng, H)
+    M._sync_stats(eng)                       # counters live in the engine; run() publishes them
     stats_fwd = {k: int(v) for k, v in M.stats.items()}
     out.backward(torch.tensor(Gfull[own]))
     # the standalone communicate_fgm entry point

@@ -43,5 +43,26 @@ def main():
         nnz = p.A_loc.nnz + sum(x.nnz for x in p.A_halo)
         print("  %-8s median %.3f ms  (%.1f G edges/s on this rank; x%d ranks = %.1f G edges/s)" % (name, np.median(ts), nnz / np.median(ts) / 1e6, a.world, a.world * nnz / np.median(ts) / 1e6))
 
+    # full training epoch of this rank (3 layers, Adam), exchange = no-op: compute + host launch cost
+    import torch.nn as nn
+    P = pkg("PGCN")
+    P.device, P.myrank, P.world_size = dev, 0, 1          # world_size 1: no gradient all-reduce
+    P.init_stats()
+    model = nn.Sequential(*[P.PGCN(eng, a.f, a.f) for _ in range(3)]).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    Hr = torch.rand(p.n_local, a.f, device=dev).requires_grad_(True)
+    labels = p.owned.to(dev) % a.f
+    def step():
+        loss = P.local_loss(model(Hr), labels, n); opt.zero_grad(); loss.backward(); opt.step()
+    for _ in range(3): step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10): step()
+    t_host = (time.perf_counter() - t0) / 10
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / 10
+    print("  epoch (no exchange): %.2f ms wall, host enqueue %.2f ms" % (1e3 * t_all, 1e3 * t_host))
+
+
 if __name__ == "__main__":
     main()
