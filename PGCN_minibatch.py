@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Launcher with the command line of the reference's GPU/PGCN-Mini-batch.py:
+
+    python PGCN_minibatch.py -a A.mtx -p partvec.pickle -b nccl|gloo -s ngpu -l layers -f hidden -n batch_size
+"""
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+_impl = importlib.import_module(
+    "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd.PGCN_minibatch")
+
+if __name__ == "__main__":
+    _impl.main(sys.argv[1:])

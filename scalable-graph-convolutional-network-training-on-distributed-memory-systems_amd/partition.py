@@ -386,7 +386,8 @@ def _offsets(owner: torch.Tensor, size: int) -> List[int]:
 
 def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: int,
                     partvec: torch.Tensor, rank: int, size: int,
-                    with_transpose: bool = True, rounds: Optional[int] = None) -> Partition:
+                    with_transpose: bool = True, rounds: Optional[int] = None,
+                    degree_sort: Optional[bool] = None) -> Partition:
     """Build rank ``rank``'s pieces from the GLOBAL COO (row, col, val) of A.
 
     Mirrors the reference, where every rank parses the whole matrix (PGCN.py:171)
@@ -408,7 +409,7 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     # dense core of a power-law graph is the top-left corner of A_loc and the head of every
     # owner segment of A_halo -- what the LDS-tiled kernel feeds on.  Purely internal: `owned`,
     # `send_global` and `halo_global` record the orders; sender and receiver agree by construction.
-    if DEGREE_SORT and n > 1:
+    if (DEGREE_SORT if degree_sort is None else degree_sort) and n > 1:
         gdeg = torch.bincount(row, minlength=n) + torch.bincount(col, minlength=n)
         gorder = torch.argsort(-gdeg, stable=True)
     else:

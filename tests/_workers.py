@@ -120,3 +120,25 @@ def run_worker_gpu(rank, P, port, path_A, path_pv, nlayers, f, seed, q):
            "weights": [m.linear.weight.detach().cpu().numpy() for m in model]})
     dist.barrier()
     dist.destroy_process_group()
+
+
+def minibatch_worker(rank, P, port, path_A, path_pv, f, bs, seed, gpu, q):
+    """PGCN_minibatch.run(); gpu=True uses the real kernels (processes share cuda:0), else the checker."""
+    _init(rank, P, port)
+    from conftest import pkg
+    M = pkg("PGCN")
+    MB = pkg("PGCN_minibatch")
+    if gpu:
+        M._kernel_provider = None
+    else:
+        from oracle_kernels import OracleKernels
+        M._kernel_provider = OracleKernels()
+    M._exchanger = None
+    torch.manual_seed(seed)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        model = MB.run(rank, P, 3, f, path_A, path_pv, "gloo", bs)
+    q.put({"rank": rank, "stdout": buf.getvalue(),
+           "weights": [m.linear.weight.detach().cpu().numpy() for m in (model.gcn1, model.gcn2, model.gcn3)]})
+    dist.barrier()
+    dist.destroy_process_group()

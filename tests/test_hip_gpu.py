@@ -512,3 +512,40 @@ def test_pargcn_cli_on_reference_inputs(dev, tmp_path):
         assert rel_err(Wn[l].cpu().numpy(), Wc[l]) < TOL
     assert rel_err(Hout.cpu().numpy(), Hl[part.owned.numpy()]) < TOL
     assert buf.getvalue().startswith("nlayers:3") and "time :" in buf.getvalue()
+
+
+@pytest.mark.parametrize("name,P", [("ref_minibatch_karateA", 1), ("ref_minibatch_gemat11pA", 1), ("ref_minibatch_gemat11pA", 2)])
+def test_minibatch_driver_real_kernels(dev, name, P, tmp_path):
+    """PGCN_minibatch.run() with the HIP kernels vs the reference's PGCN-Mini-batch.py (P=1 golden)."""
+    import json, pickle
+    import torch.multiprocessing as mp
+    import _workers
+    from conftest import GOLDEN
+    arrays = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    meta = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    pv = gpath(name + ".partvec.pickle")
+    if P > 1:
+        pv = str(tmp_path / "pv.pickle")
+        n = len(pickle.load(open(gpath(name + ".partvec.pickle"), "rb")))
+        with open(pv, "wb") as f:
+            pickle.dump([int(x) for x in np.random.default_rng(0).integers(0, P, n)], f)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_workers.minibatch_worker,
+                         args=(r, P, 29950 + P, gpath(meta["mtx"]), pv, meta["f"], meta["batch_size"], meta["seed"], True, q))
+             for r in range(P)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=600) for _ in range(P)], key=lambda r: r["rank"])
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    got = [float(x) for x in re.findall(r"Epoch \d{5} \| Loss ([0-9.]+)", res[0]["stdout"])]
+    if P == 1:
+        np.testing.assert_allclose(got, meta["losses"], rtol=5e-5, atol=2e-4)
+        for i, w in enumerate(res[0]["weights"]):
+            assert rel_err(w, arrays["w1_%d" % i]) < 5e-4
+    else:   # replicas stay identical and training makes progress; losses differ by the log(f) constant
+        assert got[-1] < got[0]
+        for a, b in zip(res[0]["weights"], res[1]["weights"]):
+            np.testing.assert_array_equal(a, b)
