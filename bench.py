@@ -244,7 +244,8 @@ def main():
                                % (args.workload, n, nnz, L, f, world),
                    "n": n, "nnz": nnz, "f": f, "layers": L, "spmm_per_epoch": 2 * L,
                    "partition": "random" if world > 1 else "none", "exchange": exch.name if exch else "none",
-                   "xcd_swizzle": bool(K.base_flags & 2), "chunk": K.chunk},
+                   "xcd_slices": eng.A_loc.nslices, "chunk": K.chunk,
+                   "core_tile_fill_min": partition.CORE_TAU, "exchange_rounds": part.rounds},
         "roofline": roofline, "ms_per_epoch": ms_per_step, "loss": loss_val, "setup_s": setup_s,
     }
     if world > 1:

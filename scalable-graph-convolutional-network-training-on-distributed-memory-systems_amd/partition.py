@@ -23,7 +23,7 @@ results are bit-exact by construction (checked against the reference's maps).
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch
@@ -303,8 +303,6 @@ class Partition:
     halo_global: torch.Tensor   # int64 [n_halo] global ids of the halo slab rows
     send_global: torch.Tensor   # int64 [n_send] global ids of the send slab rows
     nnz_global: int = 0
-    symmetric: Optional[bool] = None
-    extra: Dict = field(default_factory=dict)
 
     @property
     def rounds(self) -> int:
