@@ -33,7 +33,6 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 import torch.nn as nn
 import torch.nn.functional as F
-from scipy.io import mmread
 
 from . import engine as _engine
 from . import ingest as _ingest
