@@ -124,11 +124,15 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    dev = torch.device("cuda:%d" % (local_rank % torch.cuda.device_count()))
+    dev = torch.device("cuda:%d" % (local_rank % torch.cuda.device_count()))   # (gloo dry-run: ranks share cuda:0)
     torch.cuda.set_device(dev)
+    backend = os.environ.get("PGCN_BENCH_BACKEND", "nccl")   # "gloo": dry-run of the N>1 path on one GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     synth, partition, engine, kernels, P = pkg("synth"), pkg("partition"), pkg("engine"), pkg("kernels"), pkg("PGCN")
     n, nnz_dir, f, L = synth.SHAPES[args.workload]
@@ -143,8 +147,8 @@ def main():
     if world > 1:   # all ranks must hold the same graph
         chk = torch.stack([row.sum(), col.sum(), (val.double().sum() * 1e6).long()]).double()
         lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        P._all_reduce(lo, dist.ReduceOp.MIN)
+        P._all_reduce(hi, dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "ranks generated different graphs"
     part = partition.build_partition(row, col, val, n, partvec, rank, world)
     del row, col, val
@@ -194,7 +198,7 @@ def main():
     timer.on = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        P._all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t)
     loss_val = float(loss)
 
@@ -250,7 +254,7 @@ def main():
     }
     if world > 1:
         vol = torch.tensor([eng.stats["send_volume"]], dtype=torch.float64, device=dev)
-        dist.all_reduce(vol)
+        P._all_reduce(vol)
         out["exchange_rows_total"] = float(vol)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(part, f, args.cpu_budget)
