@@ -132,6 +132,22 @@ int pgcn_spmm_core_f32(const int32_t *work, int64_t nwork, const int32_t *tile_p
                        float *partial_ws, int64_t partial_ws_elems, int64_t nslots_total,
                        pgcn_stream_t stream);
 
+/* Gather tasks and core pieces of one SpMM in ONE launch (512-thread workgroups): the work list
+ * interleaves, per XCD, blocks of <= 16 gather tasks with core pieces, so that the L2-bound and the
+ * LDS-bound work overlap on every CU.  work: 4 x int32 per workgroup {kind, a, b, 0}: kind 0 = gather
+ * tasks [a, a+b) of `tasks` (entry i of the list runs on XCD i % 8: give it tasks of slice i % 8),
+ * kind 1 = core piece a of `core_work` (the `work` array of pgcn_spmm_core_f32), kind 2 = nothing.
+ * Partial sums are left in partial_ws (combine with pgcn_spmm_fixup_f32); direct tasks write C.
+ * Supported: f <= 128, f % 4 == 0, values present, 16-byte aligned panels; else PGCN_EUNSUPPORTED
+ * (use the separate entry points).  Results are bit-identical to the three-launch path.        */
+int pgcn_spmm_fused_f32(const int32_t *work, int64_t nwork, const int32_t *col, const float *val,
+                        const int32_t *tasks, const int32_t *row_map, const int32_t *core_work,
+                        const int32_t *tile_panel, const int64_t *tile_base, const int32_t *seg_off,
+                        const int32_t *ccol, const float *cval, const float *B, int64_t ldb,
+                        int64_t ncols, float *C, int64_t ldc, int32_t f, float *partial_ws,
+                        int64_t partial_ws_elems, int64_t nslots_total, uint32_t flags,
+                        pgcn_stream_t stream);
+
 /* C[row] (+)= sum of the partial-sum slots listed for the row, in list order.
  * fix: 4 x int32 per row {row, begin, count, 0}; slot_ids (optional): the row's slots are
  * slot_ids[begin .. begin+count), or begin .. begin+count when slot_ids is NULL.        */

@@ -42,6 +42,8 @@ SIGNATURES = {
                                               _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),
     "pgcn_spmm_core_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp,
                                           _i64, _i64, _vp]),
+    "pgcn_spmm_fused_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                           _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),
     "pgcn_spmm_fixup_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _u32, _vp]),
     "pgcn_spmm_plan_host": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp,
                                            ctypes.POINTER(_i64), ctypes.POINTER(_i64),

@@ -27,14 +27,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "pgcn_device.h"
-#include "pgcn_internal.h"
+#include "pgcn_spmm_bodies.h"
 
 namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * 64;
-constexpr int kUnroll = 8;
 
 __device__ __forceinline__ int64_t swizzle_block(int64_t b, int64_t nb, bool on) {
     if (!on) return b;
@@ -47,28 +45,6 @@ __device__ __forceinline__ int64_t swizzle_block(int64_t b, int64_t nb, bool on)
 
 struct SliceSeg { int64_t v[PGCN_MAX_SLICES + 1]; };
 
-template <int VEC>
-__device__ __forceinline__ void vfma(float (&acc)[VEC], float w, const float (&x)[VEC]) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, x[v], acc[v]);
-}
-
-// Row load of B.  OFF32: the caller guarantees that every byte offset into B fits 32 bits,
-// so the address is (uniform 64-bit base) + (32-bit lane offset): one v_mul_lo + v_add per
-// load and an SGPR base instead of a 64-bit multiply-add and two address VGPRs per load.
-template <int VEC, bool OFF32>
-__device__ __forceinline__ void load_row(float (&x)[VEC], const float *B, uint32_t lane_byte_off,
-                                         int32_t c, int64_t ldb) {
-    const float *p;
-    if constexpr (OFF32) {
-        const uint32_t off = (uint32_t)c * (uint32_t)(ldb * 4) + lane_byte_off;
-        p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
-    } else {
-        p = B + (int64_t)c * ldb + (lane_byte_off >> 2);
-    }
-    vload<VEC>(x, p);   // default cache policy: non-temporal gathers were measured 1.7x slower (r01)
-}
-
 // tasks: int4 {kbeg low 32, kbeg high 32, length, dst}; kbeg = absolute offset of the task's
 // first entry in col/val; dst >= 0: partial-sum slot, dst < 0: write row ~dst of C directly.
 template <int LPR, int VEC, bool HAS_VAL, bool OFF32>
@@ -79,12 +55,10 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
     float *__restrict__ C, int64_t ldc, int32_t f, float *__restrict__ partial,
     int64_t nblocks, uint32_t flags, int32_t nslices, SliceSeg seg) {
     constexpr int G = 64 / LPR;
-    constexpr int U = (LPR < kUnroll) ? LPR : kUnroll;   // gathers in flight per batch
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int grp = lane / LPR;
     const int sub = lane % LPR;
-    const int gbase = grp * LPR;
 
     int64_t tid;
     if (nslices > 1) {
@@ -99,9 +73,7 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
         tid = (bid * kWavesPerBlock + wave) * G + grp;
     }
     const int fcol = (blockIdx.y * LPR + sub) * VEC;  // first feature owned by this lane
-    const bool fact = fcol < f;
     const bool tact = tid < ntasks;
-    const uint32_t lane_off = (uint32_t)fcol * 4u;
 
     int32_t len = 0, dst = -1;
     int64_t kbeg = 0;
@@ -118,100 +90,9 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
         }
     }
 
-    float acc[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-
-    // (col,val) pairs: one per lane, streamed once -> non-temporal.  The loads are
-    // UNCONDITIONAL (index clamped into the task; an empty / inactive group reads a
-    // harmless valid word of rowptr) so that the prefetch of the next LPR pairs stays in
-    // flight behind the gathers instead of being fenced at a branch join.
-    const int32_t *cp = (len > 0) ? col + kbeg : reinterpret_cast<const int32_t *>(rowptr);
-    const float *vp = (len > 0) ? val + kbeg : reinterpret_cast<const float *>(rowptr);
-    const int last = (len > 0) ? len - 1 : 0;
-    int32_t nc;
-    float nv = 1.f;
-    {
-        const int e = (sub < last) ? sub : last;
-        nc = __builtin_nontemporal_load(cp + e);
-        if constexpr (HAS_VAL) nv = __builtin_nontemporal_load(vp + e);
-    }
-    // The wave's current LPR-batch of pairs lives in LDS (512 B per wave): a group
-    // broadcasts entry k to its lanes with ONE ds_read_b128 per two entries (all lanes of
-    // a group read the same address = conflict-free broadcast), instead of two
-    // ds_bpermute per entry -- the LDS pipe is shared by the whole CU and was the
-    // co-bottleneck of the gather loop.  Written and read by the same wave only, LDS
-    // operations of a wave execute in order => no workgroup barrier.
     __shared__ float2 meta_lds[kWavesPerBlock][64];
-    float2 *mrow = meta_lds[wave];
-    for (int base = 0; __any(base < len); base += LPR) {
-        __builtin_amdgcn_wave_barrier();
-        mrow[lane] = make_float2(__int_as_float(len > 0 ? nc : 0), nv);
-        __builtin_amdgcn_wave_barrier();
-        {
-            int e = base + LPR + sub;
-            e = (e < last) ? e : last;
-            nc = __builtin_nontemporal_load(cp + e);
-            if constexpr (HAS_VAL) nv = __builtin_nontemporal_load(vp + e);
-        }
-        const int cnt = len - base;  // entries left for this group (may be <= 0)
-        const float2 *mg = mrow + gbase;
-#pragma unroll
-        for (int k = 0; k < LPR; k += U) {
-            if (!__any(k < cnt)) break;
-            // U independent row loads, all unpredicated and issued back to back (a branch per
-            // load serialises them behind the broadcasts).  In a ragged batch the surplus
-            // slots re-read the task's LAST referenced row (the clamped pair parked above; row 0
-            // for an empty group) and are zeroed by a select before the FMA, so no row the task
-            // does not reference is ever combined into the result (no 0 * Inf).
-            const bool full = __all(k + U <= cnt);
-            int32_t c[U];
-            float w[U];
-            float x[U][VEC];
-            if constexpr (U >= 2) {
-#pragma unroll
-                for (int u = 0; u < U; u += 2) {
-                    const float4 m = *reinterpret_cast<const float4 *>(mg + k + u);
-                    c[u] = __float_as_int(m.x); w[u] = m.y;
-                    c[u + 1] = __float_as_int(m.z); w[u + 1] = m.w;
-                }
-            } else {
-                const float2 m = mg[k];
-                c[0] = __float_as_int(m.x); w[0] = m.y;
-            }
-            if (fact) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) load_row<VEC, OFF32>(x[u], B, lane_off, c[u], ldb);
-                if (!full) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const bool keep = k + u < cnt;
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) x[u][v] = keep ? x[u][v] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) vfma<VEC>(acc, w[u], x[u]);
-            }
-        }
-    }
-
-    if (tact && fact) {
-        if (dst >= 0) {
-            vstore<VEC>(partial + (int64_t)dst * f + fcol, acc);
-        } else {
-            const int32_t row = ~dst;
-            const int64_t orow = row_map ? row_map[row] : row;
-            float *c = C + orow * ldc + fcol;
-            if (flags & PGCN_SPMM_ACCUMULATE) {
-                float old[VEC];
-                vload<VEC>(old, c);
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[v] += old[v];
-            }
-            vstore<VEC>(c, acc);
-        }
-    }
+    pgcn_bodies::gather_task_body<LPR, VEC, HAS_VAL, OFF32>(tact, kbeg, len, dst, rowptr, col, val, row_map, B, ldb,
+                                                          C, ldc, f, partial, flags, fcol, meta_lds[wave]);
 }
 
 // fix: int4 {row, first slot, #segments, unused}; sums the segments of a split

@@ -24,38 +24,14 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "pgcn_device.h"
-#include "pgcn_internal.h"
+#include "pgcn_spmm_bodies.h"
 
 namespace {
 
-constexpr int TR = PGCN_CORE_TR;   // rows per tile
-constexpr int TC = PGCN_CORE_TC;   // columns per panel
-constexpr int kCoreThreads = 512;
-constexpr int NG = kCoreThreads / 32;   // groups per workgroup
-constexpr int RW = TR / NG;             // rows per group
-#ifndef PGCN_CORE_BATCH
-#define PGCN_CORE_BATCH 4
-#endif
-constexpr int CB = PGCN_CORE_BATCH;     // LDS row reads in flight per batch
-#ifndef PGCN_CORE_STAGE_BATCH
-#define PGCN_CORE_STAGE_BATCH 4
-#endif
-static_assert(TR % NG == 0, "tile rows must divide over the groups");
+using namespace pgcn_bodies;
 
-template <int VEC>
-__device__ __forceinline__ void lds_row(float (&x)[VEC], const float *panel, int c, int sub) {
-    vload<VEC>(x, panel + (c * 32 + sub) * VEC);
-}
-
-// work: int4 {tile row index, first dense tile, one-past-last dense tile, first slot}
-//
-// Latency structure: the (col,val) stream of a segment is the only HBM-latency-bound load in
-// the loop, so (1) the first 32 pairs of ALL eight segments of a group are requested before
-// the panel is staged (they land behind the staging copy and the barrier), (2) longer
-// segments prefetch one batch ahead.  Ragged batches are padded, not predicated: a padding lane parks the pair
-// (column TC, value 0) and column TC of the panel is an all-zero row, so every batch runs
-// the branch-free 8-entry body and 0 * 0 never meets a user value.
+// work: int4 {tile row index, first dense tile, one-past-last dense tile, first slot}; the body lives in
+// pgcn_spmm_bodies.h (core_piece_body) so that the fused kernel can run it too.
 template <int VEC>
 __global__ __launch_bounds__(kCoreThreads, 4) void spmm_core_kernel(
     const int4 *__restrict__ work, const int32_t *__restrict__ tile_panel,
@@ -63,152 +39,8 @@ __global__ __launch_bounds__(kCoreThreads, 4) void spmm_core_kernel(
     const int32_t *__restrict__ ccol, const float *__restrict__ cval, const float *__restrict__ B,
     int64_t ldb, int64_t ncols, int32_t f, float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *panel = reinterpret_cast<float *>(smem);                                        // (TC+1) x 32 x VEC
-    float2 *mpark = reinterpret_cast<float2 *>(smem + (size_t)(TC + 1) * 32 * VEC * 4);     // per wave 64 pairs
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int sub = lane & 31;
-    const int gbase = lane & 32;
-    const int group = threadIdx.x >> 5;
-    const int4 wk = work[blockIdx.x];
-    const int fcol0 = blockIdx.y * 32 * VEC;
-    const int fcol = fcol0 + sub * VEC;
-    const bool fact = fcol < f;
-    float2 *mrow = mpark + wave * 64;
-    const float2 *mg = mrow + gbase;
-
-    float acc[RW][VEC];
-#pragma unroll
-    for (int j = 0; j < RW; ++j)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[j][v] = 0.f;
-
-    if (threadIdx.x < 32) {   // the all-zero padding row
-        float z[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) z[v] = 0.f;
-        vstore<VEC>(panel + ((size_t)TC * 32 + threadIdx.x) * VEC, z);
-    }
-
-    for (int k = wk.y; k < wk.z; ++k) {
-        const int64_t col0 = (int64_t)tile_panel[k] * TC;
-        const int64_t base = tile_base[k];
-        const int32_t *cb = ccol + base;   // uniform per workgroup
-        const float *vb = cval + base;
-        int32_t bound[RW + 1];
-        {
-            const int32_t *so = seg_off + (int64_t)k * (TR + 1) + group * RW;
-#pragma unroll
-            for (int j = 0; j <= RW; ++j) bound[j] = so[j];
-        }
-        // (1) first batch of every segment of this group
-        int32_t pc[RW];
-        float pv[RW];
-#pragma unroll
-        for (int j = 0; j < RW; ++j) {
-            const int len = bound[j + 1] - bound[j];
-            const int e = (sub < len - 1) ? sub : len - 1;
-            const uint32_t idx = (len > 0) ? (uint32_t)(bound[j] + e) : 0u;   // 32-bit lane offset, uniform base
-            pc[j] = __builtin_nontemporal_load(cb + idx);
-            pv[j] = __builtin_nontemporal_load(vb + idx);
-        }
-        __syncthreads();   // everyone is done reading the previous panel
-        // stage B[col0 .. col0+TC) x [fcol0 .. fcol0+32*VEC) : one contiguous-row copy.  All
-        // loads are issued before the first LDS write (clamped addresses, no branches: a
-        // per-iteration bounds branch serialises the eight round trips); out-of-range
-        // rows / features are zeroed by a select.
-        {
-            constexpr int NIT = TC * 32 / kCoreThreads;   // 8 row-vectors per thread
-            constexpr int HB = PGCN_CORE_STAGE_BATCH;     // loads in flight per thread
-            const int64_t lastrow = ncols - 1;
-            const int lastf = f - VEC;
-#pragma unroll
-            for (int h = 0; h < NIT; h += HB) {
-                float xs[HB][VEC];
-#pragma unroll
-                for (int it = 0; it < HB; ++it) {
-                    const int idx = (h + it) * kCoreThreads + threadIdx.x;
-                    const int r = idx >> 5, s = idx & 31;
-                    const int64_t rr = (col0 + r < ncols) ? col0 + r : lastrow;
-                    const int cc = (fcol0 + s * VEC < f) ? fcol0 + s * VEC : lastf;
-                    vload<VEC>(xs[it], B + rr * ldb + cc);
-                }
-#pragma unroll
-                for (int it = 0; it < HB; ++it) {
-                    const int idx = (h + it) * kCoreThreads + threadIdx.x;
-                    const int r = idx >> 5, s = idx & 31;
-                    const bool ok = (col0 + r < ncols) && (fcol0 + s * VEC < f);
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) xs[it][v] = ok ? xs[it][v] : 0.f;
-                    vstore<VEC>(panel + (size_t)idx * VEC, xs[it]);
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < RW; ++j) {
-            const int len = bound[j + 1] - bound[j];
-            int32_t cur_c = pc[j];
-            float cur_v = pv[j];
-            for (int b = 0; __any(b < len); b += 32) {
-                const int cnt = len - b;   // entries left in this group's segment (may be <= 0)
-                int32_t nx_c = 0;
-                float nx_v = 0.f;
-                if (__any(b + 32 < len)) {   // (2) one batch ahead
-                    int e = b + 32 + sub;
-                    e = (e < len - 1) ? e : len - 1;
-                    const uint32_t idx = (len > 0) ? (uint32_t)(bound[j] + e) : 0u;
-                    nx_c = __builtin_nontemporal_load(cb + idx);
-                    nx_v = __builtin_nontemporal_load(vb + idx);
-                }
-                const bool valid = sub < cnt;
-                __builtin_amdgcn_wave_barrier();
-                mrow[lane] = make_float2(__int_as_float(valid ? cur_c : TC), valid ? cur_v : 0.f);
-                __builtin_amdgcn_wave_barrier();
-                // software-pipelined: the pairs of batch k4+CB are read while batch k4 computes, so a
-                // batch costs one LDS round trip (rows) instead of two (pairs, then rows).
-                float4 m[CB / 2];
-#pragma unroll
-                for (int u = 0; u < CB / 2; ++u) m[u] = *reinterpret_cast<const float4 *>(mg + 2 * u);
-#pragma unroll
-                for (int k4 = 0; k4 < 32; k4 += CB) {
-                    if (!__any(k4 < cnt)) break;
-                    float4 mn[CB / 2];
-                    if (k4 + CB < 32) {
-#pragma unroll
-                        for (int u = 0; u < CB / 2; ++u) mn[u] = *reinterpret_cast<const float4 *>(mg + k4 + CB + 2 * u);
-                    }
-                    float x[CB][VEC];
-#pragma unroll
-                    for (int u = 0; u < CB / 2; ++u) {
-                        lds_row<VEC>(x[2 * u], panel, __float_as_int(m[u].x), sub);
-                        lds_row<VEC>(x[2 * u + 1], panel, __float_as_int(m[u].z), sub);
-                    }
-#pragma unroll
-                    for (int u = 0; u < CB / 2; ++u) {
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[j][v] = fmaf(m[u].y, x[2 * u][v], acc[j][v]);
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[j][v] = fmaf(m[u].w, x[2 * u + 1][v], acc[j][v]);
-                    }
-                    if (k4 + CB < 32) {
-#pragma unroll
-                        for (int u = 0; u < CB / 2; ++u) m[u] = mn[u];
-                    }
-                }
-                cur_c = nx_c;
-                cur_v = nx_v;
-            }
-        }
-    }
-    if (fact) {
-#pragma unroll
-        for (int j = 0; j < RW; ++j) {
-            const int rit = j * NG + group;   // row inside the tile
-            vstore<VEC>(partial + ((int64_t)wk.w + rit) * f + fcol, acc[j]);
-        }
-    }
+    pgcn_bodies::core_piece_body<VEC>(work[blockIdx.x], tile_panel, tile_base, seg_off, ccol, cval, B, ldb, ncols, f,
+                                      partial, smem, blockIdx.y * 32 * VEC);
 }
 
 // fix: int4 {row, begin, count, 0}.  slot_ids != NULL: the slots of the row are

@@ -51,6 +51,7 @@ class DeviceCSR:
     fix_all: Optional[torch.Tensor] = None    # int32 [nfix_all,4] combined fix list (core + gather slots)
     slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
     nslots_total: int = 0
+    fused_work: Optional[torch.Tensor] = None  # int32 [nwork,4] unified work list (pgcn_spmm_fused_f32)
     launch_cache: dict = None                 # bound C-ABI calls per (ldb, ldc, f, accumulate)
 
     def __post_init__(self):
@@ -114,6 +115,41 @@ def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarr
     return tasks, fix[:nf.value], int(ns.value), seg
 
 
+def fused_work_list(seg, nslices: int, ntasks: int, npieces: int, gb: int = 16, nxcd: int = 8) -> np.ndarray:
+    """Unified work list of pgcn_spmm_fused_f32: entry i runs on XCD i % 8.  Queue x holds the
+    gather blocks (<= gb tasks, never crossing a slice) of slice x -- all slices round-robin when
+    the plan is not 8-sliced -- and core pieces x, x+8, ...; inside a queue the two kinds are
+    spread evenly so that a CU tends to host one workgroup of each.  Both inputs come longest
+    first (LPT), the merge keeps that order within a kind."""
+    queues_g = [[] for _ in range(nxcd)]
+    bounds = [0, ntasks] if seg is None else [int(seg[i]) for i in range(nslices + 1)]
+    k = 0
+    for sl in range(len(bounds) - 1):
+        beg = np.arange(bounds[sl], bounds[sl + 1], gb, dtype=np.int64)
+        cnt = np.minimum(beg + gb, bounds[sl + 1]) - beg
+        blk = np.stack([np.zeros_like(beg), beg, cnt, np.zeros_like(beg)], 1)
+        if len(bounds) - 1 == nxcd:
+            queues_g[sl].append(blk)
+        else:
+            for j in range(blk.shape[0]):
+                queues_g[(k + j) % nxcd].append(blk[j:j + 1])
+            k += blk.shape[0]
+    out = []
+    for x in range(nxcd):
+        g = np.concatenate(queues_g[x]) if queues_g[x] else np.zeros((0, 4), np.int64)
+        pc = np.arange(x, npieces, nxcd, dtype=np.int64)
+        c = np.stack([np.ones_like(pc), pc, np.zeros_like(pc), np.zeros_like(pc)], 1)
+        key = np.concatenate([(np.arange(g.shape[0]) + 0.5) / max(g.shape[0], 1),
+                              (np.arange(c.shape[0]) + 0.25) / max(c.shape[0], 1)])
+        out.append(np.concatenate([g, c])[np.argsort(key, kind="stable")])
+    T = max(q.shape[0] for q in out)
+    work = np.zeros((T, nxcd, 4), dtype=np.int32)
+    work[:, :, 0] = 2
+    for x, q in enumerate(out):
+        work[:q.shape[0], x] = q
+    return work.reshape(T * nxcd, 4)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -141,6 +177,9 @@ class HipKernels:
         # pipes of a CU: optionally run them on two streams so the hardware can co-schedule them
         self.core_overlap = os.environ.get("PGCN_CORE_OVERLAP", "0") != "0"
         self._side = None
+        # one launch for gather tasks + core pieces (pgcn_spmm_fused_f32) instead of two
+        self.fused = os.environ.get("PGCN_SPMM_FUSED", "0") != "0"
+        self.fused_gb = int(os.environ.get("PGCN_FUSED_GB", "16"))
 
     # -- data placement -------------------------------------------------
     def prepare(self, csr: HostCSR, pattern_only: bool = False) -> DeviceCSR:
@@ -204,6 +243,9 @@ class HipKernels:
         d.slot_ids = slots.to(torch.int32).to(dev).contiguous()
         d.nslots_total = ns_rem + hc.nslots
         d.nnz = csr.nnz
+        if d.ntasks and d.val is not None:
+            fw = fused_work_list(d.seg, d.nslices, d.ntasks, hc.npieces, gb=self.fused_gb)
+            d.fused_work = torch.from_numpy(fw).to(dev).contiguous()
 
     # -- kernels ----------------------------------------------------------
     def _stream(self) -> int:
@@ -226,7 +268,7 @@ class HipKernels:
             raise _lib.PgcnError("B and C must be fp32 CUDA matrices")
         if B.shape[0] < A.ncols or (A.row_map is None and C.shape[0] < A.nrows):
             raise _lib.PgcnError("B or C has too few rows")
-        key = (B.stride(0), C.stride(0), B.shape[1], accumulate, C.shape[1], B.stride(1), C.stride(1))
+        key = (B.stride(0), C.stride(0), B.shape[1], accumulate, C.shape[1], B.stride(1), C.stride(1), self.fused)
         fn = A.launch_cache.get(key)
         if fn is None:
             fn = self._bind_spmm(A, B, C, accumulate)
@@ -284,6 +326,19 @@ class HipKernels:
         fixp, nfa, slots = A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr()
         gflags, fflags = flags | _lib.SPMM_NO_FIXUP, flags & _lib.SPMM_ACCUMULATE
         overlap = self.core_overlap and ntasks
+        if (self.fused and A.fused_work is not None and f <= 128 and f % 4 == 0 and ldb % 4 == 0 and ldc % 4 == 0
+                and B.data_ptr() % 16 == 0 and C.data_ptr() % 16 == 0):
+            fw, nfw = A.fused_work.data_ptr(), A.fused_work.shape[0]
+
+            def fused(B, C):
+                b, c, s = B.data_ptr(), C.data_ptr(), stream()
+                if (b | c) & 15:
+                    return hybrid(B, C)
+                check(lib.pgcn_spmm_fused_f32(fw, nfw, col, val, tasks, rmap, cw, ctp, ctb, cso, ccol, cval, b, ldb,
+                                              ncols, c, ldc, f, ws, ws_n, nst, gflags, s), "pgcn_spmm_fused_f32")
+                check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, c, ldc, f, fflags, s), "pgcn_spmm_fixup_f32")
+        else:
+            fused = None
 
         def hybrid(B, C):
             b, c, s = B.data_ptr(), C.data_ptr(), stream()
@@ -306,7 +361,7 @@ class HipKernels:
                 done.record(self._side)
                 torch.cuda.current_stream(self.device).wait_event(done)
             check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, c, ldc, f, fflags, s), "pgcn_spmm_fixup_f32")
-        return hybrid
+        return fused or hybrid
 
     def gather_rows(self, H: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         n = idx.numel()

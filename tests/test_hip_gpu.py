@@ -159,6 +159,21 @@ def test_spmm_dense_core_lds_kernel(K, dev, f, nslices):
         C4 = torch.empty((n, f), device=dev)
         K.spmm(d, torch.from_numpy(B2).to(dev), C4)
         assert np.isfinite(C4.cpu().numpy()).all()
+    # the one-launch variant (gather tasks + core pieces co-scheduled) is bit-identical
+    assert d.fused_work is not None
+    kinds = d.fused_work[:, 0].cpu().numpy()
+    assert (kinds == 1).sum() == d.core.npieces
+    assert int(d.fused_work[:, 2].sum()) == d.ntasks
+    was = K.fused
+    try:
+        K.fused = True
+        C5 = torch.full((n, f), float("nan"), device=dev)
+        K.spmm(d, Bd, C5)
+        C6 = torch.from_numpy(base).to(dev)
+        K.spmm(d, Bd, C6, accumulate=True)
+    finally:
+        K.fused = was
+    assert torch.equal(C5, C) and torch.equal(C6, C3)
 
 
 def test_spmm_edge_cases(K, dev):

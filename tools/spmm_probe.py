@@ -56,6 +56,9 @@ def main():
     for name in names:
         # name: s<slices>[g<groups>]c<chunk>[x][k[tau]] (g = column groups; x = xcd swizzle for
         # unsliced; k = degree sort + LDS core)
+        fused = name.endswith("F")
+        name0 = name
+        name = name.rstrip("F")
         head = name[1:name.index("c")]
         G = None
         if "g" in head:
@@ -78,14 +81,16 @@ def main():
         else:
             h = partition.csr_from_coo(row, col, val, n, n, nslices=S, ngroups=G)
         K.chunk = chunk
-        d = K.prepare(h)
+        d = prepared.get(name)
+        if d is None:
+            d = prepared[name] = K.prepare(h)
         for tag, L in libs.items():
-            variants[name + ("@" + tag if tag else "")] = (d, sw, L)
+            variants[name0 + ("@" + tag if tag else "")] = (d, sw, L, fused)
     alg = 8 * nnz + 8 * (n + 1) + 2 * 4 * f * n
     C = torch.empty(n, f, device=dev)
 
     def run(name):
-        d, sw, L = variants[name]
+        d, sw, L, K.fused = variants[name]
         K.base_flags = 2 if sw else 0
         K.lib = L
         K.spmm(d, B, C)
