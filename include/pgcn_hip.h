@@ -65,6 +65,27 @@ int pgcn_mtx_info(const char *path, int64_t out[4]);
 int pgcn_mtx_read_coo(const char *path, int64_t cap, int64_t *row, int64_t *col, float *val,
                       int64_t *nnz_out, int32_t nthreads);
 
+/* ---- 1D partition, host side (multi-threaded) ----------------------------------------
+ * pgcn_build_comm_maps replaces compute_communication_maps(A, partvec, rank, size)
+ * GPU/PGCN.py:37-51.  (row, col) are 0-based coordinates of stored entries -- all of them, as the
+ * reference scans, or any subset that holds every entry with one end on `rank`.  For every peer
+ * q != rank:  send ids [send_off[q], send_off[q+1]) = sorted unique columns j owned by `rank` that
+ * appear in a row owned by q (PGCN.py:44-47);  recv ids [recv_off[q], recv_off[q+1]) = sorted
+ * unique columns owned by q that appear in a row owned by `rank` (:41-43).  The own-rank segments
+ * are empty (:49-50).  Offsets arrays have nranks+1 entries.  Sizing call: pass send_ids =
+ * recv_ids = NULL, read the totals from send_off[nranks] / recv_off[nranks].
+ *
+ * pgcn_load_mtx_partition replaces mmread (:171) + get_partitiont_of_adjacency_matrix (:53-64):
+ * the stored entries of the rows owned by `rank`, GLOBAL 0-based coordinates, file order.
+ * Sizing call: row = col = val = NULL.                                                        */
+int pgcn_build_comm_maps(const int64_t *row, const int64_t *col, int64_t nnz, const int32_t *partvec,
+                         int64_t n, int32_t rank, int32_t nranks, int64_t *send_off,
+                         int64_t *recv_off, int64_t *send_ids, int64_t cap_send, int64_t *recv_ids,
+                         int64_t cap_recv, int32_t nthreads);
+int pgcn_load_mtx_partition(const char *path, const int32_t *partvec, int64_t n, int32_t rank,
+                            int64_t cap, int64_t *row, int64_t *col, float *val, int64_t *nnz_out,
+                            int32_t nthreads);
+
 /* ---- CSR SpMM ------------------------------------------------------------
  * C[nrows x f] (+)= A[nrows x *] . B[* x f]
  * replaces  torch.sparse.mm(A, H)            GPU/PGCN.py:127

@@ -37,6 +37,9 @@ SIGNATURES = {
     "pgcn_device_info": (ctypes.c_int, [_i32, ctypes.POINTER(_i64)]),
     "pgcn_mtx_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64)]),
     "pgcn_mtx_read_coo": (ctypes.c_int, [ctypes.c_char_p, _i64, _vp, _vp, _vp, ctypes.POINTER(_i64), _i32]),
+    "pgcn_build_comm_maps": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i32]),
+    "pgcn_load_mtx_partition": (ctypes.c_int, [ctypes.c_char_p, _vp, _i64, _i32, _i64, _vp, _vp, _vp,
+                                               ctypes.POINTER(_i64), _i32]),
     "pgcn_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _u32, _vp]),
     "pgcn_spmm_csr_plan_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp,
                                               _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),

@@ -18,8 +18,9 @@ done
 "$HIPCC" $FLAGS -c "$HERE/pgcn_core.cpp" -o "$OUT/pgcn_core.o" & pids+=($!)
 "$HIPCC" $FLAGS -c "$HERE/pgcn_exchange.cpp" -o "$OUT/pgcn_exchange.o" & pids+=($!)
 "$HIPCC" $FLAGS -c "$HERE/pgcn_mtx.cpp" -o "$OUT/pgcn_mtx.o" & pids+=($!)
+"$HIPCC" $FLAGS -c "$HERE/pgcn_maps.cpp" -o "$OUT/pgcn_maps.o" & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpgcn_hip.so" \
-  "$OUT/pgcn_spmm.o" "$OUT/pgcn_spmm_core.o" "$OUT/pgcn_spmm_fused.o" "$OUT/pgcn_rows.o" "$OUT/pgcn_core.o" "$OUT/pgcn_exchange.o" "$OUT/pgcn_mtx.o" \
+  "$OUT/pgcn_spmm.o" "$OUT/pgcn_spmm_core.o" "$OUT/pgcn_spmm_fused.o" "$OUT/pgcn_rows.o" "$OUT/pgcn_core.o" "$OUT/pgcn_exchange.o" "$OUT/pgcn_mtx.o" "$OUT/pgcn_maps.o" \
   -L"$ROCM/lib" -lrccl -lpthread
 echo "built $OUT/libpgcn_hip.so"

@@ -42,3 +42,46 @@ def mmread(path: str, nthreads: int = 0) -> sp.coo_matrix:
                                    val.ctypes.data, ctypes.byref(n), nthreads), "pgcn_mtx_read_coo")
     k = n.value
     return sp.coo_matrix((val[:k], (row[:k], col[:k])), shape=(out[0], out[1]))
+
+
+def comm_maps(row, col, partvec, rank: int, nranks: int, nthreads: int = 0):
+    """compute_communication_maps (GPU/PGCN.py:37-51) on the native builder: returns
+    (send_map, recv_map), dicts peer -> ascending int64 numpy array of GLOBAL ids, own rank
+    absent.  ``row``/``col``: 0-based coordinates of the stored entries (every entry, or at
+    least every entry with one end owned by ``rank``)."""
+    L = _lib.lib()
+    row = np.ascontiguousarray(row, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int64)
+    pv = np.ascontiguousarray(partvec, dtype=np.int32)
+    if row.shape != col.shape or row.ndim != 1:
+        raise ValueError("row and col must be 1-D arrays of the same length")
+    so = np.zeros(nranks + 1, dtype=np.int64)
+    ro = np.zeros(nranks + 1, dtype=np.int64)
+    args = (row.ctypes.data, col.ctypes.data, row.shape[0], pv.ctypes.data, pv.shape[0], rank, nranks,
+            so.ctypes.data, ro.ctypes.data)
+    _lib.check(L.pgcn_build_comm_maps(*args, None, 0, None, 0, nthreads), "pgcn_build_comm_maps")
+    sid = np.empty(max(int(so[-1]), 1), dtype=np.int64)
+    rid = np.empty(max(int(ro[-1]), 1), dtype=np.int64)
+    _lib.check(L.pgcn_build_comm_maps(*args, sid.ctypes.data, sid.shape[0], rid.ctypes.data, rid.shape[0], nthreads),
+               "pgcn_build_comm_maps")
+    send = {q: sid[so[q]:so[q + 1]].copy() for q in range(nranks) if q != rank}
+    recv = {q: rid[ro[q]:ro[q + 1]].copy() for q in range(nranks) if q != rank}
+    return send, recv
+
+
+def load_partition(path: str, partvec, rank: int, nthreads: int = 0) -> sp.coo_matrix:
+    """mmread + get_partitiont_of_adjacency_matrix (GPU/PGCN.py:171,53-64): the rows of the
+    matrix owned by ``rank`` as an n x n COO matrix (global coordinates, file order)."""
+    L = _lib.lib()
+    pv = np.ascontiguousarray(partvec, dtype=np.int32)
+    info = mtx_info(path)
+    n = ctypes.c_int64()
+    a = (os.fsencode(path), pv.ctypes.data, pv.shape[0], rank)
+    _lib.check(L.pgcn_load_mtx_partition(*a, 0, None, None, None, ctypes.byref(n), nthreads), "pgcn_load_mtx_partition")
+    k = n.value
+    row = np.empty(max(k, 1), dtype=np.int64)
+    col = np.empty(max(k, 1), dtype=np.int64)
+    val = np.empty(max(k, 1), dtype=np.float32)
+    _lib.check(L.pgcn_load_mtx_partition(*a, k, row.ctypes.data, col.ctypes.data, val.ctypes.data, ctypes.byref(n),
+                                         nthreads), "pgcn_load_mtx_partition")
+    return sp.coo_matrix((val[:k], (row[:k], col[:k])), shape=(info["nrows"], info["ncols"]))

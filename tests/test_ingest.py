@@ -83,3 +83,77 @@ def test_errors(tmp_path):
     p = str(tmp_path / "dense.mtx")
     mmwrite(p, np.arange(6.0).reshape(2, 3))
     _same(ingest.mmread(p), sp.coo_matrix(sp_mmread(p)))
+
+
+# ---- native comm-map builder / partition loader against the reference's own maps --------------
+from conftest import SPMM_CASES, golden, read_partvec  # noqa: E402
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES)
+def test_native_comm_maps_match_reference(name, mtx, pv, P, threads):
+    """pgcn_build_comm_maps == compute_communication_maps of GPU/PGCN.py:37-51 (golden files made
+    by running the reference) -- integer work, exact."""
+    ingest = pkg("ingest")
+    arrays, meta = golden(name)
+    A = sp.coo_matrix(sp_mmread(gpath(mtx)))
+    part = np.array(read_partvec(gpath(pv)), dtype=np.int32)
+    for r in range(P):
+        send, recv = ingest.comm_maps(A.row, A.col, part, r, P, nthreads=threads)
+        assert sorted(send) == sorted(recv) == [q for q in range(P) if q != r]
+        for q in send:
+            np.testing.assert_array_equal(send[q], arrays["send_%d_%d" % (r, q)])
+            np.testing.assert_array_equal(recv[q], arrays["recv_%d_%d" % (r, q)])
+        # entries touching rank r are enough (what a rank holding only its rows + columns passes)
+        touch = (part[A.row] == r) | (part[A.col] == r)
+        s2, r2 = ingest.comm_maps(A.row[touch], A.col[touch], part, r, P, nthreads=threads)
+        for q in send:
+            np.testing.assert_array_equal(s2[q], send[q])
+            np.testing.assert_array_equal(r2[q], recv[q])
+
+
+def test_native_comm_maps_large_random_vs_sets():
+    ingest = pkg("ingest")
+    rng = np.random.default_rng(5)
+    n, nnz, P = 20000, 600000, 5                 # several 64-bit words per bit-map row, 4+ threads
+    row, col = rng.integers(0, n, nnz), rng.integers(0, n, nnz)
+    part = rng.integers(0, P, n).astype(np.int32)
+    for r in (0, 3):
+        send, recv = ingest.comm_maps(row, col, part, r, P)
+        pr, pc = part[row], part[col]
+        for q in range(P):
+            if q == r:
+                continue
+            np.testing.assert_array_equal(recv[q], np.unique(col[(pr == r) & (pc == q)]))
+            np.testing.assert_array_equal(send[q], np.unique(col[(pc == r) & (pr == q)]))
+
+
+def test_native_comm_maps_edge_cases_and_errors():
+    ingest, _lib = pkg("ingest"), pkg("_lib")
+    e = np.zeros(0, dtype=np.int64)
+    send, recv = ingest.comm_maps(e, e, np.zeros(4, np.int32), 0, 1)       # P = 1: no peers
+    assert send == {} and recv == {}
+    send, recv = ingest.comm_maps(e, e, np.array([0, 1, 1], np.int32), 1, 2)  # no entries
+    assert send[0].size == 0 and recv[0].size == 0
+    with pytest.raises(_lib.PgcnError):
+        ingest.comm_maps(np.array([0]), np.array([7]), np.array([0, 1], np.int32), 0, 2)   # index out of range
+    with pytest.raises(_lib.PgcnError):
+        ingest.comm_maps(np.array([0]), np.array([1]), np.array([0, 2], np.int32), 0, 2)   # part id out of range
+    with pytest.raises(_lib.PgcnError):
+        ingest.comm_maps(np.array([0]), np.array([1]), np.array([0, 1], np.int32), 2, 2)   # rank out of range
+
+
+@pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES[:1] + SPMM_CASES[4:5] + SPMM_CASES[7:8])
+def test_native_partition_loader(name, mtx, pv, P):
+    """pgcn_load_mtx_partition == mmread + the np.in1d row mask of GPU/PGCN.py:53-64."""
+    ingest, _lib = pkg("ingest"), pkg("_lib")
+    _, meta = golden(name)
+    A = sp.coo_matrix(sp_mmread(gpath(mtx)))
+    part = np.array(read_partvec(gpath(pv)), dtype=np.int32)
+    for r in range(P):
+        got = ingest.load_partition(gpath(mtx), part, r)
+        keep = part[A.row] == r
+        _same(got, sp.coo_matrix((A.data[keep], (A.row[keep], A.col[keep])), shape=A.shape))
+        assert got.nnz == meta["ranks"][r]["nnz_local"]
+    with pytest.raises(_lib.PgcnError):
+        ingest.load_partition(gpath(mtx), part[:-1], 0)                   # part vector length mismatch
