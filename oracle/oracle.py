@@ -383,3 +383,147 @@ def pgcn_train_np(A: sp.spmatrix, part: Sequence[int], P: int, weights: List[np.
             g = A.T @ (g @ Ws[l])  # PSpMM.backward :130-134 (A^T)
         opt.step(grads)
     return np.array(losses), Ws
+
+
+# ---------------------------------------------------------------------------------------------
+# GAT path (GPU/PGAT.py) -- numpy restatement, vectorised per row segment (no C code: the dense
+# reference is a few matmuls; this sparse restatement is pinned to it by tests/golden/ref_gat_*).
+#
+#   mode "reference": the literal arithmetic of PGAT.forward (PGAT.py:138-151):
+#       Z = H W^T ; z1 = Z a[:F] ; z2 = Z a[F:]                       (:140-142)
+#       att = z1 + z2^T ; att = where(A > 0, att, 0)                  (:144-146)   <- non-edges get logit 0, not -inf
+#       att = softmax(att, dim=1) over ALL n columns ; out = att Z    (:147-149)
+#     restated sparsely: with m_i = max(0, max_j e_ij), D_i = sum_edges exp(e_ij-m_i) + (n-deg_i) exp(-m_i),
+#       out_i = sum_edges (p_ij - b_i) Z_j + b_i sum_all Z_j,   p_ij = exp(e_ij-m_i)/D_i,  b_i = exp(-m_i)/D_i
+#   mode "standard": e_ij = LeakyReLU(z1_i + z2_j), softmax over the neighbours only, K heads
+#     (Velickovic et al.; the semantics BASELINE config 5 names: edge-softmax + weighted SpMM).
+#
+# Layout: Z is (n_cols, K*d) with head k in columns [k*d, (k+1)*d); s1 (n_rows, K), s2 (n_cols, K).
+
+
+def _segment_ids(rowptr: np.ndarray) -> np.ndarray:
+    return np.repeat(np.arange(rowptr.shape[0] - 1), np.diff(rowptr))
+
+
+def gat_scores_np(A: sp.csr_matrix, s1: np.ndarray, s2: np.ndarray, mode: str, slope: float, n_global: int):
+    """Edge weights of one layer.  Returns (alpha [nnz,K] in CSR order, beta [n_rows,K], p [nnz,K]).
+    standard: alpha = softmax over the row's entries, beta = 0, p = alpha.
+    reference: alpha = p - beta (see header)."""
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    rowptr, col = A.indptr.astype(np.int64), A.indices.astype(np.int64)
+    nr, K = A.shape[0], s1.shape[1]
+    dt = s1.dtype
+    seg = _segment_ids(rowptr)
+    raw = s1[seg] + s2[col]                                             # PGAT.py:144
+    nonempty = np.diff(rowptr) > 0
+    starts = rowptr[:-1][nonempty]
+    if mode == "standard":
+        e = np.where(raw > 0, raw, raw * dt.type(slope))
+        m = np.full((nr, K), -np.inf, dtype=dt)
+        if e.shape[0]:
+            m[nonempty] = np.maximum.reduceat(e, starts, axis=0)
+        w = np.exp(e - m[seg])
+        D = np.zeros((nr, K), dtype=dt)
+        if e.shape[0]:
+            D[nonempty] = np.add.reduceat(w, starts, axis=0)
+        alpha = w / D[seg]
+        return alpha.astype(dt), np.zeros((nr, K), dtype=dt), alpha.astype(dt)
+    if mode != "reference":
+        raise ValueError(mode)
+    m = np.zeros((nr, K), dtype=dt)
+    if raw.shape[0]:
+        m[nonempty] = np.maximum(np.maximum.reduceat(raw, starts, axis=0), 0)
+    em = np.exp(-m)
+    w = np.exp(raw - m[seg])
+    deg = np.diff(rowptr).astype(dt)[:, None]
+    D = (dt.type(n_global) - deg) * em
+    if raw.shape[0]:
+        D[nonempty] += np.add.reduceat(w, starts, axis=0)
+    p = w / D[seg]
+    beta = em / D
+    return (p - beta[seg]).astype(dt), beta.astype(dt), p.astype(dt)
+
+
+def gat_aggregate_np(A: sp.csr_matrix, Z: np.ndarray, s1: np.ndarray, s2: np.ndarray, mode: str = "standard",
+                     slope: float = 0.2, n_global: Optional[int] = None, Zsum: Optional[np.ndarray] = None):
+    """out[i,k,:] = sum_j alpha_ijk Z[j,k,:] (+ beta_ik Zsum[k,:] in reference mode).  A is the
+    pattern (n_rows x n_cols; reference mode: the entries with A_ij > 0, PGAT.py:146)."""
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    nr, nc = A.shape
+    K = s1.shape[1]
+    d = Z.shape[1] // K
+    n_global = nc if n_global is None else n_global
+    alpha, beta, _ = gat_scores_np(A, s1, s2, mode, slope, n_global)
+    out = np.zeros((nr, K * d), dtype=Z.dtype)
+    for k in range(K):
+        Ak = sp.csr_matrix((alpha[:, k], A.indices, A.indptr), shape=A.shape)
+        out[:, k * d:(k + 1) * d] = Ak @ Z[:, k * d:(k + 1) * d]
+    if mode == "reference":
+        if Zsum is None:
+            Zsum = Z.sum(axis=0, dtype=Z.dtype)
+        out += (beta[:, :, None] * Zsum.reshape(K, d)[None]).reshape(nr, K * d)
+    return out
+
+
+def gat_aggregate_backward_np(A: sp.csr_matrix, Z: np.ndarray, s1: np.ndarray, s2: np.ndarray, dOut: np.ndarray,
+                              mode: str = "standard", slope: float = 0.2, n_global: Optional[int] = None,
+                              Zsum: Optional[np.ndarray] = None, g: Optional[np.ndarray] = None):
+    """Gradients of gat_aggregate_np w.r.t. (Z, s1, s2) given dOut.  ``g`` (reference mode) is
+    sum_i beta_i dOut_i over ALL rows of the graph (defaults to the rows of A), added to every
+    row of dZ that this call owns -- the caller decides which rows those are: here ALL n_cols."""
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    nr, nc = A.shape
+    K = s1.shape[1]
+    d = Z.shape[1] // K
+    n_global = nc if n_global is None else n_global
+    rowptr, col = A.indptr.astype(np.int64), A.indices.astype(np.int64)
+    seg = _segment_ids(rowptr)
+    alpha, beta, p = gat_scores_np(A, s1, s2, mode, slope, n_global)
+    out = gat_aggregate_np(A, Z, s1, s2, mode, slope, n_global, Zsum)
+    t = (dOut.reshape(nr, K, d) * out.reshape(nr, K, d)).sum(-1)                  # <dOut_i, out_i> per head
+    dp = (dOut.reshape(nr, K, d)[seg] * Z.reshape(nc, K, d)[col]).sum(-1)         # <dOut_i, Z_j>
+    de = p * (dp - t[seg])
+    if mode == "standard":
+        raw = s1[seg] + s2[col]
+        de = de * np.where(raw > 0, 1.0, slope).astype(Z.dtype)
+    ds1 = np.zeros((nr, K), dtype=Z.dtype)
+    ds2 = np.zeros((nc, K), dtype=Z.dtype)
+    np.add.at(ds1, seg, de)
+    np.add.at(ds2, col, de)
+    dZ = np.zeros_like(Z)
+    for k in range(K):
+        Ak = sp.csr_matrix((alpha[:, k], A.indices, A.indptr), shape=A.shape)
+        dZ[:, k * d:(k + 1) * d] = Ak.T @ dOut[:, k * d:(k + 1) * d]
+    if mode == "reference":
+        if g is None:
+            g = (beta[:, :, None] * dOut.reshape(nr, K, d)).sum(0).reshape(K * d)
+        dZ += g[None, :]
+    return dZ, ds1, ds2
+
+
+def gat_layer_np(A: sp.csr_matrix, H: np.ndarray, W: np.ndarray, a: np.ndarray, heads: int = 1,
+                 mode: str = "standard", slope: float = 0.2):
+    """One PGAT layer on one process (PGAT.py:138-151): W is (F, f_in) like nn.Linear.weight,
+    a is (2*d, heads) -- column k holds [a1_k ; a2_k] (the reference's (2F, 1) for one head)."""
+    Z = H @ W.T
+    n, F = Z.shape
+    d = F // heads
+    Zh = Z.reshape(n, heads, d)
+    s1 = np.einsum("nkd,dk->nk", Zh, a[:d])
+    s2 = np.einsum("nkd,dk->nk", Zh, a[d:])
+    return gat_aggregate_np(A, Z, s1.astype(Z.dtype), s2.astype(Z.dtype), mode, slope, n), Z, s1, s2
+
+
+def gat_dense_reference_np(Adense: np.ndarray, H: np.ndarray, W: np.ndarray, a: np.ndarray) -> np.ndarray:
+    """The reference's dense arithmetic, literally (PGAT.py:140-149), single head -- used to check
+    the sparse restatement above independently of the golden files."""
+    Z = H @ W.T
+    F = Z.shape[1]
+    att = Z @ a[:F] + (Z @ a[F:]).T
+    att = np.where(Adense > 0, att, 0.0)
+    att = att - att.max(axis=1, keepdims=True)
+    e = np.exp(att)
+    return (e / e.sum(axis=1, keepdims=True)) @ Z
