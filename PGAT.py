@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Launcher with the reference's name and command line:
+
+    python PGAT.py -a A.mtx -p partvec -b nccl|gloo -s nproc -l layers -f features [--mode standard|reference] [--heads K]
+
+(see /root/reference/GPU/PGAT.py:242-279).  Everything lives in the package
+``scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd``.
+"""
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+_impl = importlib.import_module(
+    "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd.PGAT")
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})
+
+if __name__ == "__main__":
+    _impl.main(sys.argv[1:])

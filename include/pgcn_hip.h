@@ -176,6 +176,44 @@ int pgcn_spmm_fixup_f32(const int32_t *fix, int64_t nfix, const int32_t *slot_id
                         const int32_t *row_map, const float *partial_ws, float *C, int64_t ldc,
                         int32_t f, uint32_t flags, pgcn_stream_t stream);
 
+/* ---- GAT path: attention over the stored entries ----------------------
+ * Replaces the dense n x n arithmetic of PGAT.forward, GPU/PGAT.py:138-151.  Per head k with
+ * s1 = Z a1, s2 = Z a2 (:141-142):  raw_ij = s1[i,k] + s2[col,k]  (:144).
+ *   mode 0 (standard GAT): e = LeakyReLU(raw, slope); alpha_ij = softmax over row i's entries.
+ *   mode 1 (reference-literal, :145-147): all n_global columns take part, non-edges with logit 0:
+ *     m = max(0, max e), D = sum_edges exp(e-m) + (n_global-deg) exp(-m),
+ *     alpha_ij = (exp(e_ij-m) - exp(-m))/D, beta[i,k] = exp(-m)/D, so that
+ *     out_i = sum_edges alpha_ij Z_j + beta_i sum_all Z_j  (:149).  beta: [nrows x heads].
+ * alpha / de are head-major [heads][nnz] in the storage order of `col`: plane k is the `val`
+ * array of pgcn_spmm_csr(_plan)_f32, which does the aggregation out[:,k] = A_alpha_k . Z[:,k].
+ * Row lists: rows_wave (NULL = rows 0..nrows_wave-1) get one 64-lane wave each, rows_block one
+ * 256-thread workgroup each (hub rows); a row must be in exactly one list to be processed.
+ *
+ * pgcn_gat_edge_grad_f32: de_ij = (alpha_ij + beta_i)(<dOut[i,k,:], Z[col,k,:]> - t[i,k]) [x LeakyReLU'(raw)],
+ * ds1[i,k] = sum_j de_ij; t[i,k] = <dOut[i,k,:], out[i,k,:]> is supplied by the caller.  d = head width.
+ * pgcn_csr_row_sums_f32: out[i*ldo + k] = sum of plane k of src over row i's entries, read through
+ * perm (NULL = identity): with the transposed structure and its permutation this is ds2_j = sum_i de_ij.
+ * pgcn_csr_permute_f32: dst[k][p] = src[k][perm[p]] (values of A^T from values of A).
+ * All sums run in a fixed order: bit-reproducible, no atomics.                                  */
+int pgcn_gat_edge_softmax_f32(const int64_t *rowptr, const int32_t *col, int64_t nrows, int64_t nnz,
+                              const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
+                              int64_t nrows_block, const float *s1, int64_t lds1, const float *s2,
+                              int64_t lds2, int32_t heads, float slope, int32_t mode, int64_t n_global,
+                              float *alpha, float *beta, pgcn_stream_t stream);
+int pgcn_gat_edge_grad_f32(const int64_t *rowptr, const int32_t *col, int64_t nrows, int64_t nnz,
+                           const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
+                           int64_t nrows_block, const float *s1, int64_t lds1, const float *s2,
+                           int64_t lds2, const float *alpha, const float *beta, const float *Z,
+                           int64_t ldz, const float *dOut, int64_t ldo, const float *t, int32_t heads,
+                           int32_t d, float slope, int32_t mode, float *de, float *ds1,
+                           pgcn_stream_t stream);
+int pgcn_csr_row_sums_f32(const int64_t *rowptr, const int64_t *perm, int64_t nrows, int64_t nnz,
+                          const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
+                          int64_t nrows_block, const float *src, int32_t planes, float *out,
+                          int64_t ldo, pgcn_stream_t stream);
+int pgcn_csr_permute_f32(const float *src, const int64_t *perm, int64_t nnz, int32_t planes,
+                         float *dst, pgcn_stream_t stream);
+
 /* ---- boundary-row pack / unpack -------------------------------------------
  * out[r,:] = H[idx[r],:]                      replaces H[indices]   GPU/PGCN.py:104
  * H[idx[r],:] (+)= in[r,:]                    replaces X[indices] = buf   :115

@@ -154,8 +154,9 @@ def make_exchanger(rank: int, size: int, device: torch.device, impl: str = "auto
 # --------------------------------------------------------------------------
 
 
-class AggregationEngine:
-    """Owns rank p's device-resident pieces and runs the aggregation forward/backward."""
+class BoundaryExchange:
+    """Rank p's boundary-row slabs and the round-wise all-to-all-v over them (shared by the GCN
+    aggregation engine and the GAT engine)."""
 
     def __init__(self, part: Partition, kernels, device: torch.device, exchanger=None,
                  overlap: Optional[bool] = None):
@@ -166,10 +167,6 @@ class AggregationEngine:
         self.exch = exchanger
         if self.size > 1 and exchanger is None:
             raise ValueError("a multi-rank partition needs an exchanger")
-        self.A_loc = kernels.prepare(part.A_loc)
-        self.A_halo = [kernels.prepare(a) for a in part.A_halo]
-        self.A_loc_T = kernels.prepare(part.A_loc_T) if part.A_loc_T is not None else None
-        self.A_halo_T = [kernels.prepare(a) for a in part.A_halo_T]
         self.send_idx = part.send_idx.to(self.device)
         self.unpack = [kernels.prepare(u, pattern_only=True) for u in part.unpack]
         self.rounds = part.rounds
@@ -229,6 +226,19 @@ class AggregationEngine:
                 done.record(self.comm_stream)
                 waiters.append(lambda d=done: main.wait_event(d))
         return waiters
+
+
+
+class AggregationEngine(BoundaryExchange):
+    """Owns rank p's device-resident pieces and runs the aggregation forward/backward."""
+
+    def __init__(self, part: Partition, kernels, device: torch.device, exchanger=None,
+                 overlap: Optional[bool] = None):
+        super().__init__(part, kernels, device, exchanger, overlap)
+        self.A_loc = kernels.prepare(part.A_loc)
+        self.A_halo = [kernels.prepare(a) for a in part.A_halo]
+        self.A_loc_T = kernels.prepare(part.A_loc_T) if part.A_loc_T is not None else None
+        self.A_halo_T = [kernels.prepare(a) for a in part.A_halo_T]
 
     # ------------------------------------------------------------------
     def forward(self, H: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,233 @@
+"""GAT aggregation over the 1D partition (BASELINE config 5).
+
+The reference's ``PGAT.forward`` (/root/reference/GPU/PGAT.py:138-151) is dense: an n x n score
+matrix ``z1 + z2^T`` masked with ``A > 0``, a row softmax over all n columns and a dense
+``attention @ Z``.  Here the same layer runs on the stored entries of rank p's row block:
+
+    forward   [Z | s2] boundary rows -> all-to-all-v -> panel Zc = [local rows ; halo rows]
+              alpha = edge softmax(s1_i + s2_j)              (pgcn_gat_edge_softmax_f32)
+              out[:, head k] = A_alpha_k . Zc[:, head k]     (the CSR SpMM kernels, val = alpha plane k)
+    backward  de, ds1 = edge gradient                        (pgcn_gat_edge_grad_f32)
+              dZc[:, head k] = A_alpha_k^T . dOut[:, head k] (SpMM on the transposed structure, values permuted)
+              ds2 = row sums of de over the transposed structure (pgcn_csr_row_sums_f32)
+              halo rows of [dZ | ds2] travel back to their owners and are ADDED (reverse all-to-all-v)
+
+Two semantics (``mode``): "standard" = LeakyReLU + softmax over the neighbours, K heads
+(concatenated); "reference" = the literal arithmetic of PGAT.py, where the n - deg non-edges of a
+row take part in the softmax with logit 0: out_i = sum_edges alpha_ij Z_j + beta_i sum_all Z_j, the
+global column sum being one small all-reduce.  In both modes P ranks compute exactly what one
+process computes on the whole graph (owned rows).
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from .engine import BoundaryExchange
+from .partition import HostCSR, Partition, csr_from_coo, pick_nslices
+
+LONG_ROW = int(os.environ.get("PGCN_GAT_LONG_ROW", "1024"))   # rows above this get a 256-thread workgroup
+MODES = {"standard": 0, "reference": 1}
+
+
+@dataclass
+class GatGraph:
+    """Rank p's row block over the combined column space [local rows ; halo slab] -- forward
+    structure, transposed structure, and the permutation between their storage orders."""
+    n_local: int
+    n_halo: int
+    fwd: HostCSR                 # n_local x (n_local + n_halo), pattern
+    bwd: HostCSR                 # (n_local + n_halo) x n_local, pattern
+    perm: torch.Tensor           # int64 [nnz]: entry p of bwd is entry perm[p] of fwd
+    fwd_wave: torch.Tensor       # int32 row lists (longest first)
+    fwd_block: torch.Tensor
+    bwd_wave: torch.Tensor
+    bwd_block: torch.Tensor
+
+    @property
+    def nnz(self) -> int:
+        return int(self.fwd.col.numel())
+
+
+def _row_lists(rowptr: torch.Tensor, long_row: int):
+    ln = (rowptr[1:] - rowptr[:-1])
+    order = torch.argsort(-ln, stable=True)
+    big = ln[order] > long_row
+    return order[~big].to(torch.int32).contiguous(), order[big].to(torch.int32).contiguous()
+
+
+def build_gat_graph(part: Partition, positive_only: bool = False, long_row: Optional[int] = None) -> GatGraph:
+    """Coalesce the partition's pieces into one pattern over [local ; halo] columns.
+    Duplicate coordinates count once (the reference masks a DENSE matrix, PGAT.py:146);
+    ``positive_only`` keeps the coordinates whose summed value is > 0 (``A > 0``)."""
+    n_p, n_h = part.n_local, part.n_halo
+    ncols = n_p + n_h
+    rs, cs, vs = [], [], []
+    r, c, v = part.A_loc.to_coo()
+    rs.append(r.to(torch.int64)); cs.append(c.to(torch.int64)); vs.append(v)
+    for a in part.A_halo:
+        r, c, v = a.to_coo()
+        rs.append(r.to(torch.int64)); cs.append(c.to(torch.int64) + n_p); vs.append(v)
+    r, c, v = torch.cat(rs), torch.cat(cs), torch.cat(vs).to(torch.float64)
+    key, inv = torch.unique(r * ncols + c, return_inverse=True)
+    vsum = torch.zeros(key.numel(), dtype=torch.float64, device=key.device).index_add_(0, inv, v)
+    if positive_only:
+        key = key[vsum > 0]
+    r, c = key // ncols, key % ncols
+    ones = torch.ones(r.numel(), dtype=torch.float32, device=r.device)
+    # forward storage order = the SpMM kernels' (row, col % S, col); pre-sorted so that
+    # csr_from_coo's stable sort is the identity and positions are known
+    S = pick_nslices(ncols)
+    of = torch.argsort((r * S + c % S) * max(ncols, 1) + c, stable=True)
+    r, c = r[of], c[of]
+    fwd = csr_from_coo(r, c, ones, n_p, ncols, nslices=S, core=False)
+    assert torch.equal(fwd.col.to(torch.int64), c)
+    St = pick_nslices(n_p)
+    perm = torch.argsort((c * St + r % St) * max(n_p, 1) + r, stable=True)
+    bwd = csr_from_coo(c[perm], r[perm], ones, ncols, n_p, nslices=St, core=False)
+    assert torch.equal(bwd.col.to(torch.int64), r[perm])
+    lr = LONG_ROW if long_row is None else long_row
+    fw, fb = _row_lists(fwd.rowptr, lr)
+    bw, bb = _row_lists(bwd.rowptr, lr)
+    return GatGraph(n_p, n_h, fwd, bwd, perm.contiguous(), fw, fb, bw, bb)
+
+
+@dataclass
+class GatLayerState:
+    """Per-layer buffers that live from forward to backward."""
+    heads: int
+    d: int
+    alpha: torch.Tensor                  # [heads, nnz] head-major edge weights (the SpMM `val` planes)
+    beta: torch.Tensor                   # [n_local, heads]  (reference mode)
+    fwd_heads: List[object]              # forward structure with val = alpha[k]
+    Zc: Optional[torch.Tensor] = None    # [(n_local + n_halo), Fp] = [Z | s2 | pad] of local and halo rows
+    s1: Optional[torch.Tensor] = None
+    out: Optional[torch.Tensor] = None
+
+
+class GatEngine(BoundaryExchange):
+    """Device-resident GAT structures of one rank + forward / backward of the aggregation."""
+
+    def __init__(self, part: Partition, kernels, device: torch.device, exchanger=None, mode: str = "standard",
+                 slope: float = 0.2, long_row: Optional[int] = None):
+        super().__init__(part, kernels, device, exchanger, overlap=False)
+        if mode not in MODES:
+            raise ValueError("mode must be 'standard' or 'reference', got %r" % (mode,))
+        self.mode, self.mode_id, self.slope = mode, MODES[mode], float(slope)
+        self.n_global = part.n
+        g = build_gat_graph(part, positive_only=(mode == "reference"), long_row=long_row)
+        self.graph = g
+        self.nnz = g.nnz
+        self.fwd = kernels.prepare_gat(g.fwd, g.fwd_wave, g.fwd_block)
+        self.bwd = kernels.prepare_gat(g.bwd, g.bwd_wave, g.bwd_block)
+        self.perm = g.perm.to(self.device)
+        self._scratch = {}
+
+    # -- buffers ---------------------------------------------------------
+    def _plane_scratch(self, name: str, heads: int) -> torch.Tensor:
+        t = self._scratch.get((name, heads))
+        if t is None:
+            t = torch.empty((heads, max(self.nnz, 1)), dtype=torch.float32, device=self.device)
+            self._scratch[(name, heads)] = t
+        return t
+
+    def new_layer_state(self, heads: int, d: int) -> GatLayerState:
+        alpha = torch.zeros((heads, max(self.nnz, 1)), dtype=torch.float32, device=self.device)
+        beta = torch.zeros((self.n_local, heads), dtype=torch.float32, device=self.device)
+        views = [self.k.with_values(self.fwd, alpha[k]) for k in range(heads)]
+        return GatLayerState(heads, d, alpha, beta, views)
+
+    @staticmethod
+    def padded_width(F: int, heads: int) -> int:
+        return (F + heads + 3) // 4 * 4
+
+    def _allreduce(self, buf: torch.Tensor) -> torch.Tensor:
+        if self.size > 1:
+            self.exch.allreduce_sum(buf)
+        return buf
+
+    # -- forward ---------------------------------------------------------
+    def forward(self, st: GatLayerState, Z: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor) -> torch.Tensor:
+        K, d = st.heads, st.d
+        F = K * d
+        n_p, n_h = self.n_local, self.n_halo
+        if Z.shape != (n_p, F) or s1.shape != (n_p, K) or s2.shape != (n_p, K):
+            raise ValueError("expected Z %s, s1/s2 %s" % ((n_p, F), (n_p, K)))
+        Fp = self.padded_width(F, K)
+        if st.Zc is None or st.Zc.shape != (n_p + n_h, Fp):
+            st.Zc = torch.zeros((n_p + n_h, Fp), dtype=torch.float32, device=self.device)
+        Zc = st.Zc
+        Zc[:n_p, :F].copy_(Z)
+        Zc[:n_p, F:F + K].copy_(s2)
+        if self.size > 1:                                   # PGAT.py:139 `Comm.apply(H)`: here the rows of [Z | s2]
+            send = self._slab("gat_send", self.n_send, Fp)
+            self.k.gather_rows(Zc[:n_p], self.send_idx, send)
+            for w in self._exchange_all(send, self.round_send_off, Zc[n_p:], self.round_recv_off, Fp):
+                w()
+        st.s1 = s1.contiguous()
+        self.k.gat_edge_softmax(self.fwd, st.s1, Zc[:, F:F + K], K, self.slope, self.mode_id, self.n_global,
+                                st.alpha, st.beta)
+        out = torch.empty((n_p, F), dtype=torch.float32, device=self.device)
+        for k in range(K):
+            self.k.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], out[:, k * d:(k + 1) * d])
+        if self.mode_id == 1:                               # + beta_i * (sum over ALL vertices of Z_j)
+            zsum = self._allreduce(Z.sum(0))
+            out.view(n_p, K, d).addcmul_(st.beta.view(n_p, K, 1), zsum.view(1, K, d))
+        st.out = out
+        return out
+
+    # -- backward --------------------------------------------------------
+    def backward(self, st: GatLayerState, dOut: torch.Tensor):
+        """Returns (dZ, ds1, ds2) for the owned rows."""
+        K, d = st.heads, st.d
+        F = K * d
+        n_p, n_h = self.n_local, self.n_halo
+        Fp = st.Zc.shape[1]
+        dOut = dOut.contiguous()
+        t = (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
+        de = self._plane_scratch("de", K)
+        ds1 = torch.empty((n_p, K), dtype=torch.float32, device=self.device)
+        self.k.gat_edge_grad(self.fwd, st.s1, st.Zc[:, F:F + K], st.alpha, st.beta, st.Zc, dOut, t, K, d,
+                             self.slope, self.mode_id, de, ds1)
+        alpha_t = self._plane_scratch("alpha_t", K)
+        self.k.csr_permute(st.alpha, self.perm, alpha_t)
+        bwd_heads = self._scratch.get(("bwd_heads", K))
+        if bwd_heads is None:
+            bwd_heads = [self.k.with_values(self.bwd, alpha_t[k]) for k in range(K)]
+            self._scratch[("bwd_heads", K)] = bwd_heads
+        dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
+        for k in range(K):
+            self.k.spmm(bwd_heads[k], dOut[:, k * d:(k + 1) * d], dZc[:, k * d:(k + 1) * d])
+        self.k.csr_row_sums(self.bwd, self.perm, de, K, dZc[:, F:F + K])
+        if Fp > F + K:
+            dZc[:, F + K:].zero_()
+        if self.size > 1:                                   # partial rows of [dZ | ds2] back to their owners, ADDED
+            back = self._slab("gat_send", self.n_send, Fp)
+            waits = self._exchange_all(dZc[n_p:], self.round_recv_off, back, self.round_send_off, Fp)
+            for r in range(self.rounds):
+                waits[r]()
+                self.k.spmm(self.unpack[r], back, dZc[:n_p], accumulate=True)
+        dZ = dZc[:n_p, :F].clone()
+        ds2 = dZc[:n_p, F:F + K].clone()
+        if self.mode_id == 1:                               # every Z_j also feeds every row through beta_i
+            g = self._allreduce((st.beta.view(n_p, K, 1) * dOut.view(n_p, K, d)).sum(0).reshape(F))
+            dZ += g
+        return dZ, ds1, ds2
+
+
+class GatAggregate(torch.autograd.Function):
+    """out = GAT aggregation of (Z, s1, s2) on ``engine`` with ``state``'s buffers."""
+
+    @staticmethod
+    def forward(ctx, engine: GatEngine, state: GatLayerState, Z, s1, s2):
+        ctx.engine, ctx.state = engine, state
+        return engine.forward(state, Z.contiguous(), s1, s2)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        dZ, ds1, ds2 = ctx.engine.backward(ctx.state, grad_output)
+        return None, None, dZ, ds1, ds2

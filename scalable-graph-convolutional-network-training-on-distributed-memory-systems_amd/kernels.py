@@ -14,6 +14,7 @@ multi-process ``gloo`` tests with a checker-backed provider that lives in
 from __future__ import annotations
 
 import ctypes
+import dataclasses
 import os
 from dataclasses import dataclass
 from typing import Optional
@@ -52,6 +53,8 @@ class DeviceCSR:
     slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
     nslots_total: int = 0
     fused_work: Optional[torch.Tensor] = None  # int32 [nwork,4] unified work list (pgcn_spmm_fused_f32)
+    rows_wave: Optional[torch.Tensor] = None   # GAT kernels: int32 rows handled by one wave each ...
+    rows_block: Optional[torch.Tensor] = None  # ... and by one 256-thread workgroup each (hub rows)
     launch_cache: dict = None                 # bound C-ABI calls per (ldb, ldc, f, accumulate)
 
     def __post_init__(self):
@@ -362,6 +365,90 @@ class HipKernels:
                 torch.cuda.current_stream(self.device).wait_event(done)
             check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, c, ldc, f, fflags, s), "pgcn_spmm_fixup_f32")
         return fused or hybrid
+
+    # -- GAT path (pgcn_gat.hip) ---------------------------------------------
+    def prepare_gat(self, csr: HostCSR, rows_wave: torch.Tensor, rows_block: torch.Tensor) -> DeviceCSR:
+        """Pattern structure for the attention kernels + SpMM plan; the values come per layer and
+        head through ``with_values``."""
+        if csr.core is not None or csr.row_map is not None:
+            raise _lib.PgcnError("GAT structures are plain (sliced) CSR blocks")
+        d = self.prepare(csr, pattern_only=True)
+        d.rows_wave = rows_wave.to(self.device, torch.int32).contiguous()
+        d.rows_block = rows_block.to(self.device, torch.int32).contiguous()
+        return d
+
+    def with_values(self, A: DeviceCSR, plane: torch.Tensor) -> DeviceCSR:
+        """The same structure with ``plane`` (fp32 [nnz], storage order) as its value array."""
+        if plane.dtype is not torch.float32 or not plane.is_cuda or plane.dim() != 1 or plane.stride(0) != 1 \
+                or plane.numel() < A.col.numel():
+            raise _lib.PgcnError("value plane must be a contiguous fp32 CUDA vector of nnz entries")
+        return dataclasses.replace(A, val=plane, launch_cache={}, ws=None)
+
+    @staticmethod
+    def _lists(A: DeviceCSR):
+        return (_ptr(A.rows_wave), A.rows_wave.numel(), _ptr(A.rows_block), A.rows_block.numel())
+
+    def _check_rows(self, t: torch.Tensor, rows: int, cols: int, what: str):
+        if not (t.is_cuda and t.dtype is torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] >= rows
+                and t.shape[1] == cols):
+            raise _lib.PgcnError("%s must be an fp32 CUDA matrix with >= %d rows and %d unit-stride columns"
+                                 % (what, rows, cols))
+
+    def gat_edge_softmax(self, A: DeviceCSR, s1, s2, heads: int, slope: float, mode: int, n_global: int,
+                         alpha: torch.Tensor, beta: torch.Tensor) -> None:
+        self._check_rows(s1, A.nrows, heads, "s1")
+        self._check_rows(s2, A.ncols, heads, "s2")
+        self._check_rows(alpha, heads, alpha.shape[1], "alpha")
+        self._check_rows(beta, A.nrows, heads, "beta")
+        nnz = A.col.numel()
+        if alpha.shape[1] < nnz or alpha.stride(0) != alpha.shape[1] or beta.stride(0) != heads:
+            raise _lib.PgcnError("alpha must be [heads, nnz] and beta [nrows, heads], both contiguous")
+        _lib.check(self.lib.pgcn_gat_edge_softmax_f32(
+            A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, alpha.shape[1], *self._lists(A), s1.data_ptr(),
+            s1.stride(0), s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, alpha.data_ptr(), beta.data_ptr(),
+            self._stream()), "pgcn_gat_edge_softmax_f32")
+
+    def gat_edge_grad(self, A: DeviceCSR, s1, s2, alpha, beta, Z, dOut, t, heads: int, d: int, slope: float,
+                      mode: int, de: torch.Tensor, ds1: torch.Tensor) -> None:
+        self._check_rows(s1, A.nrows, heads, "s1")
+        self._check_rows(s2, A.ncols, heads, "s2")
+        self._check_rows(t, A.nrows, heads, "t")
+        self._check_rows(ds1, A.nrows, heads, "ds1")
+        self._check_rows(dOut, A.nrows, heads * d, "dOut")
+        if not (Z.is_cuda and Z.dtype is torch.float32 and Z.dim() == 2 and Z.stride(1) == 1 and Z.shape[0] >= A.ncols
+                and Z.shape[1] >= heads * d):
+            raise _lib.PgcnError("Z must hold ncols rows of at least heads*d fp32 columns")
+        if de.shape != alpha.shape or not de.is_contiguous() or not alpha.is_contiguous() \
+                or t.stride(0) != heads or ds1.stride(0) != heads or beta.stride(0) != heads:
+            raise _lib.PgcnError("alpha/de must be [heads, nnz] contiguous; t, ds1, beta [nrows, heads] contiguous")
+        _lib.check(self.lib.pgcn_gat_edge_grad_f32(
+            A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, alpha.shape[1], *self._lists(A), s1.data_ptr(),
+            s1.stride(0), s2.data_ptr(), s2.stride(0), alpha.data_ptr(), beta.data_ptr(), Z.data_ptr(), Z.stride(0),
+            dOut.data_ptr(), dOut.stride(0), t.data_ptr(), heads, d, slope, mode, de.data_ptr(), ds1.data_ptr(),
+            self._stream()), "pgcn_gat_edge_grad_f32")
+
+    def csr_row_sums(self, A: DeviceCSR, perm: Optional[torch.Tensor], src: torch.Tensor, planes: int,
+                     out: torch.Tensor) -> None:
+        self._check_rows(out, A.nrows, planes, "out")
+        if src.dim() != 2 or src.shape[0] != planes or not src.is_contiguous() or src.shape[1] < A.col.numel():
+            raise _lib.PgcnError("src must be [planes, nnz] contiguous")
+        if perm is not None and (perm.dtype is not torch.int64 or perm.numel() < A.col.numel()):
+            raise _lib.PgcnError("perm must be int64 [nnz]")
+        _lib.check(self.lib.pgcn_csr_row_sums_f32(
+            A.rowptr.data_ptr(), _ptr(perm), A.nrows, src.shape[1], *self._lists(A), src.data_ptr(), planes,
+            out.data_ptr(), out.stride(0), self._stream()), "pgcn_csr_row_sums_f32")
+
+    def csr_permute(self, src: torch.Tensor, perm: torch.Tensor, dst: torch.Tensor) -> None:
+        if src.shape != dst.shape or src.dim() != 2 or not src.is_contiguous() or not dst.is_contiguous() \
+                or perm.dtype is not torch.int64:
+            raise _lib.PgcnError("src/dst must be [planes, nnz] contiguous, perm int64")
+        n = perm.numel()
+        if n == 0:
+            return
+        if src.shape[1] != n:                         # planes are padded when nnz == 0 only
+            raise _lib.PgcnError("perm length must equal the plane length")
+        _lib.check(self.lib.pgcn_csr_permute_f32(src.data_ptr(), perm.data_ptr(), n, src.shape[0], dst.data_ptr(),
+                                                 self._stream()), "pgcn_csr_permute_f32")
 
     def gather_rows(self, H: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         n = idx.numel()

@@ -142,3 +142,70 @@ def minibatch_worker(rank, P, port, path_A, path_pv, f, bs, seed, gpu, q):
            "weights": [m.linear.weight.detach().cpu().numpy() for m in (model.gcn1, model.gcn2, model.gcn3)]})
     dist.barrier()
     dist.destroy_process_group()
+
+
+# ---- GAT path ---------------------------------------------------------------------------------
+def _pgat_module(rank, P, mode, heads):
+    from conftest import pkg
+    from oracle_kernels import OracleKernels
+    M = pkg("PGAT")
+    M._kernel_provider = OracleKernels()       # test-only checker-backed kernels
+    M.myrank, M.world_size, M.device = rank, P, torch.device("cpu")
+    M.mode, M.heads = mode, heads
+    M._exchanger = None
+    return M
+
+
+def gat_layers_worker(rank, P, port, path_A, path_pv, mode, heads, f, L, seed, q):
+    """L PGAT layers + run()'s objective on seeded inputs / parameters: outputs and every gradient,
+    owned rows only."""
+    from conftest import read_partvec
+    from scipy.io import mmread
+    _init(rank, P, port)
+    M = _pgat_module(rank, P, mode, heads)
+    A = mmread(path_A)
+    n = A.shape[0]
+    part = read_partvec(path_pv)
+    M.send_map, M.recv_map = M.compute_communication_maps(A, part, rank, P)
+    eng = M.get_partitiont_of_adjacency_matrix(A, part, rank)
+    own = eng.part.owned.numpy()
+    rng = np.random.default_rng(seed)
+    Hfull = (rng.random((n, f), dtype=np.float32) * 2 - 1)
+    H = torch.tensor(Hfull[own], requires_grad=True)
+    layers = [M.PGAT(eng, f, f) for _ in range(L)]
+    with torch.no_grad():
+        for layer in layers:
+            layer.linear.weight.copy_(torch.from_numpy((rng.standard_normal((f, f)) * 0.4).astype(np.float32)))
+            layer.attention.copy_(torch.from_numpy((rng.standard_normal(tuple(layer.attention.shape)) * 0.4).astype(np.float32)))
+    x, outs = H, []
+    for layer in layers:
+        x = layer(x)
+        outs.append(x)
+    labels = torch.from_numpy(own) % f
+    loss = M.local_loss(x, labels, n)
+    loss.backward()
+    # the standalone Comm entry point: halo rows of H, and its backward (accumulating unpack)
+    H2 = torch.tensor(Hfull[own], requires_grad=True)
+    halo = M.Comm.apply(H2)
+    ok_halo = bool(np.array_equal(halo.detach().numpy(), Hfull[eng.part.halo_global.numpy()]))
+    halo.sum().backward()
+    q.put({"rank": rank, "own": own, "outs": [o.detach().numpy() for o in outs], "loss": float(loss),
+           "dH": H.grad.numpy(), "dW": [l.linear.weight.grad.numpy() for l in layers],
+           "da": [l.attention.grad.numpy() for l in layers], "ok_halo": ok_halo,
+           "comm_grad": H2.grad.numpy(), "n_send_rows": int(eng.n_send)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gat_run_worker(rank, P, port, path_A, path_pv, mode, heads, nlayers, f, seed, epochs, q):
+    """The drop-in's run() end to end (PGAT.py:165-233) over gloo."""
+    _init(rank, P, port)
+    M = _pgat_module(rank, P, mode, heads)
+    torch.manual_seed(seed)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        model = M.run(rank, P, nlayers, f, path_A, path_pv, "gloo", epochs=epochs)
+    q.put({"rank": rank, "stdout": buf.getvalue(),
+           "params": {k: v.detach().numpy() for k, v in model.named_parameters()}})
+    dist.barrier()
+    dist.destroy_process_group()

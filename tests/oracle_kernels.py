@@ -57,3 +57,96 @@ class OracleKernels:
             h = H.numpy()
             oracle.scatter_rows(h, idx.numpy(), src[:n].contiguous().numpy(), accumulate)
         return H
+
+
+# ---- GAT path: numpy stand-ins for pgcn_gat.hip on the STORAGE order of the structure ----------
+class _CpuGat(_CpuCSR):
+    def __init__(self, csr, rows_wave, rows_block):
+        super().__init__(csr)
+        self.rowptr = csr.rowptr.cpu().numpy().astype(np.int64)
+        self.col = csr.col.cpu().numpy().astype(np.int64)
+        self.seg = np.repeat(np.arange(self.nrows), np.diff(self.rowptr))
+        listed = np.sort(np.concatenate([rows_wave.cpu().numpy(), rows_block.cpu().numpy()]))
+        assert np.array_equal(listed, np.arange(self.nrows)), "every row must be in exactly one list"
+
+
+def _prepare_gat(self, csr, rows_wave, rows_block):
+    assert csr.core is None and csr.row_map is None
+    return _CpuGat(csr, rows_wave, rows_block)
+
+
+def _with_values(self, A, plane):
+    import copy
+    B = copy.copy(A)
+    B.v = plane.numpy()[:A.col.shape[0]]              # shares memory with the tensor: later writes are seen
+    return B
+
+
+def _raw(A, s1, s2, k):
+    return s1.numpy()[A.seg, k] + s2.numpy()[A.col, k]
+
+
+def _gat_edge_softmax(self, A, s1, s2, heads, slope, mode, n_global, alpha, beta):
+    nz = A.col.shape[0]
+    ne = np.diff(A.rowptr) > 0
+    starts = A.rowptr[:-1][ne]
+    for k in range(heads):
+        raw = _raw(A, s1, s2, k).astype(np.float32)
+        m = np.zeros(A.nrows, np.float32)
+        if mode == 0:
+            raw = np.where(raw > 0, raw, raw * np.float32(slope))
+            if nz:
+                m[ne] = np.maximum.reduceat(raw, starts)
+            em = np.zeros(A.nrows, np.float32)
+        else:
+            if nz:
+                m[ne] = np.maximum(np.maximum.reduceat(raw, starts), 0)
+            em = np.exp(-m)
+        w = np.exp(raw - m[A.seg])
+        D = (np.float32(n_global) - np.diff(A.rowptr).astype(np.float32)) * em
+        if nz:
+            D[ne] += np.add.reduceat(w, starts)
+        inv = np.where(D > 0, 1 / np.where(D > 0, D, 1), 0).astype(np.float32)
+        alpha[k, :nz] = torch.from_numpy((w - em[A.seg]) * inv[A.seg])
+        if mode == 1:
+            beta[:, k] = torch.from_numpy(em * inv)
+
+
+def _gat_edge_grad(self, A, s1, s2, alpha, beta, Z, dOut, t, heads, d, slope, mode, de, ds1):
+    nz = A.col.shape[0]
+    Zn, Gn = Z.numpy(), dOut.numpy()
+    for k in range(heads):
+        dp = (Gn[A.seg, k * d:(k + 1) * d] * Zn[A.col, k * d:(k + 1) * d]).sum(1)
+        p = alpha.numpy()[k, :nz] + (beta.numpy()[A.seg, k] if mode == 1 else 0)
+        g = p * (dp - t.numpy()[A.seg, k])
+        if mode == 0:
+            g = g * np.where(_raw(A, s1, s2, k) > 0, 1.0, slope)
+        de[k, :nz] = torch.from_numpy(g.astype(np.float32))
+        acc = np.zeros(A.nrows, np.float32)
+        np.add.at(acc, A.seg, g.astype(np.float32))
+        ds1[:, k] = torch.from_numpy(acc)
+
+
+def _csr_row_sums(self, A, perm, src, planes, out):
+    nz = A.col.shape[0]
+    for k in range(planes):
+        v = src.numpy()[k, :nz]
+        if perm is not None:
+            v = v[perm.numpy()]
+        acc = np.zeros(A.nrows, np.float32)
+        np.add.at(acc, A.seg, v)
+        out[:A.nrows, k] = torch.from_numpy(acc)
+
+
+def _csr_permute(self, src, perm, dst):
+    n = perm.numel()
+    if n:
+        dst[:, :n] = src[:, perm]
+
+
+OracleKernels.prepare_gat = _prepare_gat
+OracleKernels.with_values = _with_values
+OracleKernels.gat_edge_softmax = _gat_edge_softmax
+OracleKernels.gat_edge_grad = _gat_edge_grad
+OracleKernels.csr_row_sums = _csr_row_sums
+OracleKernels.csr_permute = _csr_permute
