@@ -401,10 +401,10 @@ class HipKernels:
         self._check_rows(alpha, heads, alpha.shape[1], "alpha")
         self._check_rows(beta, A.nrows, heads, "beta")
         nnz = A.col.numel()
-        if alpha.shape[1] < nnz or alpha.stride(0) != alpha.shape[1] or beta.stride(0) != heads:
+        if (nnz and alpha.shape[1] != nnz) or alpha.stride(0) != alpha.shape[1] or beta.stride(0) != heads:
             raise _lib.PgcnError("alpha must be [heads, nnz] and beta [nrows, heads], both contiguous")
         _lib.check(self.lib.pgcn_gat_edge_softmax_f32(
-            A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, alpha.shape[1], *self._lists(A), s1.data_ptr(),
+            A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, *self._lists(A), s1.data_ptr(),
             s1.stride(0), s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, alpha.data_ptr(), beta.data_ptr(),
             self._stream()), "pgcn_gat_edge_softmax_f32")
 
@@ -418,11 +418,13 @@ class HipKernels:
         if not (Z.is_cuda and Z.dtype is torch.float32 and Z.dim() == 2 and Z.stride(1) == 1 and Z.shape[0] >= A.ncols
                 and Z.shape[1] >= heads * d):
             raise _lib.PgcnError("Z must hold ncols rows of at least heads*d fp32 columns")
+        nnz = A.col.numel()
         if de.shape != alpha.shape or not de.is_contiguous() or not alpha.is_contiguous() \
+                or (nnz and alpha.shape[1] != nnz) \
                 or t.stride(0) != heads or ds1.stride(0) != heads or beta.stride(0) != heads:
             raise _lib.PgcnError("alpha/de must be [heads, nnz] contiguous; t, ds1, beta [nrows, heads] contiguous")
         _lib.check(self.lib.pgcn_gat_edge_grad_f32(
-            A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, alpha.shape[1], *self._lists(A), s1.data_ptr(),
+            A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, *self._lists(A), s1.data_ptr(),
             s1.stride(0), s2.data_ptr(), s2.stride(0), alpha.data_ptr(), beta.data_ptr(), Z.data_ptr(), Z.stride(0),
             dOut.data_ptr(), dOut.stride(0), t.data_ptr(), heads, d, slope, mode, de.data_ptr(), ds1.data_ptr(),
             self._stream()), "pgcn_gat_edge_grad_f32")
@@ -430,12 +432,13 @@ class HipKernels:
     def csr_row_sums(self, A: DeviceCSR, perm: Optional[torch.Tensor], src: torch.Tensor, planes: int,
                      out: torch.Tensor) -> None:
         self._check_rows(out, A.nrows, planes, "out")
-        if src.dim() != 2 or src.shape[0] != planes or not src.is_contiguous() or src.shape[1] < A.col.numel():
+        nnz = A.col.numel()
+        if src.dim() != 2 or src.shape[0] != planes or not src.is_contiguous() or (nnz and src.shape[1] != nnz):
             raise _lib.PgcnError("src must be [planes, nnz] contiguous")
         if perm is not None and (perm.dtype is not torch.int64 or perm.numel() < A.col.numel()):
             raise _lib.PgcnError("perm must be int64 [nnz]")
         _lib.check(self.lib.pgcn_csr_row_sums_f32(
-            A.rowptr.data_ptr(), _ptr(perm), A.nrows, src.shape[1], *self._lists(A), src.data_ptr(), planes,
+            A.rowptr.data_ptr(), _ptr(perm), A.nrows, nnz, *self._lists(A), src.data_ptr(), planes,
             out.data_ptr(), out.stride(0), self._stream()), "pgcn_csr_row_sums_f32")
 
     def csr_permute(self, src: torch.Tensor, perm: torch.Tensor, dst: torch.Tensor) -> None:

@@ -145,24 +145,30 @@ def minibatch_worker(rank, P, port, path_A, path_pv, f, bs, seed, gpu, q):
 
 
 # ---- GAT path ---------------------------------------------------------------------------------
-def _pgat_module(rank, P, mode, heads):
+def _pgat_module(rank, P, mode, heads, gpu=False):
     from conftest import pkg
-    from oracle_kernels import OracleKernels
     M = pkg("PGAT")
-    M._kernel_provider = OracleKernels()       # test-only checker-backed kernels
-    M.myrank, M.world_size, M.device = rank, P, torch.device("cpu")
+    if gpu:                                    # the real HIP kernels; processes share cuda:0
+        M._kernel_provider = None
+        M.myrank, M.world_size, M.device = rank, P, torch.device("cuda:0")
+        torch.cuda.set_device(0)
+    else:
+        from oracle_kernels import OracleKernels
+        M._kernel_provider = OracleKernels()   # test-only checker-backed kernels
+        M.myrank, M.world_size, M.device = rank, P, torch.device("cpu")
     M.mode, M.heads = mode, heads
     M._exchanger = None
     return M
 
 
-def gat_layers_worker(rank, P, port, path_A, path_pv, mode, heads, f, L, seed, q):
+def gat_layers_worker(rank, P, port, path_A, path_pv, mode, heads, f, L, seed, q, gpu=False):
     """L PGAT layers + run()'s objective on seeded inputs / parameters: outputs and every gradient,
     owned rows only."""
     from conftest import read_partvec
     from scipy.io import mmread
     _init(rank, P, port)
-    M = _pgat_module(rank, P, mode, heads)
+    M = _pgat_module(rank, P, mode, heads, gpu)
+    dev = M.device
     A = mmread(path_A)
     n = A.shape[0]
     part = read_partvec(path_pv)
@@ -171,8 +177,8 @@ def gat_layers_worker(rank, P, port, path_A, path_pv, mode, heads, f, L, seed, q
     own = eng.part.owned.numpy()
     rng = np.random.default_rng(seed)
     Hfull = (rng.random((n, f), dtype=np.float32) * 2 - 1)
-    H = torch.tensor(Hfull[own], requires_grad=True)
-    layers = [M.PGAT(eng, f, f) for _ in range(L)]
+    H = torch.tensor(Hfull[own], requires_grad=True, device=dev)
+    layers = [M.PGAT(eng, f, f).to(dev) for _ in range(L)]
     with torch.no_grad():
         for layer in layers:
             layer.linear.weight.copy_(torch.from_numpy((rng.standard_normal((f, f)) * 0.4).astype(np.float32)))
@@ -181,31 +187,32 @@ def gat_layers_worker(rank, P, port, path_A, path_pv, mode, heads, f, L, seed, q
     for layer in layers:
         x = layer(x)
         outs.append(x)
-    labels = torch.from_numpy(own) % f
+    labels = torch.from_numpy(own).to(dev) % f
     loss = M.local_loss(x, labels, n)
     loss.backward()
     # the standalone Comm entry point: halo rows of H, and its backward (accumulating unpack)
-    H2 = torch.tensor(Hfull[own], requires_grad=True)
+    H2 = torch.tensor(Hfull[own], requires_grad=True, device=dev)
     halo = M.Comm.apply(H2)
-    ok_halo = bool(np.array_equal(halo.detach().numpy(), Hfull[eng.part.halo_global.numpy()]))
+    ok_halo = bool(np.array_equal(halo.detach().cpu().numpy(), Hfull[eng.part.halo_global.numpy()]))
     halo.sum().backward()
-    q.put({"rank": rank, "own": own, "outs": [o.detach().numpy() for o in outs], "loss": float(loss),
-           "dH": H.grad.numpy(), "dW": [l.linear.weight.grad.numpy() for l in layers],
-           "da": [l.attention.grad.numpy() for l in layers], "ok_halo": ok_halo,
-           "comm_grad": H2.grad.numpy(), "n_send_rows": int(eng.n_send)})
+    q.put({"rank": rank, "own": own, "outs": [o.detach().cpu().numpy() for o in outs], "loss": float(loss.detach()),
+           "dH": H.grad.cpu().numpy(), "dW": [l.linear.weight.grad.cpu().numpy() for l in layers],
+           "da": [l.attention.grad.cpu().numpy() for l in layers], "ok_halo": ok_halo,
+           "comm_grad": H2.grad.cpu().numpy(), "n_send_rows": int(eng.n_send),
+           "provider": type(M._kernel_provider).__name__})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def gat_run_worker(rank, P, port, path_A, path_pv, mode, heads, nlayers, f, seed, epochs, q):
+def gat_run_worker(rank, P, port, path_A, path_pv, mode, heads, nlayers, f, seed, epochs, q, gpu=False):
     """The drop-in's run() end to end (PGAT.py:165-233) over gloo."""
     _init(rank, P, port)
-    M = _pgat_module(rank, P, mode, heads)
+    M = _pgat_module(rank, P, mode, heads, gpu)
     torch.manual_seed(seed)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         model = M.run(rank, P, nlayers, f, path_A, path_pv, "gloo", epochs=epochs)
-    q.put({"rank": rank, "stdout": buf.getvalue(),
-           "params": {k: v.detach().numpy() for k, v in model.named_parameters()}})
+    q.put({"rank": rank, "stdout": buf.getvalue(), "provider": type(M._kernel_provider).__name__,
+           "params": {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}})
     dist.barrier()
     dist.destroy_process_group()

@@ -21,11 +21,11 @@ TOL = 1e-5
 _port = [29800]
 
 
-def _spawn(fn, P, *args):
+def _spawn(fn, P, *args, **kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     _port[0] += 1
-    procs = [ctx.Process(target=fn, args=(r, P, _port[0]) + args + (q,)) for r in range(P)]
+    procs = [ctx.Process(target=fn, args=(r, P, _port[0]) + args + (q,), kwargs=kw) for r in range(P)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(P)]

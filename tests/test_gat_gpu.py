@@ -1,0 +1,272 @@
+"""GAT path on the MI355X: the HIP attention kernels (through the C ABI) against the numpy oracle,
+the engine against the reference's own PGAT layers (tests/golden/ref_gat_*), multi-rank with the real
+kernels.  fp32 throughout; tolerances are relative to the largest magnitude of the compared array."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+from scipy.io import mmread
+
+import _workers
+from conftest import golden, gpath, pkg, rel_err
+from oracle import oracle
+from test_engine_gloo import _spawn
+from test_gat_gloo import CASES, _expected, _losses, _pattern
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    d = torch.device("cuda:0")
+    torch.cuda.set_device(d)
+    return d
+
+
+@pytest.fixture(scope="module")
+def K(dev):
+    return pkg("kernels").HipKernels(dev)
+
+
+def _structure(K, A, nslices, long_row):
+    """Device structure of pattern A and of A^T + the permutation, like gat.build_gat_graph."""
+    partition, gat = pkg("partition"), pkg("gat")
+    A = sp.coo_matrix(A)
+    r, c = torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64))
+    nr, nc = A.shape
+    S = nslices
+    of = torch.argsort((r * S + c % S) * nc + c, stable=True)
+    r, c = r[of], c[of]
+    ones = torch.ones(r.numel())
+    h = partition.csr_from_coo(r, c, ones, nr, nc, nslices=S, core=False)
+    perm = torch.argsort((c * S + r % S) * nr + r, stable=True)
+    ht = partition.csr_from_coo(c[perm], r[perm], ones, nc, nr, nslices=S, core=False)
+    d = K.prepare_gat(h, *gat._row_lists(h.rowptr, long_row))
+    dt = K.prepare_gat(ht, *gat._row_lists(ht.rowptr, long_row))
+    return d, dt, perm.to(K.device), r.numpy(), c.numpy()
+
+
+def _graph(n, m, seed, hub=True):
+    rng = np.random.default_rng(seed)
+    A = sp.random(n, m, density=0.03, random_state=seed, format="lil")
+    if hub:
+        A[3, :] = 1                      # a row longer than every threshold
+        A[:, 5] = 1                      # and a hub column (long row of the transpose)
+    A[7, :] = 0                          # an empty row
+    A = sp.csr_matrix(A)
+    A.data[:] = 1
+    A.eliminate_zeros()
+    return A, rng
+
+
+@pytest.mark.parametrize("mode", ["standard", "reference"])
+@pytest.mark.parametrize("heads,d", [(1, 16), (3, 4), (4, 64), (2, 30), (1, 7)])
+@pytest.mark.parametrize("nslices,long_row", [(1, 1 << 30), (8, 64)])
+def test_attention_kernels_vs_oracle(K, dev, mode, heads, d, nslices, long_row):
+    n, m = 300, 260
+    A, rng = _graph(n, m, heads * 10 + d)
+    A.sort_indices()
+    mode_id = {"standard": 0, "reference": 1}[mode]
+    dA, dT, perm, er, ec = _structure(K, A, nslices, long_row)
+    nnz = A.nnz
+    F = heads * d
+    ld = F + heads + 3                                                   # s2 lives behind Z in a wider panel
+    Zc = (rng.standard_normal((m, ld)) * 0.7).astype(np.float32)
+    s1 = (rng.standard_normal((n, heads)) * 1.5).astype(np.float32)
+    s2 = Zc[:, F:F + heads].copy()
+    Zd = torch.from_numpy(Zc).to(dev)
+    s1d = torch.from_numpy(s1).to(dev)
+    alpha = torch.full((heads, nnz), float("nan"), device=dev)
+    beta = torch.full((n, heads), float("nan"), device=dev)
+    K.gat_edge_softmax(dA, s1d, Zd[:, F:F + heads], heads, 0.2, mode_id, 1000, alpha, beta)
+    torch.cuda.synchronize()
+    ea, eb, ep = oracle.gat_scores_np(A, s1, s2, mode, 0.2, 1000)        # CSR order, columns ascending
+    got = alpha.cpu().numpy()
+    for k in range(heads):
+        G = sp.csr_matrix((got[k], (er, ec)), shape=A.shape).toarray()
+        E = sp.csr_matrix((ea[:, k], A.indices, A.indptr), shape=A.shape).toarray()
+        assert rel_err(G, E) < TOL
+    if mode == "reference":
+        assert rel_err(beta.cpu().numpy(), eb) < TOL
+    else:
+        sums = np.zeros((n, heads)); np.add.at(sums, er, got.T)
+        np.testing.assert_allclose(sums[np.diff(A.indptr) > 0], 1.0, atol=1e-5)
+        beta.zero_()
+    # aggregation through the SpMM kernels, one value plane per head
+    out = torch.full((n, F), float("nan"), device=dev)
+    for k in range(heads):
+        K.spmm(K.with_values(dA, alpha[k]), Zd[:, k * d:(k + 1) * d], out[:, k * d:(k + 1) * d])
+    Z = Zc[:, :F]
+    zsum = Z.sum(0)
+    exp_out = oracle.gat_aggregate_np(A, Z.astype(np.float64), s1.astype(np.float64), s2.astype(np.float64), mode, 0.2,
+                                      1000, zsum.astype(np.float64))
+    if mode == "reference":
+        out.view(n, heads, d).addcmul_(beta.view(n, heads, 1), torch.from_numpy(zsum).to(dev).view(1, heads, d))
+    assert rel_err(out.cpu().numpy(), exp_out) < TOL
+    # backward pieces
+    dOut = (rng.standard_normal((n, F))).astype(np.float32)
+    dOd = torch.from_numpy(dOut).to(dev)
+    t = (dOd.view(n, heads, d) * out.view(n, heads, d)).sum(-1).contiguous()
+    de = torch.full((heads, nnz), float("nan"), device=dev)
+    ds1 = torch.full((n, heads), float("nan"), device=dev)
+    K.gat_edge_grad(dA, s1d, Zd[:, F:F + heads], alpha, beta, Zd, dOd, t, heads, d, 0.2, mode_id, de, ds1)
+    ds2 = torch.full((m, heads + 2), float("nan"), device=dev)
+    K.csr_row_sums(dT, perm, de, heads, ds2[:, 1:1 + heads])             # strided output
+    alpha_t = torch.empty_like(alpha)
+    K.csr_permute(alpha, perm, alpha_t)
+    dZ = torch.full((m, F), float("nan"), device=dev)
+    for k in range(heads):
+        K.spmm(K.with_values(dT, alpha_t[k]), dOd[:, k * d:(k + 1) * d], dZ[:, k * d:(k + 1) * d])
+    torch.cuda.synchronize()
+    g = (eb[:, :, None] * dOut.reshape(n, heads, d)).sum(0).reshape(F) if mode == "reference" else None
+    edZ, eds1, eds2 = oracle.gat_aggregate_backward_np(A, Z.astype(np.float64), s1.astype(np.float64),
+                                                       s2.astype(np.float64), dOut.astype(np.float64), mode, 0.2, 1000,
+                                                       zsum.astype(np.float64), None if g is None else g * 0)
+    assert rel_err(ds1.cpu().numpy(), eds1) < 5 * TOL
+    assert rel_err(ds2[:, 1:1 + heads].cpu().numpy(), eds2) < 5 * TOL
+    assert torch.isnan(ds2[:, 0]).all() and torch.isnan(ds2[:, 1 + heads]).all()      # neighbours untouched
+    assert rel_err(dZ.cpu().numpy(), edZ) < TOL
+    # bit-reproducible
+    de2, ds1b = torch.empty_like(de), torch.empty_like(ds1)
+    K.gat_edge_grad(dA, s1d, Zd[:, F:F + heads], alpha, beta, Zd, dOd, t, heads, d, 0.2, mode_id, de2, ds1b)
+    assert torch.equal(de, de2) and torch.equal(ds1, ds1b)
+
+
+def test_attention_kernels_edge_cases_and_errors(K, dev):
+    _lib, gat, partition = pkg("_lib"), pkg("gat"), pkg("partition")
+    # empty matrix / all rows empty
+    Z = sp.csr_matrix((5, 4), dtype=np.float32)
+    dA, dT, perm, _, _ = _structure(K, Z, 1, 1 << 30)
+    alpha, beta = torch.zeros((2, 1), device=dev), torch.full((5, 2), float("nan"), device=dev)
+    s1, s2 = torch.zeros((5, 2), device=dev), torch.zeros((4, 2), device=dev)
+    K.gat_edge_softmax(dA, s1, s2, 2, 0.2, 1, 4, alpha, beta)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(beta.cpu().numpy(), 0.25)                 # softmax over 4 zero logits
+    out = torch.full((4, 2), float("nan"), device=dev)
+    K.csr_row_sums(dT, perm, alpha, 2, out)
+    assert (out == 0).all()
+    # a row missing from the lists is left alone; wrong shapes are refused loudly
+    A, _ = _graph(40, 30, 1, hub=False)
+    dA, _, _, _, _ = _structure(K, A, 1, 1 << 30)
+    with pytest.raises(_lib.PgcnError):
+        K.gat_edge_softmax(dA, torch.zeros((40, 2), device=dev), torch.zeros((30, 1), device=dev), 2, 0.2, 0, 30,
+                           torch.zeros((2, A.nnz), device=dev), torch.zeros((40, 2), device=dev))
+    with pytest.raises(_lib.PgcnError):
+        K.with_values(dA, torch.zeros(A.nnz - 1, device=dev))
+    L = _lib.lib()
+    assert L.pgcn_gat_edge_softmax_f32(None, None, 3, 0, None, 3, None, 0, None, 1, None, 1, 1, 0.2, 2, 3, None, None,
+                                       None) == -1                       # bad mode -> PGCN_EINVAL
+    assert b"pgcn_gat_edge_softmax_f32" in L.pgcn_last_error()
+
+
+@pytest.mark.parametrize("name,mtx", [("ref_gat_karateA", "karate.A.mtx"), ("ref_gat_gemat11pA", "gemat11p.A.mtx")])
+def test_engine_reference_mode_vs_reference_layers(dev, name, mtx):
+    """The product path on the GPU (P = 1, reference mode) against the reference's own dense layers."""
+    arrays, meta = golden(name)
+    M = _workers._pgat_module(0, 1, "reference", 1, gpu=True)
+    A = mmread(gpath(mtx))
+    n, f, L = meta["n"], meta["f"], meta["layers"]
+    eng = M.get_partitiont_of_adjacency_matrix(A, [0] * n, 0)
+    assert type(M._kernel_provider).__name__ == "HipKernels"
+    own = eng.part.owned.numpy()
+    H = torch.tensor(arrays["H"][own], requires_grad=True, device=dev)
+    layers = [M.PGAT(eng, f, f).to(dev) for _ in range(L)]
+    with torch.no_grad():
+        for i, layer in enumerate(layers):
+            layer.linear.weight.copy_(torch.from_numpy(arrays["W_%d" % i]))
+            layer.attention.copy_(torch.from_numpy(arrays["a_%d" % i]))
+    x = H
+    for i, layer in enumerate(layers):
+        x = layer(x)
+        assert rel_err(x.detach().cpu().numpy(), arrays["out_%d" % i][own]) < 1e-4
+    loss = M.local_loss(x, torch.from_numpy(own).to(dev) % f, n)
+    assert abs(float(loss.detach()) - meta["loss"]) < 1e-5 * meta["loss"]
+    loss.backward()
+    assert rel_err(H.grad.cpu().numpy(), arrays["dH"][own]) < 2e-3
+    for i, layer in enumerate(layers):
+        assert rel_err(layer.linear.weight.grad.cpu().numpy(), arrays["dW_%d" % i]) < 2e-3
+        assert rel_err(layer.attention.grad.cpu().numpy(), arrays["da_%d" % i]) < 2e-3
+
+
+@pytest.mark.parametrize("mtx,pv,P,mode,heads,f,L", CASES)
+def test_layers_multi_rank_real_kernels(dev, mtx, pv, P, mode, heads, f, L):
+    """P processes on the one GPU (gloo transport, host-staged), the real kernels everywhere."""
+    seed = 11
+    res = _spawn(_workers.gat_layers_worker, P, gpath(mtx), gpath(pv), mode, heads, f, L, seed, gpu=True)
+    A = _pattern(mtx, mode)
+    n = A.shape[0]
+    outs, loss, dH, dW, da = _expected(A, mode, heads, f, L, seed)
+    got_out = [np.zeros((n, f), np.float32) for _ in range(L)]
+    got_dH = np.zeros((n, f), np.float32)
+    for r in res:
+        assert r["provider"] == "HipKernels" and r["ok_halo"]
+        for i in range(L):
+            got_out[i][r["own"]] = r["outs"][i]
+        got_dH[r["own"]] = r["dH"]
+    for i in range(L):
+        assert rel_err(got_out[i], outs[i]) < 2e-5
+    assert abs(sum(r["loss"] for r in res) - loss) < 1e-5 * abs(loss)
+    assert rel_err(got_dH, dH) < 2e-4
+    for i in range(L):
+        assert rel_err(sum(r["dW"][i] for r in res), dW[i]) < 2e-4
+        assert rel_err(sum(r["da"][i] for r in res), da[i]) < 2e-4
+
+
+def test_run_reference_mode_real_kernels(dev):
+    _, meta = golden("ref_gat_run_karateA")
+    f, L, seed = meta["f"], meta["layers"], meta["seed"]
+    r2 = _spawn(_workers.gat_run_worker, 2, gpath(meta["mtx"]), gpath("karate.mtx.2.rp"), "reference", 1, L, f, seed, 50,
+                gpu=True)
+    assert r2[0]["provider"] == "HipKernels"
+    l2 = _losses(r2[0]["stdout"])
+    np.testing.assert_allclose(l2[:10], meta["losses"][:10], rtol=1e-5, atol=1.5e-4)
+    np.testing.assert_allclose(l2, meta["losses"], rtol=1e-2)
+
+
+def test_full_size_properties_reddit_like_gat(K, dev):
+    """BASELINE config 5 shape (Reddit-sized, 4 heads x 64) through size-independent properties:
+    attention rows sum to one, so a constant panel aggregates to itself; the hub rows (block path)
+    and the short rows agree with a float64 recomputation on a sample of rows; backward is linear."""
+    synth, partition, gat = pkg("synth"), pkg("partition"), pkg("gat")
+    n, row, col, val = synth.make_graph("reddit", seed=0, device=dev)
+    heads, d = 4, 64
+    F = heads * d
+    part = partition.build_partition(row, col, val, n, torch.zeros(n, dtype=torch.int64, device=dev), 0, 1,
+                                     with_transpose=False)
+    eng = gat.GatEngine(part, K, dev, None, mode="standard")
+    assert eng.graph.fwd_block.numel() > 0 and eng.nnz == row.numel()
+    st = eng.new_layer_state(heads, d)
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    s1 = torch.randn(n, heads, device=dev, generator=gen)
+    s2 = torch.randn(n, heads, device=dev, generator=gen)
+    ones = torch.ones(n, F, device=dev)
+    out = eng.forward(st, ones, s1, s2)
+    torch.cuda.synchronize()
+    assert float((out - 1).abs().max()) < 1e-5                             # sum_j alpha_ij = 1 for every row and head
+    Z = torch.randn(n, F, device=dev, generator=gen)
+    out = eng.forward(st, Z, s1, s2).clone()
+    # sample rows (the longest, some middle, the shortest) against float64 on the host
+    rp, cc = eng.fwd.rowptr.cpu().numpy(), eng.fwd.col.cpu().numpy()
+    order = np.argsort(-np.diff(rp))
+    sample = np.concatenate([order[:3], order[n // 2:n // 2 + 3], order[-3:]])
+    Zh, s1h, s2h = Z.cpu().double().numpy(), s1.cpu().double().numpy(), s2.cpu().double().numpy()
+    for i in sample:
+        cols = cc[rp[i]:rp[i + 1]]
+        raw = s1h[i][None, :] + s2h[cols]
+        e = np.where(raw > 0, raw, 0.2 * raw)
+        w = np.exp(e - e.max(0)); w /= w.sum(0)
+        exp = np.einsum("jk,jkd->kd", w, Zh[cols].reshape(-1, heads, d)).reshape(F)
+        assert rel_err(out[i].cpu().numpy(), exp) < 2e-5
+    # backward: linear in dOut, and <dOut, out(Z)> = <dZ, Z> for the aggregation alone (alpha fixed)
+    G = torch.randn(n, F, device=dev, generator=gen)
+    dZ1, ds1a, ds2a = eng.backward(st, G)
+    dZ2, ds1b, ds2b = eng.backward(st, 2 * G)
+    assert rel_err(dZ2.cpu().numpy(), 2 * dZ1.cpu().numpy()) < 1e-6
+    assert rel_err(ds1b.cpu().numpy(), 2 * ds1a.cpu().numpy()) < 1e-5
+    lhs = float((G.double() * out.double()).sum())
+    rhs = float((dZ1.double() * Z.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), 1.0)
+    # ds1 and ds2 both sum the same edge quantities
+    assert abs(float(ds1a.double().sum()) - float(ds2a.double().sum())) < 1e-3 * float(ds1a.double().abs().sum())
