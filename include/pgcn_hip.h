@@ -194,12 +194,21 @@ int pgcn_spmm_fixup_f32(const int32_t *fix, int64_t nfix, const int32_t *slot_id
  * pgcn_csr_row_sums_f32: out[i*ldo + k] = sum of plane k of src over row i's entries, read through
  * perm (NULL = identity): with the transposed structure and its permutation this is ds2_j = sum_i de_ij.
  * pgcn_csr_permute_f32: dst[k][p] = src[k][perm[p]] (values of A^T from values of A).
+ * rowstat (optional output of the softmax, [nrows x heads x 4] fp32, 16-byte aligned) = (s1, m, 1/D,
+ * exp(-m) or 0) per row and head; pgcn_gat_edge_weights_t_f32 recomputes from it the alpha planes
+ * in the storage order of the TRANSPOSED structure (rowptr_t/col_t; s2 indexed by its rows) --
+ * the same numbers as permuting alpha, without the 4-byte random gathers.
  * All sums run in a fixed order: bit-reproducible, no atomics.                                  */
 int pgcn_gat_edge_softmax_f32(const int64_t *rowptr, const int32_t *col, int64_t nrows, int64_t nnz,
                               const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
                               int64_t nrows_block, const float *s1, int64_t lds1, const float *s2,
                               int64_t lds2, int32_t heads, float slope, int32_t mode, int64_t n_global,
-                              float *alpha, float *beta, pgcn_stream_t stream);
+                              float *alpha, float *beta, float *rowstat, pgcn_stream_t stream);
+int pgcn_gat_edge_weights_t_f32(const int64_t *rowptr_t, const int32_t *col_t, int64_t nrows_t,
+                                int64_t nnz, const int32_t *rows_wave, int64_t nrows_wave,
+                                const int32_t *rows_block, int64_t nrows_block, const float *s2,
+                                int64_t lds2, const float *rowstat, int32_t heads, float slope,
+                                int32_t mode, float *alpha_t, pgcn_stream_t stream);
 int pgcn_gat_edge_grad_f32(const int64_t *rowptr, const int32_t *col, int64_t nrows, int64_t nnz,
                            const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
                            int64_t nrows_block, const float *s1, int64_t lds1, const float *s2,

@@ -52,7 +52,9 @@ SIGNATURES = {
                                            ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                            ctypes.POINTER(_i64)]),
     "pgcn_gat_edge_softmax_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32,
-                                                 ctypes.c_float, _i32, _i64, _vp, _vp, _vp]),
+                                                 ctypes.c_float, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "pgcn_gat_edge_weights_t_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32,
+                                                   ctypes.c_float, _i32, _vp, _vp]),
     "pgcn_gat_edge_grad_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                                               _vp, _i64, _vp, _i64, _vp, _i32, _i32, ctypes.c_float, _i32, _vp, _vp, _vp]),
     "pgcn_csr_row_sums_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),

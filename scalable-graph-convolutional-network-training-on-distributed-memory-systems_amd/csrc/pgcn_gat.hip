@@ -67,39 +67,115 @@ __device__ __forceinline__ bool pick_row(const int32_t *rows, int64_t nlist, int
     return true;
 }
 
+// alpha of the TRANSPOSED structure, recomputed from the per-row softmax statistics instead of
+// gathered through a permutation (a 4-byte random gather per entry from a GB-sized array):
+// entry (row j, col i) of A^T is entry (i, j) of A, alpha = (exp(e - m_i) - em_i) * inv_i with
+// e from s1_i (in rowstat) and s2_j.  rowstat (n x heads float4) stays in L2 / Infinity Cache.
 template <int TPR, int MODE>
-__global__ __launch_bounds__(kThreads) void gat_softmax_kernel(
+__global__ __launch_bounds__(kThreads) void gat_weights_t_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ rows,
+    int64_t nlist, const float *__restrict__ s2, int64_t lds2, const float4 *__restrict__ rowstat, int32_t heads,
+    float slope, float *__restrict__ alpha_t, int64_t nnz) {
+    int64_t j;
+    int lane;
+    if (!pick_row<TPR>(rows, nlist, j, lane)) return;
+    const int k = blockIdx.y;
+    const int64_t b = rowptr[j], e = rowptr[j + 1];
+    const float a2 = s2[j * lds2 + k];
+    float *ak = alpha_t + (int64_t)k * nnz;
+    for (int64_t p = b + lane; p < e; p += TPR) {
+        const float4 st = rowstat[(int64_t)col[p] * heads + k];
+        float r = st.x + a2;
+        if (MODE == 0) r = r > 0.f ? r : r * slope;
+        ak[p] = (expf(r - st.y) - st.w) * st.z;
+    }
+}
+
+// KH heads of a row per pass (KH = 1, 2, 4; s2 compact, lds2 % KH == 0): one col load and one
+// 4*KH-byte s2 gather per entry serve KH heads, two entries per lane and iteration are in flight.
+template <int KH> struct HeadVec;
+template <> struct HeadVec<1> { using T = float; };
+template <> struct HeadVec<2> { using T = float2; };
+template <> struct HeadVec<4> { using T = float4; };
+
+template <int TPR, int MODE, int KH>
+__global__ __launch_bounds__(kThreads) void gat_softmax_heads_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ rows,
     int64_t nlist, const float *__restrict__ s1, int64_t lds1, const float *__restrict__ s2, int64_t lds2,
-    int32_t heads, float slope, float nglobal, float *__restrict__ alpha, float *__restrict__ beta, int64_t nnz) {
+    int32_t heads, float slope, float nglobal, float *__restrict__ alpha, float *__restrict__ beta,
+    float4 *__restrict__ rowstat, int64_t nnz) {
+    using HV = typename HeadVec<KH>::T;
     __shared__ float red[4];
     int64_t i;
     int lane;
     if (!pick_row<TPR>(rows, nlist, i, lane)) return;
-    const int k = blockIdx.y;
+    const int kb = blockIdx.y * KH;
     const int64_t b = rowptr[i], e = rowptr[i + 1];
-    const float a = s1[i * lds1 + k];
-    const float *s2k = s2 + k;
-    auto score = [&](int64_t p) {
-        float r = a + s2k[(int64_t)col[p] * lds2];
-        if (MODE == 0) r = r > 0.f ? r : r * slope;
-        return r;
-    };
-    float m = MODE == 1 ? 0.f : -INFINITY;
-    for (int64_t p = b + lane; p < e; p += TPR) m = fmaxf(m, score(p));
-    m = group_reduce<TPR, true>(m, red);
-    float sum = 0.f;
-    for (int64_t p = b + lane; p < e; p += TPR) sum += expf(score(p) - m);
-    sum = group_reduce<TPR, false>(sum, red);
-    float em = 0.f, D = sum;
-    if (MODE == 1) {
-        em = expf(-m);
-        D = (nglobal - (float)(e - b)) * em + sum;
+    float a[KH], m[KH], sum[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+        a[k] = s1[i * lds1 + kb + k];
+        m[k] = MODE == 1 ? 0.f : -INFINITY;
+        sum[k] = 0.f;
     }
-    const float inv = D > 0.f ? 1.f / D : 0.f;
-    float *ak = alpha + (int64_t)k * nnz;
-    for (int64_t p = b + lane; p < e; p += TPR) ak[p] = (expf(score(p) - m) - em) * inv;
-    if (MODE == 1 && lane == 0) beta[i * heads + k] = em * inv;
+    auto scores = [&](int64_t p, float *r) {
+        const HV v = *reinterpret_cast<const HV *>(s2 + (int64_t)col[p] * lds2 + kb);
+        const float *vf = reinterpret_cast<const float *>(&v);
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            const float x = a[k] + vf[k];
+            r[k] = MODE == 0 ? (x > 0.f ? x : x * slope) : x;
+        }
+    };
+    for (int64_t p = b + lane; p < e; p += 2 * TPR) {
+        float r0[KH], r1[KH];
+        const bool two = p + TPR < e;
+        scores(p, r0);
+        scores(two ? p + TPR : p, r1);
+#pragma unroll
+        for (int k = 0; k < KH; ++k) m[k] = fmaxf(m[k], fmaxf(r0[k], r1[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) m[k] = group_reduce<TPR, true>(m[k], red);
+    for (int64_t p = b + lane; p < e; p += 2 * TPR) {
+        float r0[KH], r1[KH];
+        const bool two = p + TPR < e;
+        scores(p, r0);
+        scores(two ? p + TPR : p, r1);
+#pragma unroll
+        for (int k = 0; k < KH; ++k) sum[k] += expf(r0[k] - m[k]) + (two ? expf(r1[k] - m[k]) : 0.f);
+    }
+    float em[KH], inv[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+        sum[k] = group_reduce<TPR, false>(sum[k], red);
+        em[k] = 0.f;
+        float D = sum[k];
+        if (MODE == 1) {
+            em[k] = expf(-m[k]);
+            D = (nglobal - (float)(e - b)) * em[k] + sum[k];
+        }
+        inv[k] = D > 0.f ? 1.f / D : 0.f;
+    }
+    for (int64_t p = b + lane; p < e; p += 2 * TPR) {
+        float r0[KH], r1[KH];
+        const bool two = p + TPR < e;
+        scores(p, r0);
+        scores(two ? p + TPR : p, r1);
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            float *ak = alpha + (int64_t)(kb + k) * nnz;
+            ak[p] = (expf(r0[k] - m[k]) - em[k]) * inv[k];
+            if (two) ak[p + TPR] = (expf(r1[k] - m[k]) - em[k]) * inv[k];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            if (MODE == 1) beta[i * heads + kb + k] = em[k] * inv[k];
+            if (rowstat) rowstat[i * heads + kb + k] = make_float4(a[k], m[k], inv[k], em[k]);
+        }
+    }
 }
 
 template <int VEC> struct Vec;
@@ -186,6 +262,79 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_kernel(
     if (lane == 0) ds1[i * heads + k] = acc;
 }
 
+// All heads of a row in one pass: a team of lpe = pow2(F/4) lanes holds one whole row of Z as
+// float4 (F = heads*d <= 256); the dot products are reduced inside the d/4-lane segment of each
+// head (xor shuffles leave the sum in every lane of the segment).  U entries are in flight per team
+// and iteration -- the kernel is bound by gather latency, not by issue -- and lane u of head k's
+// segment finishes entry u of the batch, so the alpha loads and the de stores of a head are U
+// consecutive addresses.  One gather of the full row per entry instead of one per entry and head.
+template <int TPR, int MODE, int U>
+__global__ __launch_bounds__(kThreads) void gat_edge_grad_heads_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ rows,
+    int64_t nlist, const float *__restrict__ s1, int64_t lds1, const float *__restrict__ s2, int64_t lds2,
+    const float *__restrict__ alpha, const float *__restrict__ beta, const float *__restrict__ Z, int64_t ldz,
+    const float *__restrict__ dOut, int64_t ldo, const float *__restrict__ t, int32_t heads, int32_t d, int32_t lpe,
+    float slope, float *__restrict__ de, float *__restrict__ ds1, int64_t nnz) {
+    __shared__ float red[4];
+    int64_t i;
+    int lane;
+    if (!pick_row<TPR>(rows, nlist, i, lane)) return;
+    const int64_t b = rowptr[i], e = rowptr[i + 1];
+    const int nvec = heads * d / 4;
+    const int hl = d / 4;                  // lanes per head (>= U)
+    const int sub = lane & (lpe - 1);
+    const int team = lane / lpe;
+    const int nteam = TPR / lpe;
+    const int hk = sub / hl;
+    const int u_mine = sub % hl;           // which entry of the batch this lane finishes
+    const bool live = sub < nvec;
+    const bool fin = live && u_mine < U;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) g0 = reinterpret_cast<const float4 *>(dOut + i * ldo)[sub];
+    float a = 0.f, ti = 0.f, bi = 0.f;
+    if (fin) {
+        a = s1[i * lds1 + hk];
+        ti = t[i * heads + hk];
+        if (MODE == 1) bi = beta[i * heads + hk];
+    }
+    const float *ak = alpha + (int64_t)hk * nnz;
+    float *dk = de + (int64_t)hk * nnz;
+    float acc = 0.f;
+    for (int64_t p0 = b + (int64_t)team * U; p0 < e; p0 += (int64_t)nteam * U) {
+        int64_t c[U];
+        float dot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = col[p0 + u < e ? p0 + u : e - 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dot[u] = 0.f;
+            if (live) dot[u] = Vec<4>::dot(g0, reinterpret_cast<const float4 *>(Z + c[u] * ldz)[sub]);
+        }
+        for (int o = hl >> 1; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+        }
+        float dm = dot[0];
+        int64_t cm = c[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u) {
+            dm = u_mine == u ? dot[u] : dm;
+            cm = u_mine == u ? c[u] : cm;
+        }
+        const int64_t p = p0 + u_mine;
+        if (fin && p < e) {
+            float g = (ak[p] + bi) * (dm - ti);
+            if (MODE == 0) g *= (a + s2[cm * lds2 + hk]) > 0.f ? 1.f : slope;
+            dk[p] = g;
+            acc += g;
+        }
+    }
+    for (int k = 0; k < heads; ++k) {
+        const float v = group_reduce<TPR, false>((fin && hk == k) ? acc : 0.f, red);
+        if (lane == 0) ds1[i * heads + k] = v;
+    }
+}
+
 template <int TPR>
 __global__ __launch_bounds__(kThreads) void csr_row_sums_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ perm, const int32_t *__restrict__ rows,
@@ -238,7 +387,7 @@ extern "C" int pgcn_gat_edge_softmax_f32(const int64_t *rowptr, const int32_t *c
                                          const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
                                          int64_t nrows_block, const float *s1, int64_t lds1, const float *s2,
                                          int64_t lds2, int32_t heads, float slope, int32_t mode, int64_t n_global,
-                                         float *alpha, float *beta, pgcn_stream_t stream) {
+                                         float *alpha, float *beta, float *rowstat, pgcn_stream_t stream) {
     const char *who = "pgcn_gat_edge_softmax_f32";
     if (nrows < 0 || nnz < 0 || heads < 1 || heads > 65535 || lds1 < heads || lds2 < heads || (mode != 0 && mode != 1))
         return pgcn_set_error2(PGCN_EINVAL, who, "bad sizes");
@@ -248,19 +397,31 @@ extern "C" int pgcn_gat_edge_softmax_f32(const int64_t *rowptr, const int32_t *c
     if (nrows == 0 || l.nwave + l.nblock == 0) return PGCN_OK;
     if (!rowptr || !s1 || (nnz && (!col || !s2 || !alpha)) || (mode == 1 && !beta))
         return pgcn_set_error2(PGCN_EINVAL, who, "null pointer");
+    if ((uintptr_t)rowstat % 16) return pgcn_set_error2(PGCN_EINVAL, who, "rowstat must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const float ng = (float)n_global;
-#define PGCN_SOFTMAX(TPR, MODE, GRID, ROWS, N)                                                                   \
-    hipLaunchKernelGGL((gat_softmax_kernel<TPR, MODE>), GRID, dim3(kThreads), 0, s, rowptr, col, ROWS, N, s1, lds1, \
-                       s2, lds2, heads, slope, ng, alpha, beta, nnz)
+    int kh = 1;
+    if (heads % 4 == 0 && lds2 % 4 == 0 && (uintptr_t)s2 % 16 == 0) kh = 4;
+    else if (heads % 2 == 0 && lds2 % 2 == 0 && (uintptr_t)s2 % 8 == 0) kh = 2;
+    float4 *rs = reinterpret_cast<float4 *>(rowstat);
+#define PGCN_SOFTMAX(TPR, MODE, KH, GRID, ROWS, N)                                                                     \
+    hipLaunchKernelGGL((gat_softmax_heads_kernel<TPR, MODE, KH>), GRID, dim3(kThreads), 0, s, rowptr, col, ROWS, N, s1, \
+                       lds1, s2, lds2, heads, slope, ng, alpha, beta, rs, nnz)
+#define PGCN_SOFTMAX_K(TPR, MODE, GRIDFN, ROWS, N)                                      \
+    do {                                                                                \
+        if (kh == 4) PGCN_SOFTMAX(TPR, MODE, 4, GRIDFN(N, heads / 4), ROWS, N);         \
+        else if (kh == 2) PGCN_SOFTMAX(TPR, MODE, 2, GRIDFN(N, heads / 2), ROWS, N);    \
+        else PGCN_SOFTMAX(TPR, MODE, 1, GRIDFN(N, heads), ROWS, N);                     \
+    } while (0)
     if (l.nwave) {
-        if (mode == 0) PGCN_SOFTMAX(64, 0, wave_grid(l.nwave, heads), l.wave, l.nwave);
-        else PGCN_SOFTMAX(64, 1, wave_grid(l.nwave, heads), l.wave, l.nwave);
+        if (mode == 0) PGCN_SOFTMAX_K(64, 0, wave_grid, l.wave, l.nwave);
+        else PGCN_SOFTMAX_K(64, 1, wave_grid, l.wave, l.nwave);
     }
     if (l.nblock) {
-        if (mode == 0) PGCN_SOFTMAX(256, 0, block_grid(l.nblock, heads), l.block, l.nblock);
-        else PGCN_SOFTMAX(256, 1, block_grid(l.nblock, heads), l.block, l.nblock);
+        if (mode == 0) PGCN_SOFTMAX_K(256, 0, block_grid, l.block, l.nblock);
+        else PGCN_SOFTMAX_K(256, 1, block_grid, l.block, l.nblock);
     }
+#undef PGCN_SOFTMAX_K
 #undef PGCN_SOFTMAX
     PGCN_HIP_CHECK(hipGetLastError());
     return PGCN_OK;
@@ -298,10 +459,68 @@ extern "C" int pgcn_gat_edge_grad_f32(const int64_t *rowptr, const int32_t *col,
         else if (mode == 0) PGCN_EGRAD(TPR, 1, 0, GRID, ROWS, N);          \
         else PGCN_EGRAD(TPR, 1, 1, GRID, ROWS, N);                         \
     } while (0)
-    if (l.nwave) PGCN_EGRAD_VM(64, wave_grid(l.nwave, heads), l.wave, l.nwave);
-    if (l.nblock) PGCN_EGRAD_VM(256, block_grid(l.nblock, heads), l.block, l.nblock);
+    const int F4 = heads * d / 4, hl = d / 4;
+    if (v4 && F4 <= 64 && (hl & (hl - 1)) == 0) {       // all heads of a row in one pass
+        int team = 1;
+        while (team < F4) team *= 2;
+#define PGCN_EGRAD_H(TPR, MODE, UU, GRID, ROWS, N)                                                                      \
+    hipLaunchKernelGGL((gat_edge_grad_heads_kernel<TPR, MODE, UU>), GRID, dim3(kThreads), 0, s, rowptr, col, ROWS, N, s1, \
+                       lds1, s2, lds2, alpha, beta, Z, ldz, dOut, ldo, t, heads, d, team, slope, de, ds1, nnz)
+#define PGCN_EGRAD_HU(TPR, GRID, ROWS, N)                                                   \
+    do {                                                                                    \
+        if (hl >= 8) {                                                                      \
+            if (mode == 0) PGCN_EGRAD_H(TPR, 0, 8, GRID, ROWS, N);                          \
+            else PGCN_EGRAD_H(TPR, 1, 8, GRID, ROWS, N);                                    \
+        } else if (hl >= 4) {                                                               \
+            if (mode == 0) PGCN_EGRAD_H(TPR, 0, 4, GRID, ROWS, N);                          \
+            else PGCN_EGRAD_H(TPR, 1, 4, GRID, ROWS, N);                                    \
+        } else {                                                                            \
+            if (mode == 0) PGCN_EGRAD_H(TPR, 0, 1, GRID, ROWS, N);                          \
+            else PGCN_EGRAD_H(TPR, 1, 1, GRID, ROWS, N);                                    \
+        }                                                                                   \
+    } while (0)
+        if (l.nwave) PGCN_EGRAD_HU(64, wave_grid(l.nwave, 1), l.wave, l.nwave);
+        if (l.nblock) PGCN_EGRAD_HU(256, block_grid(l.nblock, 1), l.block, l.nblock);
+#undef PGCN_EGRAD_HU
+#undef PGCN_EGRAD_H
+    } else {
+        if (l.nwave) PGCN_EGRAD_VM(64, wave_grid(l.nwave, heads), l.wave, l.nwave);
+        if (l.nblock) PGCN_EGRAD_VM(256, block_grid(l.nblock, heads), l.block, l.nblock);
+    }
 #undef PGCN_EGRAD_VM
 #undef PGCN_EGRAD
+    PGCN_HIP_CHECK(hipGetLastError());
+    return PGCN_OK;
+}
+
+extern "C" int pgcn_gat_edge_weights_t_f32(const int64_t *rowptr_t, const int32_t *col_t, int64_t nrows_t, int64_t nnz,
+                                           const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
+                                           int64_t nrows_block, const float *s2, int64_t lds2, const float *rowstat,
+                                           int32_t heads, float slope, int32_t mode, float *alpha_t,
+                                           pgcn_stream_t stream) {
+    const char *who = "pgcn_gat_edge_weights_t_f32";
+    if (nrows_t < 0 || nnz < 0 || heads < 1 || heads > 65535 || lds2 < heads || (mode != 0 && mode != 1))
+        return pgcn_set_error2(PGCN_EINVAL, who, "bad sizes");
+    const RowLists l{rows_wave, nrows_wave, rows_block, nrows_block};
+    int rc = check_lists(who, nrows_t, l);
+    if (rc != PGCN_OK) return rc;
+    if (nrows_t == 0 || nnz == 0 || l.nwave + l.nblock == 0) return PGCN_OK;
+    if (!rowptr_t || !col_t || !s2 || !rowstat || !alpha_t) return pgcn_set_error2(PGCN_EINVAL, who, "null pointer");
+    if ((uintptr_t)rowstat % 16) return pgcn_set_error2(PGCN_EINVAL, who, "rowstat must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const float4 *rs = reinterpret_cast<const float4 *>(rowstat);
+#define PGCN_WT(TPR, MODE, GRID, ROWS, N)                                                                         \
+    hipLaunchKernelGGL((gat_weights_t_kernel<TPR, MODE>), GRID, dim3(kThreads), 0, s, rowptr_t, col_t, ROWS, N, s2, \
+                       lds2, rs, heads, slope, alpha_t, nnz)
+    if (l.nwave) {
+        if (mode == 0) PGCN_WT(64, 0, wave_grid(l.nwave, heads), l.wave, l.nwave);
+        else PGCN_WT(64, 1, wave_grid(l.nwave, heads), l.wave, l.nwave);
+    }
+    if (l.nblock) {
+        if (mode == 0) PGCN_WT(256, 0, block_grid(l.nblock, heads), l.block, l.nblock);
+        else PGCN_WT(256, 1, block_grid(l.nblock, heads), l.block, l.nblock);
+    }
+#undef PGCN_WT
     PGCN_HIP_CHECK(hipGetLastError());
     return PGCN_OK;
 }

@@ -8,7 +8,8 @@ matrix ``z1 + z2^T`` masked with ``A > 0``, a row softmax over all n columns and
               alpha = edge softmax(s1_i + s2_j)              (pgcn_gat_edge_softmax_f32)
               out[:, head k] = A_alpha_k . Zc[:, head k]     (the CSR SpMM kernels, val = alpha plane k)
     backward  de, ds1 = edge gradient                        (pgcn_gat_edge_grad_f32)
-              dZc[:, head k] = A_alpha_k^T . dOut[:, head k] (SpMM on the transposed structure, values permuted)
+              alpha^T planes recomputed from the row statistics   (pgcn_gat_edge_weights_t_f32)
+              dZc[:, head k] = A_alpha_k^T . dOut[:, head k] (SpMM on the transposed structure)
               ds2 = row sums of de over the transposed structure (pgcn_csr_row_sums_f32)
               halo rows of [dZ | ds2] travel back to their owners and are ADDED (reverse all-to-all-v)
 
@@ -104,7 +105,9 @@ class GatLayerState:
     alpha: torch.Tensor                  # [heads, nnz] head-major edge weights (the SpMM `val` planes)
     beta: torch.Tensor                   # [n_local, heads]  (reference mode)
     fwd_heads: List[object]              # forward structure with val = alpha[k]
+    rowstat: torch.Tensor                # [n_local, heads, 4] (s1, m, 1/D, exp(-m)) of the softmax rows
     Zc: Optional[torch.Tensor] = None    # [(n_local + n_halo), Fp] = [Z | s2 | pad] of local and halo rows
+    s2c: Optional[torch.Tensor] = None   # [(n_local + n_halo), heads] s2 of local and halo rows, compact (L2 resident)
     s1: Optional[torch.Tensor] = None
     out: Optional[torch.Tensor] = None
 
@@ -139,7 +142,8 @@ class GatEngine(BoundaryExchange):
         alpha = torch.zeros((heads, max(self.nnz, 1)), dtype=torch.float32, device=self.device)
         beta = torch.zeros((self.n_local, heads), dtype=torch.float32, device=self.device)
         views = [self.k.with_values(self.fwd, alpha[k]) for k in range(heads)]
-        return GatLayerState(heads, d, alpha, beta, views)
+        rowstat = torch.zeros((self.n_local, heads, 4), dtype=torch.float32, device=self.device)
+        return GatLayerState(heads, d, alpha, beta, views, rowstat)
 
     @staticmethod
     def padded_width(F: int, heads: int) -> int:
@@ -169,8 +173,11 @@ class GatEngine(BoundaryExchange):
             for w in self._exchange_all(send, self.round_send_off, Zc[n_p:], self.round_recv_off, Fp):
                 w()
         st.s1 = s1.contiguous()
-        self.k.gat_edge_softmax(self.fwd, st.s1, Zc[:, F:F + K], K, self.slope, self.mode_id, self.n_global,
-                                st.alpha, st.beta)
+        if st.s2c is None or st.s2c.shape != (n_p + n_h, K):
+            st.s2c = torch.empty((n_p + n_h, K), dtype=torch.float32, device=self.device)
+        st.s2c.copy_(Zc[:, F:F + K])        # compact: the per-entry s2 gathers stay in L2 instead of striding the panel
+        self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,
+                                st.alpha, st.beta, st.rowstat)
         out = torch.empty((n_p, F), dtype=torch.float32, device=self.device)
         for k in range(K):
             self.k.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], out[:, k * d:(k + 1) * d])
@@ -191,10 +198,10 @@ class GatEngine(BoundaryExchange):
         t = (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
         de = self._plane_scratch("de", K)
         ds1 = torch.empty((n_p, K), dtype=torch.float32, device=self.device)
-        self.k.gat_edge_grad(self.fwd, st.s1, st.Zc[:, F:F + K], st.alpha, st.beta, st.Zc, dOut, t, K, d,
+        self.k.gat_edge_grad(self.fwd, st.s1, st.s2c, st.alpha, st.beta, st.Zc, dOut, t, K, d,
                              self.slope, self.mode_id, de, ds1)
         alpha_t = self._plane_scratch("alpha_t", K)
-        self.k.csr_permute(st.alpha, self.perm, alpha_t)
+        self.k.gat_edge_weights_t(self.bwd, st.s2c, st.rowstat, K, self.slope, self.mode_id, alpha_t)
         bwd_heads = self._scratch.get(("bwd_heads", K))
         if bwd_heads is None:
             bwd_heads = [self.k.with_values(self.bwd, alpha_t[k]) for k in range(K)]

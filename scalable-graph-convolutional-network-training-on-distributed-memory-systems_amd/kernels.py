@@ -395,7 +395,7 @@ class HipKernels:
                                  % (what, rows, cols))
 
     def gat_edge_softmax(self, A: DeviceCSR, s1, s2, heads: int, slope: float, mode: int, n_global: int,
-                         alpha: torch.Tensor, beta: torch.Tensor) -> None:
+                         alpha: torch.Tensor, beta: torch.Tensor, rowstat: Optional[torch.Tensor] = None) -> None:
         self._check_rows(s1, A.nrows, heads, "s1")
         self._check_rows(s2, A.ncols, heads, "s2")
         self._check_rows(alpha, heads, alpha.shape[1], "alpha")
@@ -403,10 +403,28 @@ class HipKernels:
         nnz = A.col.numel()
         if (nnz and alpha.shape[1] != nnz) or alpha.stride(0) != alpha.shape[1] or beta.stride(0) != heads:
             raise _lib.PgcnError("alpha must be [heads, nnz] and beta [nrows, heads], both contiguous")
+        if rowstat is not None and not (rowstat.is_cuda and rowstat.dtype is torch.float32 and rowstat.is_contiguous()
+                                        and rowstat.numel() == A.nrows * heads * 4):
+            raise _lib.PgcnError("rowstat must be a contiguous fp32 [nrows, heads, 4] CUDA tensor")
         _lib.check(self.lib.pgcn_gat_edge_softmax_f32(
             A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, *self._lists(A), s1.data_ptr(),
             s1.stride(0), s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, alpha.data_ptr(), beta.data_ptr(),
-            self._stream()), "pgcn_gat_edge_softmax_f32")
+            _ptr(rowstat), self._stream()), "pgcn_gat_edge_softmax_f32")
+
+    def gat_edge_weights_t(self, AT: DeviceCSR, s2, rowstat: torch.Tensor, heads: int, slope: float, mode: int,
+                           alpha_t: torch.Tensor) -> None:
+        """alpha planes in the storage order of the transposed structure ``AT`` (rows = columns of A)."""
+        self._check_rows(s2, AT.nrows, heads, "s2")
+        nnz = AT.col.numel()
+        if alpha_t.dim() != 2 or alpha_t.shape[0] != heads or not alpha_t.is_contiguous() \
+                or (nnz and alpha_t.shape[1] != nnz):
+            raise _lib.PgcnError("alpha_t must be [heads, nnz] contiguous")
+        if not (rowstat.is_cuda and rowstat.dtype is torch.float32 and rowstat.is_contiguous()
+                and rowstat.numel() == AT.ncols * heads * 4):
+            raise _lib.PgcnError("rowstat must be a contiguous fp32 [ncols, heads, 4] CUDA tensor")
+        _lib.check(self.lib.pgcn_gat_edge_weights_t_f32(
+            AT.rowptr.data_ptr(), AT.col.data_ptr(), AT.nrows, nnz, *self._lists(AT), s2.data_ptr(), s2.stride(0),
+            rowstat.data_ptr(), heads, slope, mode, alpha_t.data_ptr(), self._stream()), "pgcn_gat_edge_weights_t_f32")
 
     def gat_edge_grad(self, A: DeviceCSR, s1, s2, alpha, beta, Z, dOut, t, heads: int, d: int, slope: float,
                       mode: int, de: torch.Tensor, ds1: torch.Tensor) -> None:

@@ -86,7 +86,7 @@ def _raw(A, s1, s2, k):
     return s1.numpy()[A.seg, k] + s2.numpy()[A.col, k]
 
 
-def _gat_edge_softmax(self, A, s1, s2, heads, slope, mode, n_global, alpha, beta):
+def _gat_edge_softmax(self, A, s1, s2, heads, slope, mode, n_global, alpha, beta, rowstat=None):
     nz = A.col.shape[0]
     ne = np.diff(A.rowptr) > 0
     starts = A.rowptr[:-1][ne]
@@ -110,6 +110,19 @@ def _gat_edge_softmax(self, A, s1, s2, heads, slope, mode, n_global, alpha, beta
         alpha[k, :nz] = torch.from_numpy((w - em[A.seg]) * inv[A.seg])
         if mode == 1:
             beta[:, k] = torch.from_numpy(em * inv)
+        if rowstat is not None:
+            rowstat[:, k, :] = torch.from_numpy(np.stack([s1.numpy()[:, k], m, inv, em], 1).astype(np.float32))
+
+
+def _gat_edge_weights_t(self, AT, s2, rowstat, heads, slope, mode, alpha_t):
+    nz = AT.col.shape[0]
+    rs = rowstat.numpy()
+    for k in range(heads):
+        st = rs[AT.col, k]                               # (s1, m, 1/D, exp(-m)) of the ORIGINAL row = column here
+        raw = st[:, 0] + s2.numpy()[AT.seg, k]
+        if mode == 0:
+            raw = np.where(raw > 0, raw, raw * np.float32(slope))
+        alpha_t[k, :nz] = torch.from_numpy(((np.exp(raw - st[:, 1]) - st[:, 3]) * st[:, 2]).astype(np.float32))
 
 
 def _gat_edge_grad(self, A, s1, s2, alpha, beta, Z, dOut, t, heads, d, slope, mode, de, ds1):
@@ -148,5 +161,6 @@ OracleKernels.prepare_gat = _prepare_gat
 OracleKernels.with_values = _with_values
 OracleKernels.gat_edge_softmax = _gat_edge_softmax
 OracleKernels.gat_edge_grad = _gat_edge_grad
+OracleKernels.gat_edge_weights_t = _gat_edge_weights_t
 OracleKernels.csr_row_sums = _csr_row_sums
 OracleKernels.csr_permute = _csr_permute

@@ -80,7 +80,8 @@ def test_attention_kernels_vs_oracle(K, dev, mode, heads, d, nslices, long_row):
     s1d = torch.from_numpy(s1).to(dev)
     alpha = torch.full((heads, nnz), float("nan"), device=dev)
     beta = torch.full((n, heads), float("nan"), device=dev)
-    K.gat_edge_softmax(dA, s1d, Zd[:, F:F + heads], heads, 0.2, mode_id, 1000, alpha, beta)
+    rowstat = torch.full((n, heads, 4), float("nan"), device=dev)
+    K.gat_edge_softmax(dA, s1d, Zd[:, F:F + heads], heads, 0.2, mode_id, 1000, alpha, beta, rowstat)
     torch.cuda.synchronize()
     ea, eb, ep = oracle.gat_scores_np(A, s1, s2, mode, 0.2, 1000)        # CSR order, columns ascending
     got = alpha.cpu().numpy()
@@ -116,6 +117,9 @@ def test_attention_kernels_vs_oracle(K, dev, mode, heads, d, nslices, long_row):
     K.csr_row_sums(dT, perm, de, heads, ds2[:, 1:1 + heads])             # strided output
     alpha_t = torch.empty_like(alpha)
     K.csr_permute(alpha, perm, alpha_t)
+    alpha_r = torch.full_like(alpha, float("nan"))                        # the same planes, recomputed from rowstat
+    K.gat_edge_weights_t(dT, torch.from_numpy(s2).to(dev), rowstat, heads, 0.2, mode_id, alpha_r)
+    assert rel_err(alpha_r.cpu().numpy(), alpha_t.cpu().numpy()) < 1e-6
     dZ = torch.full((m, F), float("nan"), device=dev)
     for k in range(heads):
         K.spmm(K.with_values(dT, alpha_t[k]), dOd[:, k * d:(k + 1) * d], dZ[:, k * d:(k + 1) * d])
@@ -157,7 +161,7 @@ def test_attention_kernels_edge_cases_and_errors(K, dev):
         K.with_values(dA, torch.zeros(A.nnz - 1, device=dev))
     L = _lib.lib()
     assert L.pgcn_gat_edge_softmax_f32(None, None, 3, 0, None, 3, None, 0, None, 1, None, 1, 1, 0.2, 2, 3, None, None,
-                                       None) == -1                       # bad mode -> PGCN_EINVAL
+                                       None, None) == -1                 # bad mode -> PGCN_EINVAL
     assert b"pgcn_gat_edge_softmax_f32" in L.pgcn_last_error()
 
 

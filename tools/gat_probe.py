@@ -45,14 +45,15 @@ def main():
     out["forward_ms"] = timed(lambda: eng.forward(st, Z, s1, s2))
     out["backward_ms"] = timed(lambda: eng.backward(st, G))
     Zc, Fh = st.Zc, F
-    out["softmax_ms"] = timed(lambda: K.gat_edge_softmax(eng.fwd, st.s1, Zc[:, Fh:Fh + heads], heads, eng.slope, eng.mode_id, n, st.alpha, st.beta))
+    out["softmax_ms"] = timed(lambda: K.gat_edge_softmax(eng.fwd, st.s1, st.s2c, heads, eng.slope, eng.mode_id, n, st.alpha, st.beta, st.rowstat))
     o = torch.empty(n, F, device=dev)
     out["spmm_heads_ms"] = timed(lambda: [K.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], o[:, k * d:(k + 1) * d]) for k in range(heads)])
     t = (G.view(n, heads, d) * st.out.view(n, heads, d)).sum(-1).contiguous()
     de = eng._plane_scratch("de", heads); ds1 = torch.empty(n, heads, device=dev)
-    out["edge_grad_ms"] = timed(lambda: K.gat_edge_grad(eng.fwd, st.s1, Zc[:, Fh:Fh + heads], st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1))
+    out["edge_grad_ms"] = timed(lambda: K.gat_edge_grad(eng.fwd, st.s1, st.s2c, st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1))
     at = eng._plane_scratch("alpha_t", heads)
     out["permute_ms"] = timed(lambda: K.csr_permute(st.alpha, eng.perm, at))
+    out["weights_t_ms"] = timed(lambda: K.gat_edge_weights_t(eng.bwd, st.s2c, st.rowstat, heads, eng.slope, eng.mode_id, at))
     ds2 = torch.empty(n, heads, device=dev)
     out["row_sums_ms"] = timed(lambda: K.csr_row_sums(eng.bwd, eng.perm, de, heads, ds2))
     bh = eng._scratch[("bwd_heads", heads)]
