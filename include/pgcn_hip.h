@@ -153,6 +153,20 @@ int pgcn_spmm_core_f32(const int32_t *work, int64_t nwork, const int32_t *tile_p
                        float *partial_ws, int64_t partial_ws_elems, int64_t nslots_total,
                        pgcn_stream_t stream);
 
+/* The densest tiles through the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32, k-ordered
+ * fmaf chains).  A tile is stored dense, pre-swizzled into the A-operand order:
+ *   vals[tile][w][s4][lane][e] = A[32 w + (lane & 31)][2 (4 s4 + e) + (lane >> 5)]   (16 384 fp32 per tile)
+ * work: 4 x int32 per piece {tile row, first tile, number of tiles, first slot}; a piece leaves a
+ * 128 x f block of partial sums in partial_ws (slot rows of f floats) for pgcn_spmm_fixup_f32.
+ * tile_panel[t]: the tile multiplies B rows [128 p, 128 p + 128) (rows >= ncols read as zero).
+ * Zeros of a dense tile are structural: a panel holding Inf / NaN takes an exact (slow) path that
+ * multiplies only where A != 0.  Any f (128 feature columns per workgroup); the panel is staged with
+ * 16-byte loads when f % 4 == 0, ldb % 4 == 0 and B is 16-byte aligned, scalar loads otherwise.   */
+int pgcn_spmm_dense_f32(const int32_t *work, int64_t nwork, const int32_t *tile_panel,
+                        const float *vals, const float *B, int64_t ldb, int64_t ncols, int32_t f,
+                        float *partial_ws, int64_t partial_ws_elems, int64_t nslots_total,
+                        pgcn_stream_t stream);
+
 /* Gather tasks and core pieces of one SpMM in ONE launch (512-thread workgroups): the work list
  * interleaves, per XCD, blocks of <= 16 gather tasks with core pieces, so that the L2-bound and the
  * LDS-bound work overlap on every CU.  work: 4 x int32 per workgroup {kind, a, b, 0}: kind 0 = gather

@@ -49,6 +49,7 @@ class DeviceCSR:
     seg: Optional[object] = None          # ctypes int64[nslices+1] (host) task segment bounds
     ws: Optional[torch.Tensor] = None     # fp32 work-space for split rows (grown on demand)
     core: Optional["DeviceCore"] = None   # dense-tile part (LDS-tiled kernel)
+    dense: Optional["DeviceDense"] = None  # densest tiles (fp32 matrix cores)
     fix_all: Optional[torch.Tensor] = None    # int32 [nfix_all,4] combined fix list (core + gather slots)
     slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
     nslots_total: int = 0
@@ -67,6 +68,15 @@ class DeviceCSR:
         nc = self.ncols if n_cols_touched is None else n_cols_touched
         nr = self.nrows if n_rows_out is None else n_rows_out
         return 8 * self.nnz + 8 * (self.nrows + 1) + 4 * f * nc + 4 * f * nr
+
+
+@dataclass
+class DeviceDense:
+    work: torch.Tensor
+    tile_panel: torch.Tensor
+    vals: torch.Tensor
+    npieces: int
+    nnz: int
 
 
 @dataclass
@@ -205,26 +215,37 @@ class HipKernels:
             d.ntasks, d.nfix, d.nslots = tasks.shape[0], fix.shape[0], nslots
             d.nslices, d.seg = csr.nslices if sc is not None else 1, seg
         d.nslots_total = d.nslots
-        if csr.core is not None:
+        if csr.core is not None or csr.dense is not None:
             self._attach_core(d, csr, fix if tasks is not None else None)
         return d
 
     def _attach_core(self, d: DeviceCSR, csr: HostCSR, fix_rem: Optional[np.ndarray]) -> None:
-        """Upload the dense-tile part and build the per-row slot lists: a row's partial sums are
-        its core pieces (in work order) followed by its gather-kernel slots."""
+        """Upload the tiled parts (LDS core, MFMA tiles) and build the per-row slot lists: a row's
+        partial sums are its core pieces (in work order), its dense pieces, then its gather-kernel slots."""
         from .partition import CORE_TR
         dev = self.device
-        hc = csr.core
+        hc, hd = csr.core, csr.dense
         ns_rem = d.nslots
-        work = hc.work.clone()
-        work[:, 3] += ns_rem                                   # core slots live behind the gather slots
-        d.core = DeviceCore(work.to(dev).contiguous(), hc.tile_panel.to(dev), hc.tile_base.to(dev),
-                            hc.seg_off.to(dev).contiguous(), hc.ccol.to(dev), hc.cval.to(dev),
-                            hc.npieces, hc.nnz)
-        wk = work.cpu().to(torch.int64)
+        pieces = []                                                # (tile row, first slot) of every piece
+        ns_core = 0
+        if hc is not None:
+            work = hc.work.clone()
+            work[:, 3] += ns_rem                                   # core slots live behind the gather slots
+            d.core = DeviceCore(work.to(dev).contiguous(), hc.tile_panel.to(dev), hc.tile_base.to(dev),
+                                hc.seg_off.to(dev).contiguous(), hc.ccol.to(dev), hc.cval.to(dev),
+                                hc.npieces, hc.nnz)
+            pieces.append(work.cpu().to(torch.int64)[:, [0, 3]])
+            ns_core = hc.nslots
+        if hd is not None:
+            work = hd.work.clone()
+            work[:, 3] += ns_rem + ns_core                         # ... and the MFMA pieces behind those
+            d.dense = DeviceDense(work.to(dev).contiguous(), hd.tile_panel.to(dev).contiguous(),
+                                  hd.vals.to(dev).contiguous(), hd.npieces, hd.nnz)
+            pieces.append(work.cpu().to(torch.int64)[:, [0, 3]])
+        wk = torch.cat(pieces)
         rit = torch.arange(CORE_TR, dtype=torch.int64)
         rows = (wk[:, 0:1] * CORE_TR + rit[None, :]).reshape(-1)
-        slots = (wk[:, 3:4] + rit[None, :]).reshape(-1)
+        slots = (wk[:, 1:2] + rit[None, :]).reshape(-1)
         seq = torch.arange(wk.shape[0], dtype=torch.int64).repeat_interleave(CORE_TR)
         ok = rows < csr.nrows
         rows, slots, seq = rows[ok], slots[ok], seq[ok]
@@ -244,9 +265,9 @@ class HipKernels:
         fix_all = torch.stack([urows, begin, counts, torch.zeros_like(urows)], 1).to(torch.int32)
         d.fix_all = fix_all.to(dev).contiguous()
         d.slot_ids = slots.to(torch.int32).to(dev).contiguous()
-        d.nslots_total = ns_rem + hc.nslots
+        d.nslots_total = ns_rem + ns_core + (hd.nslots if hd is not None else 0)
         d.nnz = csr.nnz
-        if d.ntasks and d.val is not None:
+        if d.ntasks and d.val is not None and hc is not None:
             fw = fused_work_list(d.seg, d.nslices, d.ntasks, hc.npieces, gb=self.fused_gb)
             d.fused_work = torch.from_numpy(fw).to(dev).contiguous()
 
@@ -292,7 +313,7 @@ class HipKernels:
         lib, check, stream = self.lib, _lib.check, self._stream
         if A.nrows == 0:
             return lambda B, C: None
-        if A.nnz == 0 and A.core is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
+        if A.nnz == 0 and A.core is None and A.dense is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
             if accumulate:
                 return lambda B, C: None
             if A.row_map is None:
@@ -300,7 +321,7 @@ class HipKernels:
             rows = A.row_map.long()
             return lambda B, C: C.index_fill_(0, rows, 0.0)
         rowptr, col, val, rmap = A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), _ptr(A.row_map)
-        if A.tasks is None and A.row_map is None and A.core is None:
+        if A.tasks is None and A.row_map is None and A.core is None and A.dense is None:
             nrows = A.nrows
             def simple(B, C):
                 check(lib.pgcn_spmm_csr_f32(rowptr, col, val, nrows, B.data_ptr(), ldb, C.data_ptr(), ldc, f,
@@ -313,23 +334,28 @@ class HipKernels:
         ws, ws_n = _ptr(A.ws), (0 if A.ws is None else A.ws.numel())
         tasks, ntasks, seg, nslices = A.tasks.data_ptr(), A.ntasks, A.seg, A.nslices
         nslots = A.nslots
-        if A.core is None:
+        if A.core is None and A.dense is None:
             fix, nfix = _ptr(A.fix), A.nfix
             def planned(B, C):
                 check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, rmap,
                                                  B.data_ptr(), ldb, C.data_ptr(), ldc, f, ws, ws_n, nslots, flags,
                                                  stream()), "pgcn_spmm_csr_plan_f32")
             return planned
-        # gather part (partial sums stay in the work-space) + LDS-tiled core + one combined fix-up
-        co = A.core
-        cw, cn, ctp, ctb, cso, ccol, cval = (co.work.data_ptr(), co.npieces, co.tile_panel.data_ptr(),
-                                             co.tile_base.data_ptr(), co.seg_off.data_ptr(), co.ccol.data_ptr(),
-                                             co.cval.data_ptr())
+        # gather part (partial sums stay in the work-space) + LDS-tiled core + MFMA tiles + one combined fix-up
+        co, de = A.core, A.dense
+        if co is not None:
+            cw, cn, ctp, ctb, cso, ccol, cval = (co.work.data_ptr(), co.npieces, co.tile_panel.data_ptr(),
+                                                 co.tile_base.data_ptr(), co.seg_off.data_ptr(), co.ccol.data_ptr(),
+                                                 co.cval.data_ptr())
+        else:
+            cw = cn = ctp = ctb = cso = ccol = cval = None
+        if de is not None:
+            dw, dn, dtp, dvals = de.work.data_ptr(), de.npieces, de.tile_panel.data_ptr(), de.vals.data_ptr()
         ncols, nst = A.ncols, A.nslots_total
         fixp, nfa, slots = A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr()
         gflags, fflags = flags | _lib.SPMM_NO_FIXUP, flags & _lib.SPMM_ACCUMULATE
         overlap = self.core_overlap and ntasks
-        if (self.fused and A.fused_work is not None and f <= 128 and f % 4 == 0 and ldb % 4 == 0 and ldc % 4 == 0
+        if (self.fused and A.fused_work is not None and co is not None and f <= 128 and f % 4 == 0 and ldb % 4 == 0 and ldc % 4 == 0
                 and B.data_ptr() % 16 == 0 and C.data_ptr() % 16 == 0):
             fw, nfw = A.fused_work.data_ptr(), A.fused_work.shape[0]
 
@@ -339,6 +365,9 @@ class HipKernels:
                     return hybrid(B, C)
                 check(lib.pgcn_spmm_fused_f32(fw, nfw, col, val, tasks, rmap, cw, ctp, ctb, cso, ccol, cval, b, ldb,
                                               ncols, c, ldc, f, ws, ws_n, nst, gflags, s), "pgcn_spmm_fused_f32")
+                if de is not None:
+                    check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s),
+                          "pgcn_spmm_dense_f32")
                 check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, c, ldc, f, fflags, s), "pgcn_spmm_fixup_f32")
         else:
             fused = None
@@ -357,8 +386,12 @@ class HipKernels:
             if ntasks:
                 check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, None, 0, rmap, b, ldb,
                                                  c, ldc, f, ws, ws_n, nslots, gflags, s), "pgcn_spmm_csr_plan_f32")
-            check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, cs),
-                  "pgcn_spmm_core_f32")
+            if de is not None:
+                check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s),
+                      "pgcn_spmm_dense_f32")
+            if co is not None:
+                check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, cs),
+                      "pgcn_spmm_core_f32")
             if overlap:
                 done = torch.cuda.Event()
                 done.record(self._side)

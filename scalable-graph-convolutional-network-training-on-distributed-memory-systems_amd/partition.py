@@ -43,11 +43,13 @@ class HostCSR:
     ngroups: int = 1                          # ... then by column group = col // group_width
     core: Optional["HostCore"] = None         # entries of dense tiles, stored for the LDS-tiled kernel
     row_flags: Optional[torch.Tensor] = None  # uint8 [nrows]: row also receives core partial sums
+    dense: Optional["HostDense"] = None       # the densest tiles, stored dense for the fp32 matrix cores
 
     @property
     def nnz(self) -> int:
-        """Stored entries of the whole block (gather part + dense core)."""
-        return int(self.col.numel()) + (self.core.nnz if self.core is not None else 0)
+        """Stored entries of the whole block (gather part + LDS core + MFMA tiles)."""
+        return int(self.col.numel()) + (self.core.nnz if self.core is not None else 0) + \
+            (self.dense.nnz if self.dense is not None else 0)
 
     def to_coo(self):
         """(row, col, val) of the whole block, core included (tests / checker only)."""
@@ -59,6 +61,9 @@ class HostCSR:
         if self.core is not None:
             cr, cc, cv = self.core.to_coo()
             r, c, v = torch.cat([r, cr]), torch.cat([c, cc]), torch.cat([v, cv])
+        if self.dense is not None:
+            dr, dc, dv = self.dense.coo
+            r, c, v = torch.cat([r, dr]), torch.cat([c, dc]), torch.cat([v, dv])
         return r, c, v
 
 
@@ -88,6 +93,9 @@ CORE_PG = int(os.environ.get("PGCN_CORE_PANEL_GROUP", "0"))      # >0: cut piece
 CORE_MIN_NNZ = int(os.environ.get("PGCN_CORE_MIN_NNZ", "262144"))  # smaller cores are not worth two more launches
 CORE_MIN_FRAC = float(os.environ.get("PGCN_CORE_MIN_FRAC", "0.1"))
 DEGREE_SORT = os.environ.get("PGCN_DEGREE_SORT", "1") != "0"
+DENSE_ON = os.environ.get("PGCN_DENSE", "1") != "0"
+DENSE_TAU = float(os.environ.get("PGCN_DENSE_TAU", "0.20"))       # tiles at least this full go to the matrix cores
+DENSE_PIECE = int(os.environ.get("PGCN_DENSE_PIECE", "8"))        # tiles per work piece (one 128-row partial block each)
 
 
 @dataclass
@@ -129,23 +137,84 @@ class HostCore:
         return r, c, self.cval
 
 
+@dataclass
+class HostDense:
+    """The densest tiles, stored DENSE and pre-swizzled into the A-operand order of
+    v_mfma_f32_32x32x2_f32 (pgcn_spmm_dense_f32):
+    vals[tile][w][s4][lane][e] = A[32 w + (lane & 31)][2 (4 s4 + e) + (lane >> 5)]."""
+    nrows: int
+    ncols: int
+    work: torch.Tensor        # int32 [npieces, 4] {tile row, first tile, number of tiles, first slot (local)}
+    tile_row: torch.Tensor    # int32 [ntiles]
+    tile_panel: torch.Tensor  # int32 [ntiles]
+    vals: torch.Tensor        # fp32 [ntiles, TR*TC]
+    coo: tuple                # (row, col, val) of the stored entries (host-side bookkeeping / checker)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.coo[0].numel())
+
+    @property
+    def npieces(self) -> int:
+        return int(self.work.shape[0])
+
+    @property
+    def nslots(self) -> int:
+        return self.npieces * CORE_TR
+
+
+def build_dense(r64, c64, v, tkey_local, ntiles, tile_row, tile_panel, nrows, ncols, piece: int = None) -> HostDense:
+    """``tkey_local`` numbers the dense tiles 0..ntiles-1 in (tile row, panel) order."""
+    import numpy as np
+    TR, TC = CORE_TR, CORE_TC
+    piece = DENSE_PIECE if piece is None else piece
+    dev = r64.device
+    i, k = r64 % TR, c64 % TC
+    w, il, s, kh = i // 32, i % 32, k // 2, k % 2
+    idx = ((w * 16 + s // 4) * 64 + kh * 32 + il) * 4 + s % 4
+    vals = torch.zeros(ntiles * TR * TC, dtype=torch.float32, device=dev)
+    vals.index_add_(0, tkey_local * (TR * TC) + idx, v.to(torch.float32))       # duplicates add, like an uncoalesced COO
+    ttr = tile_row.cpu().numpy()
+    run_start = np.r_[True, ttr[1:] != ttr[:-1]]
+    pos_in_run = np.arange(ntiles) - np.maximum.accumulate(np.where(run_start, np.arange(ntiles), 0))
+    newp = run_start | (pos_in_run % max(piece, 1) == 0)
+    kbeg = np.nonzero(newp)[0]
+    kcnt = np.r_[kbeg[1:], ntiles] - kbeg
+    lpt = np.argsort(-kcnt, kind="stable")
+    work = np.stack([ttr[kbeg][lpt], kbeg[lpt], kcnt[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
+    return HostDense(nrows, ncols, torch.from_numpy(work).to(dev), tile_row, tile_panel, vals.view(ntiles, TR * TC),
+                     (r64, c64, v.to(torch.float32)))
+
+
 def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
-               tau: float = None, emax: int = None):
-    """Separate the entries of dense tiles.  Returns (keep_mask, HostCore or None)."""
+               tau: float = None, emax: int = None, dense_tau: float = None):
+    """Separate the entries of dense tiles.  Returns (keep_mask, HostCore or None, HostDense or None):
+    tiles at least ``dense_tau`` full are stored dense for the matrix cores, the other tiles at least
+    ``tau`` full go to the LDS-tiled kernel."""
     tau = CORE_TAU if tau is None else tau
     emax = CORE_EMAX if emax is None else emax
+    if dense_tau is None:
+        dense_tau = DENSE_TAU if DENSE_ON else 2.0
     TR, TC, NG, RW = CORE_TR, CORE_TC, CORE_NG, CORE_RW
     dev = r.device
     if r.numel() == 0:
-        return None, None
+        return None, None, None
     r64, c64 = r.to(torch.int64), c.to(torch.int64)
     ncp = (ncols + TC - 1) // TC
     tkey = (r64 // TR) * ncp + c64 // TC
     uniq, inv, cnt = torch.unique(tkey, return_inverse=True, return_counts=True)
-    dense = cnt >= max(1, int(tau * TR * TC))
+    mfma = cnt >= max(1, int(dense_tau * TR * TC)) if dense_tau <= 1.0 else torch.zeros_like(cnt, dtype=torch.bool)
+    hdense, is_dense = None, None
+    if int(mfma.sum()):
+        is_dense = mfma[inv]
+        dmap = torch.cumsum(mfma.to(torch.int64), 0) - 1
+        dk = uniq[mfma]
+        hdense = build_dense(r64[is_dense], c64[is_dense], v[is_dense], dmap[inv[is_dense]], int(mfma.sum()),
+                             (dk // ncp).to(torch.int32), (dk % ncp).to(torch.int32), nrows, ncols)
+    dense = (cnt >= max(1, int(tau * TR * TC))) & ~mfma
     ntiles = int(dense.sum())
     if ntiles == 0:
-        return None, None
+        return (None if is_dense is None else ~is_dense), None, hdense
     is_core = dense[inv]
     if not emax:   # enough pieces to fill 2 workgroups x 256 CUs twice over, but no confetti
         emax = int(min(32768, max(4096, int(cnt[dense].sum()) // 1024)))
@@ -185,7 +254,7 @@ def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, nc
     work = np.stack([ttr[kbeg][lpt], kbeg[lpt], kend[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
     core = HostCore(nrows, ncols, torch.from_numpy(work).to(dev), tile_row, tile_panel, tile_base,
                     seg_off.contiguous(), ccol, cval)
-    return ~is_core, core
+    return (~is_core if is_dense is None else ~(is_core | is_dense)), core, hdense
 
 
 # XCD-sliced storage: above this many columns the dense panel no longer fits a 4 MiB L2
@@ -214,7 +283,8 @@ def pick_ngroups(ncols: int, nslices: int) -> int:
 
 def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
                  compact_rows: bool = False, nslices: Optional[int] = None, core: bool = False,
-                 tau: float = None, emax: int = None, ngroups: Optional[int] = None) -> HostCSR:
+                 tau: float = None, emax: int = None, ngroups: Optional[int] = None,
+                 dense_tau: float = None) -> HostCSR:
     """Sort by (row, col % nslices, col) and build CSR.  Duplicate entries are kept as
     separate stored entries (an uncoalesced COO sums them, PGCN.py:63).  With ``core``
     the entries of dense 128 x 128 tiles are split off into a HostCore (LDS-tiled kernel)."""
@@ -224,15 +294,16 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     S = nslices
     G = pick_ngroups(ncols, S) if ngroups is None else (ngroups if S > 1 else 1)
     gw = max(1, -(-ncols // G))          # columns per group
-    hcore, row_flags = None, None
+    hcore, hdense, row_flags = None, None, None
     if core and not compact_rows and r.numel():
-        keep, hcore = split_core(r, c, v, nrows, ncols, tau, emax)
-        if hcore is not None and tau is None and (hcore.nnz < CORE_MIN_NNZ or hcore.nnz < CORE_MIN_FRAC * r.numel()):
-            hcore = None          # a small core does not pay for the extra kernel + fix-up launches
-        if hcore is not None:
+        keep, hcore, hdense = split_core(r, c, v, nrows, ncols, tau, emax, dense_tau)
+        tiled = (hcore.nnz if hcore is not None else 0) + (hdense.nnz if hdense is not None else 0)
+        if tiled and tau is None and (tiled < CORE_MIN_NNZ or tiled < CORE_MIN_FRAC * r.numel()):
+            hcore = hdense = None     # a small tiled part does not pay for the extra kernel + fix-up launches
+        if hcore is not None or hdense is not None:
             r, c, v = r[keep], c[keep], v[keep]
             row_flags = torch.zeros(nrows, dtype=torch.uint8, device=dev)
-            trs = torch.unique(hcore.tile_row.to(torch.int64))
+            trs = torch.unique(torch.cat([h.tile_row.to(torch.int64) for h in (hcore, hdense) if h is not None]))
             rows = (trs[:, None] * CORE_TR + torch.arange(CORE_TR, device=dev)[None, :]).reshape(-1)
             row_flags[rows[rows < nrows]] = 1
     if r.numel():
@@ -262,17 +333,17 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     else:
         G = 1
     return HostCSR(nrows, ncols, rowptr, c.to(torch.int32).contiguous(),
-                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, G, hcore, row_flags)
+                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, G, hcore, row_flags, hdense)
 
 
 def csr_from_scipy(A, nslices: Optional[int] = None, core: bool = False, tau: float = None,
-                   emax: int = None, ngroups: Optional[int] = None) -> HostCSR:
+                   emax: int = None, ngroups: Optional[int] = None, dense_tau: float = None) -> HostCSR:
     """Convenience for tests / tools: a scipy sparse matrix -> HostCSR (optionally sliced)."""
     import numpy as np
     A = A.tocoo()
     return csr_from_coo(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
                         torch.from_numpy(A.data.astype(np.float32)), A.shape[0], A.shape[1],
-                        nslices=nslices, core=core, tau=tau, emax=emax, ngroups=ngroups)
+                        nslices=nslices, core=core, tau=tau, emax=emax, ngroups=ngroups, dense_tau=dense_tau)
 
 
 @dataclass

@@ -135,7 +135,8 @@ def test_spmm_dense_core_lds_kernel(K, dev, f, nslices):
                                ngroups=3 if nslices > 1 else None)
     assert h.core is not None and h.core.nnz > 0.2 * A.nnz and h.ngroups == (3 if nslices > 1 else 1)
     d = K.prepare(h)
-    assert d.core is not None and d.nslots_total == d.nslots + h.core.nslots
+    assert d.core is not None
+    assert d.nslots_total == d.nslots + h.core.nslots + (h.dense.nslots if h.dense is not None else 0)
     rng = np.random.default_rng(f)
     B = rng.random((n, f), dtype=np.float32) * 2 - 1
     ref = oracle.spmm(A, B)
@@ -174,6 +175,64 @@ def test_spmm_dense_core_lds_kernel(K, dev, f, nslices):
     finally:
         K.fused = was
     assert torch.equal(C5, C) and torch.equal(C6, C3)
+
+
+@pytest.mark.parametrize("f", [4, 30, 64, 128, 132, 256])
+@pytest.mark.parametrize("nslices", [1, 8])
+def test_spmm_mfma_dense_tiles(K, dev, f, nslices):
+    """The densest tiles go through the fp32 matrix cores (pgcn_spmm_dense_f32), the rest through the
+    LDS core and the gather kernel; one fix-up.  Same tolerance as every other SpMM path; zeros of a
+    dense tile stay structural when the panel holds Inf."""
+    partition = pkg("partition")
+    rng = np.random.default_rng(f + nslices)
+    n, m = 700, 520
+    D = (rng.random((n, m)) < 0.02).astype(np.float32)
+    D[:256, :256] = rng.random((256, 256)) < 0.6
+    D[256:384, :128] = rng.random((128, 128)) < 0.12
+    D[640:, 384:] = rng.random((60, 136)) < 0.5
+    D[5, :] = 0                                              # an empty row inside a dense tile
+    D[:, 300] = 0                                            # a column nobody references
+    D *= rng.standard_normal((n, m)).astype(np.float32)
+    A = sp.csr_matrix(D)
+    h = partition.csr_from_scipy(A, nslices=nslices, core=True, tau=0.05, emax=3000, dense_tau=0.2,
+                                 ngroups=2 if nslices > 1 else None)
+    assert h.dense is not None and h.dense.tile_row.numel() == 5 and h.core is not None
+    d = K.prepare(h)
+    assert d.dense is not None and d.nslots_total == d.nslots + h.core.nslots + h.dense.nslots
+    B = rng.random((m, f), dtype=np.float32) * 2 - 1
+    ref = oracle.spmm(A, B)
+    Bd = torch.from_numpy(B).to(dev)
+    C = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, Bd, C)
+    torch.cuda.synchronize()
+    assert rel_err(C.cpu().numpy(), ref) < TOL
+    C2 = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, Bd, C2)
+    assert torch.equal(C, C2)                                # deterministic
+    base = rng.random((n, f), dtype=np.float32)
+    C3 = torch.from_numpy(base).to(dev)
+    K.spmm(d, Bd, C3, accumulate=True)
+    assert rel_err(C3.cpu().numpy(), ref + base) < TOL
+    # a panel with an odd leading dimension / unaligned base takes the scalar staging path
+    wide = torch.zeros((m, f + 3), device=dev)
+    wide[:, 1:f + 1] = Bd
+    C4 = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, wide[:, 1:f + 1], C4)
+    assert rel_err(C4.cpu().numpy(), ref) < TOL
+    # Inf in a feature row no entry references: nothing leaks.  Inf in a referenced row: exactly the
+    # rows with an entry in that column see it (the exact path multiplies only where A != 0).
+    B2 = B.copy(); B2[300] = np.inf
+    C5 = torch.empty((n, f), device=dev)
+    K.spmm(d, torch.from_numpy(B2).to(dev), C5)
+    assert np.isfinite(C5.cpu().numpy()).all() and rel_err(C5.cpu().numpy(), ref) < TOL
+    B3 = B.copy(); B3[17, 0] = np.inf
+    C6 = torch.empty((n, f), device=dev)
+    K.spmm(d, torch.from_numpy(B3).to(dev), C6)
+    got = C6.cpu().numpy()
+    hit = np.asarray(A[:, 17].todense()).ravel() != 0
+    assert hit.sum() > 100                                   # column 17 crosses the dense tiles
+    assert np.isinf(got[hit, 0]).all() and np.isfinite(got[~hit]).all() and np.isfinite(got[:, 1:]).all()
+    assert rel_err(got[:, 1:], ref[:, 1:]) < TOL
 
 
 def test_spmm_edge_cases(K, dev):

@@ -176,3 +176,46 @@ def test_synthetic_graph_is_normalised_symmetric():
     assert abs(A - ref).max() < 1e-6
     n2, r2, c2, v2 = synth.make_graph(500, 6000, seed=1)
     assert torch.equal(row, r2) and torch.equal(val, v2)
+
+
+def test_mfma_tiles_layout_and_bookkeeping():
+    """The densest tiles are stored dense in the A-operand order of v_mfma_f32_32x32x2_f32
+    (vals[t][w][s4][lane][e] = A[32 w + (lane & 31)][2 (4 s4 + e) + (lane >> 5)]): un-swizzling gives back
+    exactly the entries, every entry lives in exactly one of the three parts, pieces tile the tiles."""
+    partition = pkg("partition")
+    rng = np.random.default_rng(4)
+    n, m = 700, 520
+    D = (rng.random((n, m)) < 0.02).astype(np.float32)
+    D[:256, :256] = rng.random((256, 256)) < 0.6            # 4 MFMA tiles
+    D[256:384, :128] = rng.random((128, 128)) < 0.12        # an LDS-core tile
+    D[640:, 384:] = rng.random((60, 136)) < 0.5             # ragged corner: 60 x 128 (dense) and 60 x 8 (sparse)
+    D *= rng.standard_normal((n, m)).astype(np.float32)
+    A = sp.coo_matrix(D)
+    h = partition.csr_from_scipy(A, nslices=1, core=True, tau=0.05, emax=3000, dense_tau=0.2)
+    assert h.dense is not None and h.core is not None and h.col.numel() > 0
+    hd = h.dense
+    nt = hd.tile_row.numel()
+    assert nt == 5 and h.nnz == A.nnz and hd.nnz + h.core.nnz + h.col.numel() == A.nnz
+    i, k = np.meshgrid(np.arange(128), np.arange(128), indexing="ij")
+    idx = ((i // 32 * 16 + (k // 2) // 4) * 64 + (k % 2) * 32 + i % 32) * 4 + (k // 2) % 4
+    assert np.array_equal(np.sort(idx.ravel()), np.arange(128 * 128))            # a permutation of the tile
+    vals = hd.vals.numpy()
+    Dp = np.zeros((768, 640), np.float32); Dp[:n, :m] = D
+    for t in range(nt):
+        tr, tp = int(hd.tile_row[t]), int(hd.tile_panel[t])
+        np.testing.assert_array_equal(vals[t][idx], Dp[tr * 128:(tr + 1) * 128, tp * 128:(tp + 1) * 128])
+    work = hd.work.numpy()
+    assert sorted(np.concatenate([np.arange(b, b + c) for _, b, c, _ in work]).tolist()) == list(range(nt))
+    assert np.array_equal(np.sort(work[:, 3]), np.arange(len(work)) * 128)       # one 128-row slot block per piece
+    for tr_, b, c, _ in work:
+        assert (hd.tile_row.numpy()[b:b + c] == tr_).all() and c <= partition.DENSE_PIECE
+    # the whole block is what went in
+    r, c, v = h.to_coo()
+    got = sp.coo_matrix((v.numpy(), (r.numpy(), c.numpy())), shape=(n, m)).toarray()
+    np.testing.assert_array_equal(got, D)
+    # rows of MFMA / core tiles are flagged (their gather-part sums go through the fix-up)
+    flagged = np.nonzero(h.row_flags.numpy())[0]
+    assert set(flagged) == set(range(0, 384)) | set(range(640, 700))
+    # switched off: everything dense goes to the LDS core
+    h2 = partition.csr_from_scipy(A, nslices=1, core=True, tau=0.05, emax=3000, dense_tau=2.0)
+    assert h2.dense is None and h2.core.nnz == hd.nnz + h.core.nnz
