@@ -117,6 +117,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    wd = float(os.environ.get("PGCN_BENCH_WATCHDOG", "0"))    # debugging aid: dump every thread's stack and exit
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
+    t_start = time.time()
+
+    def stage(msg):
+        if wd > 0:
+            print("[bench rank %d +%.1fs] %s" % (rank, time.time() - t_start, msg), file=sys.stderr, flush=True)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
@@ -150,13 +159,16 @@ def main():
         P._all_reduce(lo, dist.ReduceOp.MIN)
         P._all_reduce(hi, dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "ranks generated different graphs"
+    stage("graph ready")
     part = partition.build_partition(row, col, val, n, partvec, rank, world)
     del row, col, val
+    stage("partition built")
     K = kernels.HipKernels(dev)
     exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
     eng = engine.AggregationEngine(part, K, dev, exch)
     torch.cuda.synchronize()
     setup_s = time.time() - t0
+    stage("engine ready")
 
     # ---- model: L x PGCN(f, f), PGCN.py:194-200 ----------------------------------
     P.device, P.myrank, P.world_size = dev, rank, world
@@ -182,6 +194,7 @@ def main():
     timer = KernelTimer(K, dev)
     for _ in range(args.warmup):
         loss = step()
+        stage("warm-up step done")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -225,6 +238,9 @@ def main():
         if eng.A_loc.core is not None:
             kname += " + spmm_core_kernel<4> (LDS-tiled dense core, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.core.nnz / max(eng.A_loc.nnz, 1))
+        if getattr(eng.A_loc, "dense", None) is not None:
+            kname += " + spmm_dense_kernel<4> (fp32-MFMA tiles, %.0f%% of the entries)" % (
+                100.0 * eng.A_loc.dense.nnz / max(eng.A_loc.nnz, 1))
         kname += " + fix-up; one launch group, timed as a whole"
         roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -249,7 +265,9 @@ def main():
                    "n": n, "nnz": nnz, "f": f, "layers": L, "spmm_per_epoch": 2 * L,
                    "partition": "random" if world > 1 else "none", "exchange": exch.name if exch else "none",
                    "xcd_slices": eng.A_loc.nslices, "chunk": K.chunk,
-                   "core_tile_fill_min": partition.CORE_TAU, "exchange_rounds": part.rounds},
+                   "core_tile_fill_min": partition.CORE_TAU,
+                   "mfma_tile_fill_min": partition.DENSE_TAU if partition.DENSE_ON else None,
+                   "exchange_rounds": part.rounds},
         "roofline": roofline, "ms_per_epoch": ms_per_step, "loss": loss_val, "setup_s": setup_s,
     }
     if world > 1:

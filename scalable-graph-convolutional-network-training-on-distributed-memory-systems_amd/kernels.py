@@ -372,6 +372,16 @@ class HipKernels:
         else:
             fused = None
 
+        side_first = os.environ.get("PGCN_CORE_OVERLAP", "0") == "2"
+
+        def tiled(b, cs):
+            if de is not None:
+                check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, cs),
+                      "pgcn_spmm_dense_f32")
+            if co is not None:
+                check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, cs),
+                      "pgcn_spmm_core_f32")
+
         def hybrid(B, C):
             b, c, s = B.data_ptr(), C.data_ptr(), stream()
             cs = s
@@ -383,15 +393,13 @@ class HipKernels:
                 ev.record(main)
                 self._side.wait_event(ev)
                 cs = self._side.cuda_stream
+                if side_first:
+                    tiled(b, cs)
             if ntasks:
                 check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, None, 0, rmap, b, ldb,
                                                  c, ldc, f, ws, ws_n, nslots, gflags, s), "pgcn_spmm_csr_plan_f32")
-            if de is not None:
-                check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s),
-                      "pgcn_spmm_dense_f32")
-            if co is not None:
-                check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, cs),
-                      "pgcn_spmm_core_f32")
+            if not (overlap and side_first):
+                tiled(b, cs)
             if overlap:
                 done = torch.cuda.Event()
                 done.record(self._side)
