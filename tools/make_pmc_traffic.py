@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from a pmc_summary.py text (tools/final_profile.sh): per-launch L2<->fabric bytes of the
+SpMM launch group.  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md: the
+counter tallies 128-byte fabric reads at 64 B).  usage: make_pmc_traffic.py SUMMARY.txt OUT.json [source-name]"""
+import json
+import re
+import sys
+
+
+def main():
+    txt = open(sys.argv[1]).read().splitlines()
+    per, cur = {}, None
+    for ln in txt:
+        m = re.search(r"counter_collection\.csv \| .*::(\w+)<", ln)
+        if m:
+            cur = per.setdefault(m.group(1), {})
+            continue
+        m = re.match(r"\s+(\w+)\s+n=(\d+)\s+mean=([\d.e+]+)", ln)
+        if m and cur is not None:
+            cur[m.group(1)] = float(m.group(3))
+        if "kernel_trace.csv" in ln:
+            cur = None
+            m = re.search(r"::(\w+)<.*mean=([\d.]+) us", ln)
+            if m:
+                per.setdefault(m.group(1), {}).setdefault("mean_us", float(m.group(2)))
+    read = sum(2 * 1024 * v.get("FETCH_SIZE", 0) for v in per.values())
+    write = sum(1024 * v.get("WRITE_SIZE", 0) for v in per.values())
+    out = {"workload": "reddit", "n_gpus": 1, "f": 128,
+           "kernel": "A_loc.H launch group: " + " + ".join(sorted(per)),
+           "hbm_bytes_per_launch": int(read + write), "read_bytes": int(read), "write_bytes": int(write),
+           "per_kernel": per,
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes with --kernel-trace "
+                   "only (tools/final_profile.sh), mean over the dispatches of `tools/spmm_probe.py --once s8c1024k` (same plan "
+                   "as bench.py).  FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B fabric reads at 64 B). "
+                   "These are L2<->fabric bytes: Infinity-Cache (MALL) hits are included, so true HBM traffic is <= this figure.",
+           "source": sys.argv[3] if len(sys.argv) > 3 else sys.argv[1]}
+    with open(sys.argv[2], "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "read_bytes", "write_bytes")}))
+
+
+if __name__ == "__main__":
+    main()
