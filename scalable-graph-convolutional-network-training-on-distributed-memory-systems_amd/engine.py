@@ -187,7 +187,10 @@ class BoundaryExchange:
         key = (name, f)
         t = self._buf.get(key)
         if t is None or t.shape[0] < rows:
-            t = torch.empty((max(rows, 1), f), dtype=torch.float32, device=self.device)
+            # zeros, not empty: a slab row that has not been received yet may sit in a staged panel of the
+            # tiled kernels (multiplied by structural zeros) -- stale finite data is harmless, NaN bit patterns
+            # of fresh memory would send the MFMA tiles down their exact (slow) path
+            t = torch.zeros((max(rows, 1), f), dtype=torch.float32, device=self.device)
             self._buf[key] = t
         return t
 
