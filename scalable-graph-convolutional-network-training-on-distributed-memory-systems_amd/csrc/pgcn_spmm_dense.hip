@@ -18,9 +18,9 @@
 // [32 w, 32 w + 32) x 128 features in 4 x 16 accumulator registers over all tiles of the piece and
 // writes one 128 x f block of partial sums (combined by pgcn_spmm_fixup_f32, like core pieces).
 //
-// Full panels are staged with asynchronous global -> LDS copies (global_load_lds_dwordx4: no
-// staging registers, all 16 copies of a thread in flight at once); two workgroups share a CU, one
-// stages while the other multiplies.
+// Panels are staged in halves with asynchronous global -> LDS copies (global_load_lds_dwordx4: no
+// staging registers) and the tile loop is software-pipelined over the halves: the copies of the next
+// half are in flight while the matrix cores work on the current one; two workgroups share a CU.
 //
 // Zeros of the dense tile are structural: 0 x Inf must not produce NaN where the sparse matrix has
 // no entry.  A non-finite value in a panel makes every row of the tile's sums non-finite, so the
@@ -40,8 +40,85 @@ constexpr size_t kSmem = (size_t)kT * kT * sizeof(float);
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// One pass over the tiles of a piece.  EXACT = false: matrix cores.  EXACT = true: products only
-// where A != 0 (k ascending, fmaf) -- the path for panels that hold Inf / NaN.
+// Stage rows [64 h, 64 h + 64) of a tile's feature panel into their half of the LDS image.
+__device__ __forceinline__ void stage_half(const float *__restrict__ B, int64_t ldb, int64_t ncols, int64_t prow0,
+                                           int fcol0, int fw, int vec, int h, int w, float *smem) {
+    float4 *s4p = reinterpret_cast<float4 *>(smem) + h * (kT / 2) * 32;
+    const int64_t r0 = prow0 + h * (kT / 2);
+    if (vec && fw == kT && r0 + kT / 2 <= ncols) {
+        // full half panel: 8 asynchronous global -> LDS copies per thread, no staging registers.  The LDS
+        // image is lane-linear, so the rotation of the odd rows is applied to the SOURCE column.
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = q * kThreads + (int)threadIdx.x;
+            const int row = idx >> 5, c4 = ((idx & 31) - 8 * (row & 1)) & 31;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(B + (r0 + row) * ldb + fcol0 + c4 * 4),
+                (__attribute__((address_space(3))) void *)(s4p + q * kThreads + w * 64), 16, 0, 0);
+        }
+    } else if (vec) {
+        const int f4 = fw >> 2;
+#pragma unroll 4
+        for (int q = 0; q < 8; ++q) {
+            const int idx = q * kThreads + (int)threadIdx.x;
+            const int row = idx >> 5, c4 = idx & 31;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + row < ncols && c4 < f4) v = *reinterpret_cast<const float4 *>(B + (r0 + row) * ldb + fcol0 + c4 * 4);
+            s4p[row * 32 + ((c4 + 8 * (row & 1)) & 31)] = v;
+        }
+    } else {                             // any width / alignment: scalar staging
+        float *sp = smem + h * (kT / 2) * kT;
+        for (int idx = threadIdx.x; idx < (kT / 2) * kT; idx += kThreads) {
+            const int row = idx >> 7, c = idx & 127;
+            float v = 0.f;
+            if (r0 + row < ncols && c < fw) v = B[(r0 + row) * ldb + fcol0 + c];
+            sp[row * kT + ((c + 32 * (row & 1)) & 127)] = v;
+        }
+    }
+}
+
+// k rows [64 h, 64 h + 64) of one tile.  EXACT = false: matrix cores, `a` = this wave's 8 float4 of
+// A operands of the half.  EXACT = true: products only where A != 0 (k ascending, fmaf).
+template <int NBLK, bool EXACT>
+__device__ __forceinline__ void compute_half(const float4 (&a)[8], const float *__restrict__ tv, int h, int w, int hi,
+                                             int lo, const float *smem, f32x16 (&acc)[NBLK]) {
+    if (!EXACT) {
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const float av4[4] = {a[s4].x, a[s4].y, a[s4].z, a[s4].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 64 * h + 2 * (4 * s4 + e) + hi;
+                const float *brow = smem + k * kT;
+                float b[NBLK];
+#pragma unroll
+                for (int nb = 0; nb < NBLK; ++nb) b[nb] = brow[(nb * 32 + lo + 32 * hi) & 127];
+#pragma unroll
+                for (int nb = 0; nb < NBLK; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[e], b[nb], acc[nb], 0, 0, 0);
+            }
+        }
+    } else {
+        // this lane owns D[row = (r & 3) + 8 (r >> 2) + 4 hi][col = lo] of every 32 x 32 block
+        for (int k = 64 * h; k < 64 * h + 64; ++k) {
+            const int s = k >> 1, kh = k & 1;
+            float b[NBLK];
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) b[nb] = smem[k * kT + ((nb * 32 + lo + 32 * kh) & 127)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float x = tv[((w * 16 + (s >> 2)) * 64 + kh * 32 + il) * 4 + (s & 3)];
+#pragma unroll
+                for (int nb = 0; nb < NBLK; ++nb) acc[nb][r] = x != 0.f ? fmaf(x, b[nb], acc[nb][r]) : acc[nb][r];
+            }
+        }
+    }
+}
+
+// One pass over the tiles of a piece, software-pipelined over half panels: while the matrix cores
+// work on one half of the LDS image, the asynchronous copies of the next half (of this tile or of
+// the next one) and the loads of its A operands are in flight; one barrier per half.
 template <int NBLK, bool EXACT>
 __device__ __forceinline__ void dense_piece(const int4 wk, const int32_t *__restrict__ tile_panel,
                                             const float *__restrict__ vals, const float *__restrict__ B, int64_t ldb,
@@ -50,82 +127,31 @@ __device__ __forceinline__ void dense_piece(const int4 wk, const int32_t *__rest
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, lo = lane & 31;
-    const int f4 = fw >> 2;              // only used on the vector paths (fw % 4 == 0 there)
+    float4 a0[8], a1[8];
+    auto load_a = [&](int64_t ti, int h, float4 (&a)[8]) {
+        if (!EXACT) {
+            const float4 *av = reinterpret_cast<const float4 *>(vals + ti * (int64_t)(kT * kT)) + (w * 16 + 8 * h) * 64 + lane;
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) a[s4] = av[s4 * 64];
+        }
+    };
+    __syncthreads();                     // (second pass: the LDS image of the first pass is no longer read)
+    stage_half(B, ldb, ncols, (int64_t)tile_panel[wk.y] * kT, fcol0, fw, vec, 0, w, smem);
+    load_a(wk.y, 0, a0);
     for (int t = 0; t < wk.z; ++t) {
         const int64_t ti = (int64_t)wk.y + t;
         const int64_t prow0 = (int64_t)tile_panel[ti] * kT;
         const float *tv = vals + ti * (int64_t)(kT * kT);
-        // this wave's A operands of the tile: 16 coalesced float4 loads, in flight during the staging
-        float4 a[16];
-        if (!EXACT) {
-            const float4 *av = reinterpret_cast<const float4 *>(tv) + (w * 16) * 64 + lane;
-#pragma unroll
-            for (int s4 = 0; s4 < 16; ++s4) a[s4] = av[s4 * 64];
+        __syncthreads();                 // half 0 has landed; nobody reads half 1 of the previous tile any more
+        stage_half(B, ldb, ncols, prow0, fcol0, fw, vec, 1, w, smem);
+        load_a(ti, 1, a1);
+        compute_half<NBLK, EXACT>(a0, tv, 0, w, hi, lo, smem, acc);
+        __syncthreads();                 // half 1 has landed; nobody reads half 0 any more
+        if (t + 1 < wk.z) {
+            stage_half(B, ldb, ncols, (int64_t)tile_panel[ti + 1] * kT, fcol0, fw, vec, 0, w, smem);
+            load_a(ti + 1, 0, a0);
         }
-        __syncthreads();                 // the previous panel has been consumed
-        float4 *s4p = reinterpret_cast<float4 *>(smem);
-        if (vec && fw == kT && prow0 + kT <= ncols) {
-            // full panel: 16 asynchronous global -> LDS copies per thread, no staging registers.  The LDS
-            // image is lane-linear, so the rotation of the odd rows is applied to the SOURCE column.
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int idx = q * kThreads + (int)threadIdx.x;
-                const int row = idx >> 5, c4 = ((idx & 31) - 8 * (row & 1)) & 31;
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(B + (prow0 + row) * ldb + fcol0 + c4 * 4),
-                    (__attribute__((address_space(3))) void *)(s4p + q * kThreads + w * 64), 16, 0, 0);
-            }
-        } else if (vec) {
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                const int idx = q * kThreads + (int)threadIdx.x;
-                const int row = idx >> 5, c4 = idx & 31;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (prow0 + row < ncols && c4 < f4)
-                    v = *reinterpret_cast<const float4 *>(B + (prow0 + row) * ldb + fcol0 + c4 * 4);
-                s4p[row * 32 + ((c4 + 8 * (row & 1)) & 31)] = v;
-            }
-        } else {                         // any width / alignment: scalar staging
-            for (int idx = threadIdx.x; idx < kT * kT; idx += kThreads) {
-                const int row = idx >> 7, c = idx & 127;
-                float v = 0.f;
-                if (prow0 + row < ncols && c < fw) v = B[(prow0 + row) * ldb + fcol0 + c];
-                smem[row * kT + ((c + 32 * (row & 1)) & 127)] = v;
-            }
-        }
-        __syncthreads();                 // (waits for the asynchronous copies too)
-        if (!EXACT) {
-#pragma unroll
-            for (int s4 = 0; s4 < 16; ++s4) {
-                const float av4[4] = {a[s4].x, a[s4].y, a[s4].z, a[s4].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = 2 * (4 * s4 + e) + hi;
-                    const float *brow = smem + k * kT;
-                    float b[NBLK];
-#pragma unroll
-                    for (int nb = 0; nb < NBLK; ++nb) b[nb] = brow[(nb * 32 + lo + 32 * hi) & 127];
-#pragma unroll
-                    for (int nb = 0; nb < NBLK; ++nb)
-                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[e], b[nb], acc[nb], 0, 0, 0);
-                }
-            }
-        } else {
-            // this lane owns D[row = (r & 3) + 8 (r >> 2) + 4 hi][col = lo] of every 32 x 32 block
-            for (int k = 0; k < kT; ++k) {
-                const int s = k >> 1, kh = k & 1;
-                float b[NBLK];
-#pragma unroll
-                for (int nb = 0; nb < NBLK; ++nb) b[nb] = smem[k * kT + ((nb * 32 + lo + 32 * kh) & 127)];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float x = tv[((w * 16 + (s >> 2)) * 64 + kh * 32 + il) * 4 + (s & 3)];
-#pragma unroll
-                    for (int nb = 0; nb < NBLK; ++nb) acc[nb][r] = x != 0.f ? fmaf(x, b[nb], acc[nb][r]) : acc[nb][r];
-                }
-            }
-        }
+        compute_half<NBLK, EXACT>(a1, tv, 1, w, hi, lo, smem, acc);
     }
 }
 

@@ -95,7 +95,8 @@ CORE_MIN_FRAC = float(os.environ.get("PGCN_CORE_MIN_FRAC", "0.1"))
 DEGREE_SORT = os.environ.get("PGCN_DEGREE_SORT", "1") != "0"
 DENSE_ON = os.environ.get("PGCN_DENSE", "1") != "0"
 DENSE_TAU = float(os.environ.get("PGCN_DENSE_TAU", "0.20"))       # tiles at least this full go to the matrix cores
-DENSE_PIECE = int(os.environ.get("PGCN_DENSE_PIECE", "8"))        # tiles per work piece (one 128-row partial block each)
+DENSE_PIECE = int(os.environ.get("PGCN_DENSE_PIECE", "0"))        # tiles per work piece (one 128-row partial block each);
+                                                                  # 0 = adaptive: ~1024 pieces, between 1 and 16 tiles
 
 
 @dataclass
@@ -168,6 +169,8 @@ def build_dense(r64, c64, v, tkey_local, ntiles, tile_row, tile_panel, nrows, nc
     import numpy as np
     TR, TC = CORE_TR, CORE_TC
     piece = DENSE_PIECE if piece is None else piece
+    if piece <= 0:      # enough pieces to fill 2 workgroups x 256 CUs twice over; small blocks get one tile per piece
+        piece = int(min(16, max(1, ntiles // 1024)))
     dev = r64.device
     i, k = r64 % TR, c64 % TC
     w, il, s, kh = i // 32, i % 32, k // 2, k % 2

@@ -208,7 +208,7 @@ def test_mfma_tiles_layout_and_bookkeeping():
     assert sorted(np.concatenate([np.arange(b, b + c) for _, b, c, _ in work]).tolist()) == list(range(nt))
     assert np.array_equal(np.sort(work[:, 3]), np.arange(len(work)) * 128)       # one 128-row slot block per piece
     for tr_, b, c, _ in work:
-        assert (hd.tile_row.numpy()[b:b + c] == tr_).all() and c <= partition.DENSE_PIECE
+        assert (hd.tile_row.numpy()[b:b + c] == tr_).all() and c <= 16
     # the whole block is what went in
     r, c, v = h.to_coo()
     got = sp.coo_matrix((v.numpy(), (r.numpy(), c.numpy())), shape=(n, m)).toarray()
