@@ -230,6 +230,18 @@ int pgcn_gat_edge_grad_f32(const int64_t *rowptr, const int32_t *col, int64_t nr
                            int64_t ldz, const float *dOut, int64_t ldo, const float *t, int32_t heads,
                            int32_t d, float slope, int32_t mode, float *de, float *ds1,
                            pgcn_stream_t stream);
+/* The edge gradient on an XCD-sliced structure (a row's entries grouped by col % 8, as the SpMM
+ * kernels store it): slice_off[i*9 + s] = offset of row i's slice s inside the row (slice_off[i*9+8]
+ * = row length).  Workgroup b works on slice b % 8 = its XCD, so each L2 sees one eighth of Z.
+ * ds1_slices: [nrows x 8 x heads] partial sums, ds1 = their sum over the 8 slices.  rows (NULL =
+ * 0..nlist-1): the rows to process.  Needs heads*d <= 256, d a power of two >= 4, aligned panels. */
+int pgcn_gat_edge_grad_sliced_f32(const int64_t *rowptr, const int32_t *col, const int32_t *slice_off,
+                                  int64_t nrows, int64_t nnz, const int32_t *rows, int64_t nlist,
+                                  const float *s1, int64_t lds1, const float *s2, int64_t lds2,
+                                  const float *alpha, const float *beta, const float *Z, int64_t ldz,
+                                  const float *dOut, int64_t ldo, const float *t, int32_t heads,
+                                  int32_t d, float slope, int32_t mode, float *de, float *ds1_slices,
+                                  pgcn_stream_t stream);
 int pgcn_csr_row_sums_f32(const int64_t *rowptr, const int64_t *perm, int64_t nrows, int64_t nnz,
                           const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
                           int64_t nrows_block, const float *src, int32_t planes, float *out,

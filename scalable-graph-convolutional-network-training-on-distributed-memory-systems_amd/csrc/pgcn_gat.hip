@@ -268,18 +268,39 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_kernel(
 // and iteration -- the kernel is bound by gather latency, not by issue -- and lane u of head k's
 // segment finishes entry u of the batch, so the alpha loads and the de stores of a head are U
 // consecutive addresses.  One gather of the full row per entry instead of one per entry and head.
-template <int TPR, int MODE, int U>
+//
+// SLICED (TPR = 64): the structure is stored XCD-sliced (a row's entries grouped by col % 8) and
+// slice_off[i][0..8] are the offsets of row i's slices.  Workgroup b runs on XCD b % 8 and works on
+// slice b % 8 only, so every XCD's L2 holds one eighth of the Z panel instead of thrashing over all
+// of it (the same device the SpMM gather kernel uses); ds1 then holds one partial per (row, slice).
+template <int TPR, int MODE, int U, bool SLICED>
 __global__ __launch_bounds__(kThreads) void gat_edge_grad_heads_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ rows,
     int64_t nlist, const float *__restrict__ s1, int64_t lds1, const float *__restrict__ s2, int64_t lds2,
     const float *__restrict__ alpha, const float *__restrict__ beta, const float *__restrict__ Z, int64_t ldz,
     const float *__restrict__ dOut, int64_t ldo, const float *__restrict__ t, int32_t heads, int32_t d, int32_t lpe,
-    float slope, float *__restrict__ de, float *__restrict__ ds1, int64_t nnz) {
+    float slope, float *__restrict__ de, float *__restrict__ ds1, int64_t nnz, const int32_t *__restrict__ slice_off) {
     __shared__ float red[4];
     int64_t i;
     int lane;
-    if (!pick_row<TPR>(rows, nlist, i, lane)) return;
-    const int64_t b = rowptr[i], e = rowptr[i + 1];
+    int64_t b, e;
+    int64_t orow;                          // row of ds1 this wave writes
+    if constexpr (SLICED) {
+        const int sl = blockIdx.x & 7;
+        const int64_t li = (int64_t)(blockIdx.x >> 3) * (kThreads / 64) + (threadIdx.x >> 6);
+        lane = threadIdx.x & 63;
+        if (li >= nlist) return;
+        i = rows ? (int64_t)rows[li] : li;
+        const int64_t base = rowptr[i];
+        b = base + slice_off[i * 9 + sl];
+        e = base + slice_off[i * 9 + sl + 1];
+        orow = i * 8 + sl;
+    } else {
+        if (!pick_row<TPR>(rows, nlist, i, lane)) return;
+        b = rowptr[i];
+        e = rowptr[i + 1];
+        orow = i;
+    }
     const int nvec = heads * d / 4;
     const int hl = d / 4;                  // lanes per head (>= U)
     const int sub = lane & (lpe - 1);
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_heads_kernel(
     }
     for (int k = 0; k < heads; ++k) {
         const float v = group_reduce<TPR, false>((fin && hk == k) ? acc : 0.f, red);
-        if (lane == 0) ds1[i * heads + k] = v;
+        if (lane == 0) ds1[orow * heads + k] = v;
     }
 }
 
@@ -464,8 +485,8 @@ extern "C" int pgcn_gat_edge_grad_f32(const int64_t *rowptr, const int32_t *col,
         int team = 1;
         while (team < F4) team *= 2;
 #define PGCN_EGRAD_H(TPR, MODE, UU, GRID, ROWS, N)                                                                      \
-    hipLaunchKernelGGL((gat_edge_grad_heads_kernel<TPR, MODE, UU>), GRID, dim3(kThreads), 0, s, rowptr, col, ROWS, N, s1, \
-                       lds1, s2, lds2, alpha, beta, Z, ldz, dOut, ldo, t, heads, d, team, slope, de, ds1, nnz)
+    hipLaunchKernelGGL((gat_edge_grad_heads_kernel<TPR, MODE, UU, false>), GRID, dim3(kThreads), 0, s, rowptr, col, ROWS, N, s1, \
+                       lds1, s2, lds2, alpha, beta, Z, ldz, dOut, ldo, t, heads, d, team, slope, de, ds1, nnz, nullptr)
 #define PGCN_EGRAD_HU(TPR, GRID, ROWS, N)                                                   \
     do {                                                                                    \
         if (hl >= 8) {                                                                      \
@@ -489,6 +510,50 @@ extern "C" int pgcn_gat_edge_grad_f32(const int64_t *rowptr, const int32_t *col,
     }
 #undef PGCN_EGRAD_VM
 #undef PGCN_EGRAD
+    PGCN_HIP_CHECK(hipGetLastError());
+    return PGCN_OK;
+}
+
+extern "C" int pgcn_gat_edge_grad_sliced_f32(const int64_t *rowptr, const int32_t *col, const int32_t *slice_off,
+                                             int64_t nrows, int64_t nnz, const int32_t *rows, int64_t nlist,
+                                             const float *s1, int64_t lds1, const float *s2, int64_t lds2,
+                                             const float *alpha, const float *beta, const float *Z, int64_t ldz,
+                                             const float *dOut, int64_t ldo, const float *t, int32_t heads, int32_t d,
+                                             float slope, int32_t mode, float *de, float *ds1_slices,
+                                             pgcn_stream_t stream) {
+    const char *who = "pgcn_gat_edge_grad_sliced_f32";
+    if (nrows < 0 || nnz < 0 || nlist < 0 || nlist > nrows || heads < 1 || d < 1 || lds1 < heads || lds2 < heads ||
+        ldz < (int64_t)heads * d || ldo < (int64_t)heads * d || (mode != 0 && mode != 1))
+        return pgcn_set_error2(PGCN_EINVAL, who, "bad sizes");
+    const int F4 = heads * d / 4, hl = d / 4;
+    const bool v4 = d % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 && (uintptr_t)Z % 16 == 0 && (uintptr_t)dOut % 16 == 0;
+    if (!v4 || F4 > 64 || (hl & (hl - 1)) != 0)
+        return pgcn_set_error2(PGCN_EUNSUPPORTED, who, "needs heads*d <= 256, d a power of two >= 4, 16-byte aligned panels");
+    if (nrows == 0 || nlist == 0) return PGCN_OK;
+    if (!rowptr || !slice_off || !s1 || !t || !ds1_slices || !dOut || (nnz && (!col || !s2 || !alpha || !Z || !de)) ||
+        (mode == 1 && !beta))
+        return pgcn_set_error2(PGCN_EINVAL, who, "null pointer");
+    const int64_t blocks = (nlist + 3) / 4 * 8;
+    if (blocks > 0x7fffffffLL) return pgcn_set_error2(PGCN_EINVAL, who, "too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    int team = 1;
+    while (team < F4) team *= 2;
+    const dim3 grid((unsigned)blocks);
+#define PGCN_EGRAD_S(MODE, UU)                                                                                        \
+    hipLaunchKernelGGL((gat_edge_grad_heads_kernel<64, MODE, UU, true>), grid, dim3(kThreads), 0, s, rowptr, col, rows, \
+                       nlist, s1, lds1, s2, lds2, alpha, beta, Z, ldz, dOut, ldo, t, heads, d, team, slope, de,       \
+                       ds1_slices, nnz, slice_off)
+    if (hl >= 8) {
+        if (mode == 0) PGCN_EGRAD_S(0, 8);
+        else PGCN_EGRAD_S(1, 8);
+    } else if (hl >= 4) {
+        if (mode == 0) PGCN_EGRAD_S(0, 4);
+        else PGCN_EGRAD_S(1, 4);
+    } else {
+        if (mode == 0) PGCN_EGRAD_S(0, 1);
+        else PGCN_EGRAD_S(1, 1);
+    }
+#undef PGCN_EGRAD_S
     PGCN_HIP_CHECK(hipGetLastError());
     return PGCN_OK;
 }

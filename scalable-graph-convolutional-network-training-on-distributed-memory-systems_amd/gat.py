@@ -129,6 +129,7 @@ class GatEngine(BoundaryExchange):
         self.bwd = kernels.prepare_gat(g.bwd, g.bwd_wave, g.bwd_block)
         self.perm = g.perm.to(self.device)
         self._scratch = {}
+        self.sliced_grad = os.environ.get("PGCN_GAT_SLICED", "1") != "0"   # XCD-sliced edge gradient where the shape allows
 
     # -- buffers ---------------------------------------------------------
     def _plane_scratch(self, name: str, heads: int) -> torch.Tensor:
@@ -197,9 +198,14 @@ class GatEngine(BoundaryExchange):
         dOut = dOut.contiguous()
         t = (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
         de = self._plane_scratch("de", K)
-        ds1 = torch.empty((n_p, K), dtype=torch.float32, device=self.device)
-        self.k.gat_edge_grad(self.fwd, st.s1, st.s2c, st.alpha, st.beta, st.Zc, dOut, t, K, d,
-                             self.slope, self.mode_id, de, ds1)
+        ds1p = torch.empty((n_p, 8, K), dtype=torch.float32, device=self.device)
+        if self.sliced_grad and self.k.gat_edge_grad_sliced(self.fwd, st.s1, st.s2c, st.alpha, st.beta, st.Zc, dOut, t,
+                                                            K, d, self.slope, self.mode_id, de, ds1p):
+            ds1 = ds1p.sum(1)               # 8 per-XCD partials per row (plumbing: n_p x 8 x K floats)
+        else:
+            ds1 = torch.empty((n_p, K), dtype=torch.float32, device=self.device)
+            self.k.gat_edge_grad(self.fwd, st.s1, st.s2c, st.alpha, st.beta, st.Zc, dOut, t, K, d,
+                                 self.slope, self.mode_id, de, ds1)
         alpha_t = self._plane_scratch("alpha_t", K)
         self.k.gat_edge_weights_t(self.bwd, st.s2c, st.rowstat, K, self.slope, self.mode_id, alpha_t)
         bwd_heads = self._scratch.get(("bwd_heads", K))

@@ -56,6 +56,8 @@ class DeviceCSR:
     fused_work: Optional[torch.Tensor] = None  # int32 [nwork,4] unified work list (pgcn_spmm_fused_f32)
     rows_wave: Optional[torch.Tensor] = None   # GAT kernels: int32 rows handled by one wave each ...
     rows_block: Optional[torch.Tensor] = None  # ... and by one 256-thread workgroup each (hub rows)
+    slice_off: Optional[torch.Tensor] = None   # int32 [nrows, 9] offsets of a row's 8 col % 8 slices (XCD-sliced storage)
+    rows_all: Optional[torch.Tensor] = None    # int32 all rows, longest first
     launch_cache: dict = None                 # bound C-ABI calls per (ldb, ldc, f, accumulate)
 
     def __post_init__(self):
@@ -416,6 +418,12 @@ class HipKernels:
         d = self.prepare(csr, pattern_only=True)
         d.rows_wave = rows_wave.to(self.device, torch.int32).contiguous()
         d.rows_block = rows_block.to(self.device, torch.int32).contiguous()
+        if csr.nslices == 8 and csr.slice_cnt is not None and csr.ngroups == 1:
+            off = torch.zeros((csr.nrows, 9), dtype=torch.int32, device=csr.slice_cnt.device)
+            off[:, 1:] = torch.cumsum(csr.slice_cnt.to(torch.int64), 1).to(torch.int32)
+            d.slice_off = off.to(self.device).contiguous()
+            ln = csr.rowptr[1:] - csr.rowptr[:-1]
+            d.rows_all = torch.argsort(-ln, stable=True).to(torch.int32).to(self.device).contiguous()
         return d
 
     def with_values(self, A: DeviceCSR, plane: torch.Tensor) -> DeviceCSR:
@@ -487,6 +495,30 @@ class HipKernels:
             s1.stride(0), s2.data_ptr(), s2.stride(0), alpha.data_ptr(), beta.data_ptr(), Z.data_ptr(), Z.stride(0),
             dOut.data_ptr(), dOut.stride(0), t.data_ptr(), heads, d, slope, mode, de.data_ptr(), ds1.data_ptr(),
             self._stream()), "pgcn_gat_edge_grad_f32")
+
+    def gat_edge_grad_sliced(self, A: DeviceCSR, s1, s2, alpha, beta, Z, dOut, t, heads: int, d: int, slope: float,
+                             mode: int, de: torch.Tensor, ds1_slices: torch.Tensor) -> bool:
+        """XCD-sliced variant (structure stored in 8 col % 8 slices).  Returns False when the shape is
+        not covered (the caller then uses gat_edge_grad); ds1_slices: [nrows, 8, heads]."""
+        F = heads * d
+        if A.slice_off is None or d % 4 or F > 256 or (d // 4) & (d // 4 - 1) or Z.stride(0) % 4 or dOut.stride(0) % 4 \
+                or Z.data_ptr() % 16 or dOut.data_ptr() % 16:
+            return False
+        self._check_rows(s1, A.nrows, heads, "s1")
+        self._check_rows(s2, A.ncols, heads, "s2")
+        self._check_rows(t, A.nrows, heads, "t")
+        self._check_rows(dOut, A.nrows, F, "dOut")
+        nnz = A.col.numel()
+        if de.shape != alpha.shape or not de.is_contiguous() or not alpha.is_contiguous() or (nnz and alpha.shape[1] != nnz) \
+                or t.stride(0) != heads or beta.stride(0) != heads or not ds1_slices.is_contiguous() \
+                or tuple(ds1_slices.shape) != (A.nrows, 8, heads) or Z.shape[0] < A.ncols or Z.shape[1] < F:
+            raise _lib.PgcnError("bad operand shapes for the sliced edge gradient")
+        _lib.check(self.lib.pgcn_gat_edge_grad_sliced_f32(
+            A.rowptr.data_ptr(), A.col.data_ptr(), A.slice_off.data_ptr(), A.nrows, nnz, A.rows_all.data_ptr(), A.nrows,
+            s1.data_ptr(), s1.stride(0), s2.data_ptr(), s2.stride(0), alpha.data_ptr(), beta.data_ptr(), Z.data_ptr(),
+            Z.stride(0), dOut.data_ptr(), dOut.stride(0), t.data_ptr(), heads, d, slope, mode, de.data_ptr(),
+            ds1_slices.data_ptr(), self._stream()), "pgcn_gat_edge_grad_sliced_f32")
+        return True
 
     def csr_row_sums(self, A: DeviceCSR, perm: Optional[torch.Tensor], src: torch.Tensor, planes: int,
                      out: torch.Tensor) -> None:

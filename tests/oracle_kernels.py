@@ -157,6 +157,11 @@ def _csr_permute(self, src, perm, dst):
         dst[:, :n] = src[:, perm]
 
 
+def _gat_edge_grad_sliced(self, *a, **k):
+    return False                                         # no sliced variant in the stand-in: the caller falls back
+
+
+OracleKernels.gat_edge_grad_sliced = _gat_edge_grad_sliced
 OracleKernels.prepare_gat = _prepare_gat
 OracleKernels.with_values = _with_values
 OracleKernels.gat_edge_softmax = _gat_edge_softmax

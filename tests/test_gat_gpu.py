@@ -72,7 +72,7 @@ def test_attention_kernels_vs_oracle(K, dev, mode, heads, d, nslices, long_row):
     dA, dT, perm, er, ec = _structure(K, A, nslices, long_row)
     nnz = A.nnz
     F = heads * d
-    ld = F + heads + 3                                                   # s2 lives behind Z in a wider panel
+    ld = F + heads + (4 if heads % 2 == 0 else 3)                        # s2 lives behind Z in a wider panel
     Zc = (rng.standard_normal((m, ld)) * 0.7).astype(np.float32)
     s1 = (rng.standard_normal((n, heads)) * 1.5).astype(np.float32)
     s2 = Zc[:, F:F + heads].copy()
@@ -132,6 +132,16 @@ def test_attention_kernels_vs_oracle(K, dev, mode, heads, d, nslices, long_row):
     assert rel_err(ds2[:, 1:1 + heads].cpu().numpy(), eds2) < 5 * TOL
     assert torch.isnan(ds2[:, 0]).all() and torch.isnan(ds2[:, 1 + heads]).all()      # neighbours untouched
     assert rel_err(dZ.cpu().numpy(), edZ) < TOL
+    # XCD-sliced variant of the same kernel (8-slice storage, shapes it covers): same de, ds1 = sum of 8 partials
+    ds1p = torch.full((n, 8, heads), float("nan"), device=dev)
+    de_s = torch.full_like(de, float("nan"))
+    covered = nslices == 8 and d % 4 == 0 and ld % 4 == 0                 # else the caller uses the unsliced kernel
+    assert K.gat_edge_grad_sliced(dA, s1d, torch.from_numpy(s2).to(dev), alpha, beta, Zd, dOd, t, heads, d, 0.2,
+                                  mode_id, de_s, ds1p) == covered
+    assert covered == ((heads, d, nslices) in [(1, 16, 8), (4, 64, 8)])
+    if covered:
+        assert torch.equal(de_s, de)                                       # per entry: the same arithmetic
+        assert rel_err(ds1p.sum(1).cpu().numpy(), eds1) < 5 * TOL
     # bit-reproducible
     de2, ds1b = torch.empty_like(de), torch.empty_like(ds1)
     K.gat_edge_grad(dA, s1d, Zd[:, F:F + heads], alpha, beta, Zd, dOd, t, heads, d, 0.2, mode_id, de2, ds1b)
@@ -269,6 +279,11 @@ def test_full_size_properties_reddit_like_gat(K, dev):
     dZ2, ds1b, ds2b = eng.backward(st, 2 * G)
     assert rel_err(dZ2.cpu().numpy(), 2 * dZ1.cpu().numpy()) < 1e-6
     assert rel_err(ds1b.cpu().numpy(), 2 * ds1a.cpu().numpy()) < 1e-5
+    eng.sliced_grad = False                                                # the unsliced kernel gives the same numbers
+    dZ3, ds1c, ds2c = eng.backward(st, G)
+    eng.sliced_grad = True
+    assert torch.equal(dZ3, dZ1) and torch.equal(ds2c, ds2a)
+    assert rel_err(ds1c.cpu().numpy(), ds1a.cpu().numpy()) < 1e-5
     lhs = float((G.double() * out.double()).sum())
     rhs = float((dZ1.double() * Z.double()).sum())
     assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), 1.0)

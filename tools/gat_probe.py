@@ -51,6 +51,8 @@ def main():
     t = (G.view(n, heads, d) * st.out.view(n, heads, d)).sum(-1).contiguous()
     de = eng._plane_scratch("de", heads); ds1 = torch.empty(n, heads, device=dev)
     out["edge_grad_ms"] = timed(lambda: K.gat_edge_grad(eng.fwd, st.s1, st.s2c, st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1))
+    ds1p = torch.empty(n, 8, heads, device=dev)
+    out["edge_grad_sliced_ms"] = timed(lambda: K.gat_edge_grad_sliced(eng.fwd, st.s1, st.s2c, st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1p))
     at = eng._plane_scratch("alpha_t", heads)
     out["permute_ms"] = timed(lambda: K.csr_permute(st.alpha, eng.perm, at))
     out["weights_t_ms"] = timed(lambda: K.gat_edge_weights_t(eng.bwd, st.s2c, st.rowstat, heads, eng.slope, eng.mode_id, at))
