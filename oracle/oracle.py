@@ -14,8 +14,11 @@ Two layers:
                           code (float64 "shadow" arithmetic), the host-side
                           helpers of ``GPU/PGCN.py`` (communication maps, the
                           ``run()`` training loop with ReLU / log_softmax /
-                          nll_loss / Adam), and ``preprocess/GrB-GNN-IDG.py``'s
-                          normalisation.
+                          nll_loss / Adam), ``preprocess/GrB-GNN-IDG.py``'s
+                          normalisation, and the GAT layer of ``GPU/PGAT.py`` on
+                          the stored entries (``gat_*_np``; pinned to outputs and
+                          gradients of the reference's own dense layers,
+                          ``tests/golden/make_golden_gat.py``).
 
 Every function cites the reference file:line it follows (paths relative to
 ``/root/reference``).  Parity pinning is described in ``pgcn_oracle.c``'s
