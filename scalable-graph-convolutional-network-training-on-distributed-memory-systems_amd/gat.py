@@ -21,7 +21,6 @@ process computes on the whole graph (owned rows).
 """
 from __future__ import annotations
 
-import dataclasses
 import os
 from dataclasses import dataclass
 from typing import List, Optional
