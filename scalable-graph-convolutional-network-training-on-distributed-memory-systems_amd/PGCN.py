@@ -280,9 +280,18 @@ def run(rank, size, nlayers, nfeatures, path_A, path_partvec, backend):
         raise _kernels._lib.PgcnError("no HIP device visible: refusing to run (no CPU fallback); "
                                       "backend=%s only selects the transport" % backend)
 
-    A = _ingest.mmread(path_A)          # C++ multi-threaded reader, same result as scipy's mmread
     with open(path_partvec) as f:
         partvec = list(map(int, f.readline().split()))
+    if os.environ.get("PGCN_INGEST", "global") == "rows" and size > 1:
+        # every rank keeps ONLY its rows (pgcn_load_mtx_partition) and the partition is completed by two
+        # small collectives instead of a scan of the whole matrix on every rank (PGCN.py:37-64)
+        A = _ingest.load_partition(path_A, partvec, rank)
+        row, col, val = _coo_tensors(A)
+        _partition_cache.clear()
+        _partition_cache[(id(A), rank, size)] = _partition.build_partition_local(
+            row, col, val, A.shape[0], torch.as_tensor(partvec, dtype=torch.int64), rank, size)
+    else:
+        A = _ingest.mmread(path_A)      # C++ multi-threaded reader, same result as scipy's mmread
     n = A.shape[0]
 
     send_map, recv_map = compute_communication_maps(A, partvec, rank, size)

@@ -467,38 +467,116 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     dev = row.device
     row = row.to(torch.int64)
     col = col.to(torch.int64)
-    part = partvec.to(device=dev, dtype=torch.int64)
-    if part.numel() != n:
-        raise ValueError("part vector has %d entries, matrix has %d rows" % (part.numel(), n))
-    if part.numel() and (int(part.min()) < 0 or int(part.max()) >= size):
-        raise ValueError("part vector entries must be in [0, %d)" % size)
-    own_mask = part == rank
-    owned = torch.nonzero(own_mask).reshape(-1)
-    n_p = int(owned.numel())
+    part = _check_partvec(partvec, n, size, dev)
     # One global degree ranking, identical on every rank (every rank scans the whole COO, as in
     # the reference): grank[v] = position of vertex v in the order (degree descending, id
     # ascending).  It numbers the local rows AND orders the boundary-row slabs, so that the
     # dense core of a power-law graph is the top-left corner of A_loc and the head of every
-    # owner segment of A_halo -- what the LDS-tiled kernel feeds on.  Purely internal: `owned`,
+    # owner segment of A_halo -- what the tiled kernels feed on.  Purely internal: `owned`,
     # `send_global` and `halo_global` record the orders; sender and receiver agree by construction.
+    gdeg = None
     if (DEGREE_SORT if degree_sort is None else degree_sort) and n > 1:
         gdeg = torch.bincount(row, minlength=n) + torch.bincount(col, minlength=n)
+    gorder, grank = _degree_order(gdeg, n, dev)
+    prow = part[row]
+    pcol = part[col]
+    mine = prow == rank
+    # rows of mine that other ranks need: (target rank, degree rank) keys, unique and sorted
+    theirs = (pcol == rank) & (prow != rank)
+    suniq = torch.unique(prow[theirs] * n + grank[col[theirs]])
+    return _finish_partition(row[mine], col[mine], val[mine], n, part, rank, size, gorder, grank, suniq,
+                             int(row.numel()), with_transpose, rounds)
+
+
+def build_partition_local(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: int,
+                          partvec: torch.Tensor, rank: int, size: int, group=None,
+                          with_transpose: bool = True, rounds: Optional[int] = None,
+                          degree_sort: Optional[bool] = None) -> Partition:
+    """The same Partition from rank ``rank``'s OWN ROWS only (global coordinates, e.g.
+    ``ingest.load_partition``): no rank ever holds the whole matrix.  Two small collectives over
+    ``torch.distributed`` replace the global scan: an all-reduce of the n-vector of degrees (for
+    the common degree ranking) and an all-to-all-v of id lists (every rank tells the owners which
+    of their rows it needs -- the reference derives this from the global matrix, PGCN.py:44-47).
+    Field for field identical to ``build_partition`` on the global COO (tests/test_partition.py)."""
+    import torch.distributed as dist
+    dev = row.device
+    row = row.to(torch.int64)
+    col = col.to(torch.int64)
+    part = _check_partvec(partvec, n, size, dev)
+    if row.numel() and not bool((part[row] == rank).all()):
+        raise ValueError("build_partition_local takes the rows owned by this rank only")
+
+    gloo = size > 1 and dist.get_backend(group) == "gloo"
+
+    def to_wire(t):            # gloo moves host tensors; nccl (= RCCL) device tensors
+        return t.cpu() if gloo else t
+
+    gdeg = None
+    nnz_global = torch.tensor([row.numel()], dtype=torch.int64, device=dev)
+    if (DEGREE_SORT if degree_sort is None else degree_sort) and n > 1:
+        gdeg = torch.bincount(row, minlength=n) + torch.bincount(col, minlength=n)
+    if size > 1:
+        w = to_wire(nnz_global)
+        dist.all_reduce(w, group=group)
+        nnz_global = w.to(dev)
+        if gdeg is not None:
+            w = to_wire(gdeg)
+            dist.all_reduce(w, group=group)
+            gdeg = w.to(dev)
+    gorder, grank = _degree_order(gdeg, n, dev)
+    # what I need from every owner (my halo sets), as degree ranks; the owners receive the lists
+    pcol = part[col]
+    need = torch.unique(pcol[pcol != rank] * n + grank[col[pcol != rank]])          # (owner, degree rank), sorted
+    suniq = torch.zeros(0, dtype=torch.int64, device=dev)
+    if size > 1:
+        out_cnt = to_wire(torch.bincount(need // n, minlength=size))
+        in_cnt = torch.empty_like(out_cnt)
+        dist.all_to_all_single(in_cnt, out_cnt, group=group)
+        in_list, out_list = in_cnt.cpu().tolist(), out_cnt.cpu().tolist()
+        send_ids = to_wire((need % n).contiguous())
+        recv_ids = torch.empty(sum(in_list), dtype=torch.int64, device=send_ids.device)
+        dist.all_to_all_single(recv_ids, send_ids, output_split_sizes=in_list, input_split_sizes=out_list, group=group)
+        src = torch.repeat_interleave(torch.arange(size, dtype=torch.int64), torch.tensor(in_list)).to(dev)
+        suniq = torch.unique(src * n + recv_ids.to(dev))                              # (requesting rank, degree rank)
+    return _finish_partition(row, col, val, n, part, rank, size, gorder, grank, suniq, int(nnz_global),
+                             with_transpose, rounds)
+
+
+def _check_partvec(partvec, n: int, size: int, dev) -> torch.Tensor:
+    part = torch.as_tensor(partvec).to(device=dev, dtype=torch.int64)
+    if part.numel() != n:
+        raise ValueError("part vector has %d entries, matrix has %d rows" % (part.numel(), n))
+    if part.numel() and (int(part.min()) < 0 or int(part.max()) >= size):
+        raise ValueError("part vector entries must be in [0, %d)" % size)
+    return part
+
+
+def _degree_order(gdeg: Optional[torch.Tensor], n: int, dev):
+    if gdeg is not None:
         gorder = torch.argsort(-gdeg, stable=True)
     else:
         gorder = torch.arange(n, dtype=torch.int64, device=dev)
     grank = torch.empty(n, dtype=torch.int64, device=dev)
     grank[gorder] = torch.arange(n, dtype=torch.int64, device=dev)
+    return gorder, grank
+
+
+def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Tensor, n: int, part: torch.Tensor,
+                      rank: int, size: int, gorder: torch.Tensor, grank: torch.Tensor, suniq: torch.Tensor,
+                      nnz_global: int, with_transpose: bool, rounds: Optional[int]) -> Partition:
+    """Everything after the two global facts (degree ranking, who needs which of my rows):
+    ``row_m/col_m/val_m`` are this rank's entries in GLOBAL coordinates."""
+    dev = row_m.device
+    owned = torch.nonzero(part == rank).reshape(-1)
+    n_p = int(owned.numel())
     owned = owned[torch.argsort(grank[owned])]
     g2l = torch.full((n,), -1, dtype=torch.int64, device=dev)
     g2l[owned] = torch.arange(n_p, dtype=torch.int64, device=dev)
 
-    prow = part[row]
-    pcol = part[col]
-    mine = prow == rank
-    r = g2l[row[mine]]
-    c = col[mine]
-    v = val[mine]
-    cp = pcol[mine]
+    r = g2l[row_m]
+    c = col_m
+    v = val_m
+    cp = part[col_m]
     loc = cp == rank
 
     A_loc = csr_from_coo(r[loc], g2l[c[loc]], v[loc], n_p, n_p, core=CORE_ON)
@@ -531,9 +609,6 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
         A_loc_T = csr_from_coo(g2l[c[loc]], r[loc], v[loc], n_p, n_p, core=CORE_ON)
 
     # rows of mine that other ranks need, in the peers' slab order (round, target rank, degree rank)
-    theirs = (pcol == rank) & (prow != rank)
-    skey = prow[theirs] * n + grank[col[theirs]]
-    suniq = torch.unique(skey)
     s_order, _, round_send_off = _round_major(suniq // n, size, R)
     send_global = gorder[suniq % n][s_order]
     send_owner = (suniq // n)[s_order]
@@ -553,7 +628,7 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
                      A_loc_T=A_loc_T, A_halo_T=A_halo_T, send_idx=send_idx.contiguous(), unpack=unpack,
                      send_owner=send_owner, halo_owner=halo_owner, round_send_off=round_send_off,
                      round_recv_off=round_recv_off, halo_global=halo_global,
-                     send_global=send_global, nnz_global=int(row.numel()))
+                     send_global=send_global, nnz_global=nnz_global)
 
 
 def read_partvec(path: str) -> List[int]:

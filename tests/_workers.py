@@ -216,3 +216,44 @@ def gat_run_worker(rank, P, port, path_A, path_pv, mode, heads, nlayers, f, seed
            "params": {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}})
     dist.barrier()
     dist.destroy_process_group()
+
+
+def partition_local_worker(rank, P, port, path_A, path_pv, rounds, q):
+    """build_partition_local from this rank's own rows (native loader) vs build_partition from the global COO."""
+    from conftest import pkg, read_partvec
+    from scipy.io import mmread
+    _init(rank, P, port)
+    partition, ingest = pkg("partition"), pkg("ingest")
+    part = read_partvec(path_pv)
+    mine = ingest.load_partition(path_A, part, rank)                      # only the rows this rank owns
+    loc = partition.build_partition_local(torch.from_numpy(mine.row), torch.from_numpy(mine.col), torch.from_numpy(mine.data),
+                                          mine.shape[0], torch.tensor(part), rank, P, rounds=rounds)
+    A = mmread(path_A).tocoo()
+    glo = partition.build_partition(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
+                                    torch.from_numpy(A.data.astype(np.float32)), A.shape[0], torch.tensor(part), rank, P,
+                                    rounds=rounds)
+
+    def same_csr(a, b):
+        if a is None or b is None:
+            return a is b
+        ra, ca, va = a.to_coo()
+        rb, cb, vb = b.to_coo()
+        ok = a.nrows == b.nrows and a.ncols == b.ncols and torch.equal(a.rowptr, b.rowptr) and torch.equal(a.col, b.col)
+        ok = ok and torch.equal(a.val, b.val) and torch.equal(ra, rb) and torch.equal(ca, cb) and torch.equal(va, vb)
+        ok = ok and (a.row_map is None) == (b.row_map is None) and (a.row_map is None or torch.equal(a.row_map, b.row_map))
+        return bool(ok)
+
+    checks = {
+        "scalars": (loc.n, loc.rank, loc.size, loc.nnz_global) == (glo.n, glo.rank, glo.size, glo.nnz_global),
+        "owned": torch.equal(loc.owned, glo.owned), "send_idx": torch.equal(loc.send_idx, glo.send_idx),
+        "send_owner": torch.equal(loc.send_owner, glo.send_owner), "halo_owner": torch.equal(loc.halo_owner, glo.halo_owner),
+        "halo_global": torch.equal(loc.halo_global, glo.halo_global), "send_global": torch.equal(loc.send_global, glo.send_global),
+        "offs": loc.round_send_off == glo.round_send_off and loc.round_recv_off == glo.round_recv_off,
+        "A_loc": same_csr(loc.A_loc, glo.A_loc), "A_loc_T": same_csr(loc.A_loc_T, glo.A_loc_T),
+        "A_halo": len(loc.A_halo) == len(glo.A_halo) and all(same_csr(a, b) for a, b in zip(loc.A_halo, glo.A_halo)),
+        "A_halo_T": all(same_csr(a, b) for a, b in zip(loc.A_halo_T, glo.A_halo_T)),
+        "unpack": all(same_csr(a, b) for a, b in zip(loc.unpack, glo.unpack)),
+    }
+    q.put({"rank": rank, "checks": {k: bool(v) for k, v in checks.items()}, "nnz_local": int(mine.nnz)})
+    dist.barrier()
+    dist.destroy_process_group()

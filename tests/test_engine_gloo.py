@@ -133,3 +133,30 @@ def test_pargcn_semantics_multi_rank():
         assert r["stats"]["send_volume"] // 12 * 50 * 3 == st[r["rank"], 0]
         assert r["stats"]["send_nmsg"] == st[r["rank"], 1]
     assert rel_err(Hg, Hl) < TOL
+
+
+@pytest.mark.parametrize("rounds", [1, 2])
+@pytest.mark.parametrize("name,mtx,pv,P", [SPMM_CASES[i] for i in (0, 3, 4, 6, 8)])
+def test_partition_from_own_rows_equals_global_build(name, mtx, pv, P, rounds):
+    """N1: every rank loads ONLY its rows (pgcn_load_mtx_partition) and builds its Partition with two small
+    collectives (degree all-reduce, all-to-all-v of needed ids) -- field for field what the global scan gives."""
+    _, meta = golden(name)
+    res = _spawn(_workers.partition_local_worker, P, gpath(mtx), gpath(pv), rounds)
+    for r in res:
+        assert all(r["checks"].values()), (r["rank"], r["checks"])
+        assert r["nnz_local"] == meta["ranks"][r["rank"]]["nnz_local"]
+
+
+def test_run_with_row_block_ingest_is_identical(monkeypatch):
+    """PGCN_INGEST=rows: run() where no rank parses more than its own rows into memory -- same printed
+    losses, same statistics, bit-identical weights as the default (global) ingest."""
+    mtx, pv, P, L, f = "gemat11p.A.mtx", "gemat11.mtx.3.hp", 3, 2, 8
+    base = _spawn(_workers.run_worker, P, gpath(mtx), gpath(pv), L, f, 7)
+    monkeypatch.setenv("PGCN_INGEST", "rows")
+    rows = _spawn(_workers.run_worker, P, gpath(mtx), gpath(pv), L, f, 7)
+    assert rows[0]["stdout"].split("Elapsed")[0] == base[0]["stdout"].split("Elapsed")[0]      # env echo, losses, stats
+    vol = re.findall(r"total_vol: \d+ total_nmsg: \d+", rows[0]["stdout"])
+    assert len(vol) == 1 and vol == re.findall(r"total_vol: \d+ total_nmsg: \d+", base[0]["stdout"])
+    for a, b in zip(rows, base):
+        for wa, wb in zip(a["weights"], b["weights"]):
+            np.testing.assert_array_equal(wa, wb)
