@@ -176,3 +176,27 @@ def test_module_contract():
     assert tuple(M.PGAT(None, 12, 12, heads=3).attention.shape) == (8, 3)
     with pytest.raises(ValueError):
         M.PGAT(None, 12, 10, heads=4)
+
+
+def test_four_ranks_random_partition(tmp_path):
+    """More peers than the shipped part vectors have: P = 4, seeded random partition, 2 heads."""
+    mtx, mode, heads, f, L, seed = "gemat11p.A.mtx", "standard", 2, 8, 2, 5
+    A = _pattern(mtx, mode)
+    n = A.shape[0]
+    part = np.random.default_rng(9).integers(0, 4, n)
+    pv = tmp_path / "rand4.pv"
+    pv.write_text(" ".join(map(str, part.tolist())) + "\n")
+    res = _spawn(_workers.gat_layers_worker, 4, gpath(mtx), str(pv), mode, heads, f, L, seed)
+    outs, loss, dH, dW, da = _expected(A, mode, heads, f, L, seed)
+    got = np.zeros((n, f), np.float32)
+    got_dH = np.zeros((n, f), np.float32)
+    for r in res:
+        assert np.array_equal(np.sort(r["own"]), np.nonzero(part == r["rank"])[0]) and r["ok_halo"]
+        got[r["own"]] = r["outs"][-1]
+        got_dH[r["own"]] = r["dH"]
+    assert rel_err(got, outs[-1]) < 2e-5
+    assert abs(sum(r["loss"] for r in res) - loss) < 1e-5 * abs(loss)
+    assert rel_err(got_dH, dH) < 2e-4
+    for i in range(L):
+        assert rel_err(sum(r["dW"][i] for r in res), dW[i]) < 2e-4
+        assert rel_err(sum(r["da"][i] for r in res), da[i]) < 2e-4
