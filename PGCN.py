@@ -13,7 +13,10 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 _impl = importlib.import_module(
     "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd.PGCN")
-globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})
+if __name__ != "__main__":
+    # alias, not a copy: `import PGCN; PGCN.device = ...` must reach the implementation's module globals
+    # (the reference's variants poke them, GPU/PGCN.py:23-35)
+    sys.modules[__name__] = _impl
 
 if __name__ == "__main__":
     _impl.main(sys.argv[1:])

@@ -101,6 +101,20 @@ def cpu_baseline(part, f, budget_s=20.0):
             "ms_per_spmm": 1e3 * t_total / reps}
 
 
+def self_launch(nproc):
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // nproc)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,12 +141,14 @@ def main():
         if wd > 0:
             print("[bench rank %d +%.1fs] %s" % (rank, time.time() - t_start, msg), file=sys.stderr, flush=True)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: start the N ranks ourselves (one per GPU), exactly the
+            # command the driver would use; rank 0's JSON line goes to our stdout.  The reference's
+            # own main() spawns its ranks the same way (GPU/PGAT.py:267-275).
+            sys.exit(self_launch(args.gpus))
         args.gpus = world
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X (no CPU fallback in the product path)")
+        sys.exit("bench.py needs an MI355X (no CPU fallback in the product path) [rank %d of %d]" % (rank, world))
     dev = torch.device("cuda:%d" % (local_rank % torch.cuda.device_count()))   # (gloo dry-run: ranks share cuda:0)
     torch.cuda.set_device(dev)
     backend = os.environ.get("PGCN_BENCH_BACKEND", "nccl")   # "gloo": dry-run of the N>1 path on one GPU
@@ -166,6 +182,7 @@ def main():
     K = kernels.HipKernels(dev)
     exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
     eng = engine.AggregationEngine(part, K, dev, exch)
+    P._engine_current = eng           # gradient all-reduce rides the exchange's communicator and stream
     torch.cuda.synchronize()
     setup_s = time.time() - t0
     stage("engine ready")

@@ -26,7 +26,7 @@
  * see tests/test_oracle_golden.py.  The sigmoid/BCE/SGD training loop of
  * main.c cannot be executed here (GraphBLAS absent) => for that part parity is
  * UNPINNED against a reference binary; it is cross-checked against an
- * independent float64 numpy restatement only (oracle/oracle_np.py).
+ * independent float64 numpy restatement only (oracle/oracle.py).
  *
  * Summation order.  GraphBLAS leaves the order of the PLUS reduction to its
  * kernels and main.c:278 accumulates remote pieces in message-arrival order,

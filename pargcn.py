@@ -12,5 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 _impl = importlib.import_module(
     "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd.pargcn")
 
+if __name__ != "__main__":
+    sys.modules[__name__] = _impl      # alias, not a copy: module globals set by callers reach the implementation
+
 if __name__ == "__main__":
     _impl.main(sys.argv[1:])

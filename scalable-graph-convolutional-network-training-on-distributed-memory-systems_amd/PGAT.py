@@ -75,14 +75,16 @@ def _provider():
 
 
 def _get_partition(A, partvec, rank, size):
-    key = (id(A), rank, size)
-    p = _partition_cache.get(key)
-    if p is None:
-        row, col, val = _pgcn._coo_tensors(A)
-        p = _partition.build_partition(row, col, val, A.shape[0], torch.as_tensor(partvec, dtype=torch.int64),
-                                       rank, size, with_transpose=False)
-        _partition_cache.clear()
-        _partition_cache[key] = p
+    """One-entry cache; the entry holds the matrix and is matched by identity + part-vector fingerprint
+    (see PGCN._get_partition)."""
+    key = ("gat", rank, size, tuple(A.shape), int(A.nnz), _pgcn._partvec_fingerprint(partvec))
+    ent = _partition_cache.get("entry")
+    if ent is not None and ent[0] is A and ent[1] == key:
+        return ent[2]
+    row, col, val = _pgcn._coo_tensors(A)
+    p = _partition.build_partition(row, col, val, A.shape[0], torch.as_tensor(partvec, dtype=torch.int64),
+                                   rank, size, with_transpose=False)
+    _partition_cache["entry"] = (A, key, p)
     return p
 
 
@@ -193,6 +195,16 @@ class PGAT(nn.Module):
 _all_reduce = _pgcn._all_reduce
 
 
+def _reduce_sum(t):
+    """Sum over ranks on the engine's own transport / stream when there is one (see PGCN._reduce_sum)."""
+    eng = _engine_current
+    if eng is not None and eng.size > 1 and eng.exch is not None and t.dtype is torch.float32:
+        eng.allreduce_sum(t)
+    else:
+        _all_reduce(t)
+    return t
+
+
 def average_gradients(model):
     """PGAT.py:153-157 (SUM, then / world_size)."""
     if world_size <= 1:
@@ -209,7 +221,7 @@ def sum_gradients(model):
         return
     grads = [p.grad.data for p in model.parameters()]
     flat = torch.cat([g.reshape(-1) for g in grads])
-    _all_reduce(flat)
+    _reduce_sum(flat)
     o = 0
     for g in grads:
         g.copy_(flat[o:o + g.numel()].view_as(g))

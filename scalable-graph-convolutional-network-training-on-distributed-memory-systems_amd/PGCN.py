@@ -79,16 +79,29 @@ def _coo_tensors(A):
             torch.from_numpy(np.ascontiguousarray(A.data, dtype=np.float32)))
 
 
+def _partvec_fingerprint(partvec):
+    pv = np.ascontiguousarray(np.asarray(partvec, dtype=np.int64))
+    return (int(pv.size), int(pv.sum()), int((pv * (np.arange(pv.size, dtype=np.int64) % 1000003 + 1)).sum()))
+
+
 def _get_partition(A, partvec, rank, size):
-    key = (id(A), rank, size)
-    p = _partition_cache.get(key)
-    if p is None:
-        row, col, val = _coo_tensors(A)
-        p = _partition.build_partition(row, col, val, A.shape[0],
-                                       torch.as_tensor(partvec, dtype=torch.int64), rank, size)
-        _partition_cache.clear()
-        _partition_cache[key] = p
+    """One-entry cache (compute_communication_maps and get_partitiont_of_adjacency_matrix are called back
+    to back on the same matrix, PGCN.py:178-179).  The entry HOLDS the matrix it was built from and is
+    matched by identity plus a fingerprint of the part vector, so a recycled id() or a new part vector
+    can never return a stale partition."""
+    key = (rank, size, tuple(A.shape), int(A.nnz), _partvec_fingerprint(partvec))
+    ent = _partition_cache.get("entry")
+    if ent is not None and ent[0] is A and ent[1] == key:
+        return ent[2]
+    row, col, val = _coo_tensors(A)
+    p = _partition.build_partition(row, col, val, A.shape[0],
+                                   torch.as_tensor(partvec, dtype=torch.int64), rank, size)
+    _partition_cache["entry"] = (A, key, p)
     return p
+
+
+def _seed_partition_cache(A, partvec, rank, size, p):
+    _partition_cache["entry"] = (A, (rank, size, tuple(A.shape), int(A.nnz), _partvec_fingerprint(partvec)), p)
 
 
 def compute_communication_maps(A, partvec, rank, size):
@@ -230,13 +243,25 @@ def _all_reduce(t, op=dist.ReduceOp.SUM):
     return t
 
 
+def _reduce_sum(t):
+    """Sum over ranks through the SAME transport (and stream) as the boundary-row exchange when an
+    engine exists -- one RCCL communicator carries every collective of a training step -- else
+    through torch.distributed."""
+    eng = _engine_current
+    if eng is not None and eng.size > 1 and eng.exch is not None and t.dtype is torch.float32:
+        eng.allreduce_sum(t)
+    else:
+        _all_reduce(t)
+    return t
+
+
 def average_gradients(model):
     """PGCN.py:150-154, as ONE fused all-reduce of all layers' gradients."""
     if world_size <= 1:
         return
     grads = [p.grad.data for p in model.parameters()]
     flat = torch.cat([g.reshape(-1) for g in grads])
-    _all_reduce(flat)
+    _reduce_sum(flat)
     flat /= world_size
     o = 0
     for g in grads:
@@ -245,12 +270,17 @@ def average_gradients(model):
 
 
 def initiliaze_parameters(model):
-    """PGCN.py:156-160."""
+    """PGCN.py:156-160 (one fused all-reduce instead of one per layer)."""
     if world_size <= 1:
         return
-    for param in model.parameters():
-        _all_reduce(param.data)
-        param.data /= world_size
+    params = [p.data for p in model.parameters()]
+    flat = torch.cat([p.reshape(-1) for p in params])
+    _reduce_sum(flat)
+    flat /= world_size
+    o = 0
+    for p in params:
+        p.copy_(flat[o:o + p.numel()].view_as(p))
+        o += p.numel()
 
 
 def local_loss(logits, labels, n_global):
@@ -282,20 +312,21 @@ def run(rank, size, nlayers, nfeatures, path_A, path_partvec, backend):
 
     with open(path_partvec) as f:
         partvec = list(map(int, f.readline().split()))
+    _partition_cache.clear()
     if os.environ.get("PGCN_INGEST", "global") == "rows" and size > 1:
         # every rank keeps ONLY its rows (pgcn_load_mtx_partition) and the partition is completed by two
         # small collectives instead of a scan of the whole matrix on every rank (PGCN.py:37-64)
         A = _ingest.load_partition(path_A, partvec, rank)
         row, col, val = _coo_tensors(A)
-        _partition_cache.clear()
-        _partition_cache[(id(A), rank, size)] = _partition.build_partition_local(
-            row, col, val, A.shape[0], torch.as_tensor(partvec, dtype=torch.int64), rank, size)
+        _seed_partition_cache(A, partvec, rank, size, _partition.build_partition_local(
+            row, col, val, A.shape[0], torch.as_tensor(partvec, dtype=torch.int64), rank, size))
     else:
         A = _ingest.mmread(path_A)      # C++ multi-threaded reader, same result as scipy's mmread
     n = A.shape[0]
 
     send_map, recv_map = compute_communication_maps(A, partvec, rank, size)
     A = get_partitiont_of_adjacency_matrix(A, partvec, rank)
+    _partition_cache.clear()              # the engine owns the pieces now; let the host matrix go
     send_buffers, recv_buffers = {}, {}   # persistent slabs live inside the engine
 
     init_stats()

@@ -230,6 +230,33 @@ class BoundaryExchange:
                 waiters.append(lambda d=done: main.wait_event(d))
         return waiters
 
+    def allreduce_sum(self, buf: torch.Tensor) -> None:
+        """Sum ``buf`` (fp32, contiguous) over the ranks through the exchange transport.  With the
+        comm stream on, the collective is issued THERE (after the producers of ``buf`` on the compute
+        stream) so that every operation of the communicator is ordered on one stream; the compute
+        stream waits for its completion."""
+        if self.size == 1:
+            return
+        if not buf.is_contiguous():
+            raise ValueError("allreduce_sum needs a contiguous buffer")
+        if buf.is_cuda and getattr(self.exch, "backend", "") == "gloo":
+            h = buf.cpu()
+            self.exch.allreduce_sum(h)
+            buf.copy_(h)
+            return
+        if not self.overlap:
+            self.exch.allreduce_sum(buf)
+            return
+        main = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            self.exch.allreduce_sum(buf)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+        buf.record_stream(self.comm_stream)
+        main.wait_event(done)
 
 
 class AggregationEngine(BoundaryExchange):

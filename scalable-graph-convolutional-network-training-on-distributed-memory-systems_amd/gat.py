@@ -151,7 +151,7 @@ class GatEngine(BoundaryExchange):
 
     def _allreduce(self, buf: torch.Tensor) -> torch.Tensor:
         if self.size > 1:
-            self.exch.allreduce_sum(buf)
+            self.allreduce_sum(buf)          # BoundaryExchange: same communicator AND stream as the slabs
         return buf
 
     # -- forward ---------------------------------------------------------

@@ -128,11 +128,11 @@ def main(argv, kernels=None, out=None):
     Ym = torch.from_numpy(prob["Ymask"][own]).to(dev)
     allreduce = None
     if world > 1:
-        def allreduce(t):
-            if t.is_cuda and dist.get_backend() == "gloo":
-                h = t.cpu(); dist.all_reduce(h); t.copy_(h)
-            else:
-                dist.all_reduce(t)
+        def allreduce(t):          # main.c:321,425 MPI_Allreduce SUM -- on the engine's own transport / stream
+            c = t.contiguous()
+            eng.allreduce_sum(c)
+            if c is not t:
+                t.copy_(c)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     tic = time.time()
@@ -148,10 +148,13 @@ def main(argv, kernels=None, out=None):
     st = torch.tensor([rows_out * sum(widths) * 3, rows_in * sum(widths) * 3, nz_t * len(widths) * 3,
                        nz_s * len(widths) * 3], dtype=torch.float64)
     if world > 1:
-        tot, mx = st.clone(), st.clone()
+        # NCCL (= RCCL) process groups only move device tensors, gloo only host tensors here
+        wire = dev if (dev.type == "cuda" and dist.get_backend() != "gloo") else torch.device("cpu")
+        tot, mx, el = st.to(wire), st.to(wire), elapsed.to(wire)
         dist.all_reduce(tot)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        tot, mx, elapsed = tot.cpu(), mx.cpu(), el.cpu()
     else:
         tot, mx = st, st
     if rank == 0:

@@ -1,0 +1,141 @@
+"""Command lines end to end: `python bench.py --gpus N` (the driver's form, self-launching for N > 1) and the
+drop-in `python PGCN.py -a .. -p .. -b .. -s .. -l .. -f ..` (reference: GPU/PGCN.py:256-283 main / init_process,
+stdout lines :224,230,237,238,249)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, gpath
+
+_STRIP = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "SLURM_PROCID", "SLURM_NPROCS", "MASTER_PORT",
+          "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in _STRIP}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.update({k: str(v) for k, v in kw.items()})
+    return env
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "expected ONE JSON line, got %d:\n%s" % (len(lines), stdout[-2000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the launch mechanics on a box without a GPU")
+def test_bench_self_launch_starts_every_rank_and_fails_loudly_without_gpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start 2 ranks itself; without a
+    GPU every rank refuses to run (no CPU fallback) and says which rank it is."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cora",
+                          "--steps", "1", "--warmup", "0"], env=_env(PGCN_BENCH_BACKEND="gloo"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "[rank 0 of 2]" in out.stderr and "[rank 1 of 2]" in out.stderr, out.stderr[-3000:]
+    assert "needs an MI355X" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_small_workload():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "cora",
+                          "--steps", "3", "--warmup", "1", "--cpu-budget", "1"], env=_env(),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["value"] > 0
+    assert rec["roofline"] and rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
+    assert rec["cpu_baseline"] and rec["cpu_baseline"]["value"] > 0
+    assert np.isfinite(rec["loss"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [2, 4])
+def test_bench_self_launch_n_ranks_share_the_gpu(N):
+    """The exact command form the driver uses for N = 1, with N > 1 and nothing else: the ranks are started by
+    bench.py itself (here they share the one GPU and talk over gloo; real kernels, comm-stream overlap on)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(N), "--workload", "cora",
+                          "--steps", "3", "--warmup", "1"], env=_env(PGCN_BENCH_BACKEND="gloo"),
+                         capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["n_gpus"] == N and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["config"]["partition"] != "none" and rec["exchange_rows_total"] > 0
+    assert np.isfinite(rec["loss"])
+
+
+def _run_pgcn_cli(ranks, size, backend, mtx, pv, L, f, port):
+    procs = []
+    for r in ranks:
+        env = _env(SLURM_NPROCS=size, SLURM_PROCID=r, MASTER_PORT=port, WORLD_SIZE=size)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "PGCN.py"), "-a", gpath(mtx), "-p", gpath(pv),
+                                       "-b", backend, "-s", str(size), "-l", str(L), "-f", str(f)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(o)
+    return outs
+
+
+def _check_stdout(out, rank, size, L, n_epochs=4):
+    """The reference's lines: :249 process-group echo, :224 per-epoch loss (rank 0), :230 stats dict (every rank),
+    :237 elapsed and :238 totals (rank 0)."""
+    assert re.search(r"\[\d+\] Initializing process group with: \{'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '\d+', "
+                     r"'RANK': '%d', 'WORLD_SIZE': '%d'\}" % (rank, size), out), out
+    m = re.search(r"\{'send_volume': tensor\((\d+)\), 'recv_volume': tensor\((\d+)\), 'send_nmsg': tensor\((\d+)\), "
+                  r"'recv_nmsg': tensor\((\d+)\)\}", out)
+    assert m, out
+    losses = [float(x) for x in re.findall(r"Epoch (?:0000\d) \| Loss ([0-9.]+)", out)]
+    if rank == 0:
+        assert len(losses) == n_epochs and all(np.isfinite(losses))
+        assert re.search(r"Elapsed time \d+\.\d{4}", out)
+        t = re.search(r"total_vol: (\d+) total_nmsg: (\d+)", out)
+        assert t, out
+        return [int(x) for x in m.groups()], [int(x) for x in t.groups()], losses
+    assert not losses and "Elapsed time" not in out and "total_vol" not in out
+    return [int(x) for x in m.groups()], None, losses
+
+
+@pytest.mark.gpu
+def test_pgcn_main_single_rank_rccl_backend():
+    """a10: `python PGCN.py ... -b nccl -s 1` with SLURM_* in the environment, through main() -> spawn ->
+    init_process(nccl = RCCL) -> run()."""
+    L, f = 3, 16
+    (out,) = _run_pgcn_cli([0], 1, "nccl", "karate.A.mtx", "karate.mtx.1.rp", L, f, 29741)
+    stats, tot, losses = _check_stdout(out, 0, 1, L)
+    assert stats == [0, 0, 0, 0] and tot == [0, 0]
+    assert losses[-1] <= losses[0]
+
+
+@pytest.mark.gpu
+def test_pgcn_main_three_ranks_share_the_gpu():
+    """a10 with P = 3 (one invocation per rank, as under srun): KATs of the message statistics
+    (5 epochs x 2L exchanges x rows / peers, GPU/PGCN.py:105-114)."""
+    from scipy.io import mmread
+    import scipy.sparse as sp
+    from oracle import oracle
+    from conftest import read_partvec
+    L, f, P = 2, 16, 3
+    outs = _run_pgcn_cli(range(P), P, "gloo", "gemat11p.A.mtx", "gemat11.mtx.3.hp", L, f, 29743)
+    A = sp.csr_matrix(mmread(gpath("gemat11p.A.mtx"))).astype(np.float32)
+    part = read_partvec(gpath("gemat11.mtx.3.hp"))
+    rows_total = 0
+    for r in range(P):
+        stats, tot, _ = _check_stdout(outs[r], r, P, L)
+        smap, rmap = oracle.communication_maps(A, part, r, P)
+        rows_out, rows_in = sum(v.size for v in smap.values()), sum(v.size for v in rmap.values())
+        nx = 5 * L * 2
+        assert stats == [rows_out * nx, rows_in * nx, (P - 1) * nx, (P - 1) * nx]
+        rows_total += rows_out
+        if r == 0:
+            totals = tot
+    assert totals == [rows_total * 5 * L * 2, P * (P - 1) * 5 * L * 2]
