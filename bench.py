@@ -252,6 +252,9 @@ def main():
             except Exception:
                 traffic = None
         kname = "A_loc.H forward SpMM = spmm_tasks_kernel<32,4,1,1> (gather part)"
+        if getattr(eng.A_loc, "strip", None) is not None:
+            kname += " + spmm_strip_kernel (512x128 strip tiles, async LDS pipeline, %.0f%% of the entries)" % (
+                100.0 * eng.A_loc.strip.nnz / max(eng.A_loc.nnz, 1))
         if eng.A_loc.core is not None:
             kname += " + spmm_core_kernel<4> (LDS-tiled dense core, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.core.nnz / max(eng.A_loc.nnz, 1))

@@ -47,6 +47,8 @@ typedef void *pgcn_stream_t; /* hipStream_t */
 #define PGCN_MAX_COL_GROUPS 64   /* column groups per slice (time slicing of the column space) */
 #define PGCN_CORE_TR 128         /* rows per tile of the LDS-tiled core kernel    */
 #define PGCN_CORE_TC 128         /* columns per panel of the LDS-tiled core kernel */
+#define PGCN_STRIP_TR 512        /* rows per tile of the strip kernel (pgcn_spmm_strip_f32) */
+#define PGCN_STRIP_B 2           /* pair slots per row and strip record                  */
 
 int pgcn_abi_version(void);
 const char *pgcn_last_error(void);
@@ -152,6 +154,24 @@ int pgcn_spmm_core_f32(const int32_t *work, int64_t nwork, const int32_t *tile_p
                        const float *cval, const float *B, int64_t ldb, int64_t ncols, int32_t f,
                        float *partial_ws, int64_t partial_ws_elems, int64_t nslots_total,
                        pgcn_stream_t stream);
+
+/* ---- strip tiles: 512 x 128, LDS-staged, asynchronous double-buffered pipeline -------------
+ * Same product (torch.sparse.mm, GPU/PGCN.py:127,132) for the entries of TALL tiles: a 1024-thread
+ * workgroup stages the 128 feature rows of a column panel in LDS once (global_load_lds, one record
+ * ahead) and serves all entries of its 512 matrix rows from LDS; pays from 128 entries per tile on.
+ *   work  4 x int32 per piece {tile row, first record, one-past-last record, first slot}
+ *   recs  4 x int32 per record {panel, flags, stored entries, layer}; flags bit 0: the panel is the
+ *         one the previous record of the piece staged.  A record is one LAYER of a tile: the
+ *         (2 l)-th and (2 l + 1)-th stored entry (column order) of every one of its 512 rows
+ *   pairs 512 x 2 int32 pairs per record {byte offset of the column's row in the staged panel
+ *         (= column-in-panel * 512), value bits}, rows in (group, row slot) order with local row =
+ *         row slot * 32 + group; an unused slot holds {65536 (an all-zero LDS row), 0.0f}
+ * A piece leaves 512 partial rows in slots [first slot, first slot + 512) of partial_ws for
+ * pgcn_spmm_fixup_f32.  All three arrays 16-byte aligned.  f % 4 == 0 with 16-byte aligned B /
+ * partial_ws takes the LDS pipeline (128 features per workgroup); anything else a plain kernel. */
+int pgcn_spmm_strip_f32(const int32_t *work, int64_t nwork, const int32_t *recs, const int32_t *pairs,
+                        const float *B, int64_t ldb, int64_t ncols, int32_t f, float *partial_ws,
+                        int64_t partial_ws_elems, int64_t nslots_total, pgcn_stream_t stream);
 
 /* The densest tiles through the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32, k-ordered
  * fmaf chains).  A tile is stored dense, pre-swizzled into the A-operand order:

@@ -45,6 +45,7 @@ SIGNATURES = {
                                               _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),
     "pgcn_spmm_core_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp,
                                           _i64, _i64, _vp]),
+    "pgcn_spmm_strip_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
     "pgcn_spmm_dense_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
     "pgcn_spmm_fused_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                            _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),

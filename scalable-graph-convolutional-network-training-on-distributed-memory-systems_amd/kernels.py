@@ -50,6 +50,7 @@ class DeviceCSR:
     ws: Optional[torch.Tensor] = None     # fp32 work-space for split rows (grown on demand)
     core: Optional["DeviceCore"] = None   # dense-tile part (LDS-tiled kernel)
     dense: Optional["DeviceDense"] = None  # densest tiles (fp32 matrix cores)
+    strip: Optional["DeviceStrip"] = None  # 512 x 128 strip tiles (LDS-staged, async pipeline)
     fix_all: Optional[torch.Tensor] = None    # int32 [nfix_all,4] combined fix list (core + gather slots)
     slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
     nslots_total: int = 0
@@ -77,6 +78,15 @@ class DeviceDense:
     work: torch.Tensor
     tile_panel: torch.Tensor
     vals: torch.Tensor
+    npieces: int
+    nnz: int
+
+
+@dataclass
+class DeviceStrip:
+    work: torch.Tensor
+    rec: torch.Tensor
+    pairs: torch.Tensor
     npieces: int
     nnz: int
 
@@ -217,38 +227,50 @@ class HipKernels:
             d.ntasks, d.nfix, d.nslots = tasks.shape[0], fix.shape[0], nslots
             d.nslices, d.seg = csr.nslices if sc is not None else 1, seg
         d.nslots_total = d.nslots
-        if csr.core is not None or csr.dense is not None:
+        if csr.core is not None or csr.dense is not None or csr.strip is not None:
             self._attach_core(d, csr, fix if tasks is not None else None)
         return d
 
     def _attach_core(self, d: DeviceCSR, csr: HostCSR, fix_rem: Optional[np.ndarray]) -> None:
         """Upload the tiled parts (LDS core, MFMA tiles) and build the per-row slot lists: a row's
         partial sums are its core pieces (in work order), its dense pieces, then its gather-kernel slots."""
-        from .partition import CORE_TR
+        from .partition import CORE_TR, STRIP_TR
         dev = self.device
-        hc, hd = csr.core, csr.dense
+        hc, hd, hs = csr.core, csr.dense, csr.strip
         ns_rem = d.nslots
-        pieces = []                                                # (tile row, first slot) of every piece
-        ns_core = 0
+        pieces = []                                                # (first row, rows, first slot) of every piece
+        ns_core = ns_strip = 0
+        if hs is not None:
+            work = hs.work.clone()
+            work[:, 3] += ns_rem                                   # strip slots live behind the gather slots
+            d.strip = DeviceStrip(work.to(dev).contiguous(), hs.rec.to(dev).contiguous(), hs.pairs.to(dev).contiguous(),
+                                  hs.npieces, hs.nnz)
+            w64 = work.cpu().to(torch.int64)
+            pieces.append(torch.stack([w64[:, 0] * STRIP_TR, torch.full_like(w64[:, 0], STRIP_TR), w64[:, 3]], 1))
+            ns_strip = hs.nslots
         if hc is not None:
             work = hc.work.clone()
-            work[:, 3] += ns_rem                                   # core slots live behind the gather slots
+            work[:, 3] += ns_rem + ns_strip                        # core slots behind those
             d.core = DeviceCore(work.to(dev).contiguous(), hc.tile_panel.to(dev), hc.tile_base.to(dev),
                                 hc.seg_off.to(dev).contiguous(), hc.ccol.to(dev), hc.cval.to(dev),
                                 hc.npieces, hc.nnz)
-            pieces.append(work.cpu().to(torch.int64)[:, [0, 3]])
+            w64 = work.cpu().to(torch.int64)
+            pieces.append(torch.stack([w64[:, 0] * CORE_TR, torch.full_like(w64[:, 0], CORE_TR), w64[:, 3]], 1))
             ns_core = hc.nslots
         if hd is not None:
             work = hd.work.clone()
-            work[:, 3] += ns_rem + ns_core                         # ... and the MFMA pieces behind those
+            work[:, 3] += ns_rem + ns_strip + ns_core              # ... and the MFMA pieces behind those
             d.dense = DeviceDense(work.to(dev).contiguous(), hd.tile_panel.to(dev).contiguous(),
                                   hd.vals.to(dev).contiguous(), hd.npieces, hd.nnz)
-            pieces.append(work.cpu().to(torch.int64)[:, [0, 3]])
+            w64 = work.cpu().to(torch.int64)
+            pieces.append(torch.stack([w64[:, 0] * CORE_TR, torch.full_like(w64[:, 0], CORE_TR), w64[:, 3]], 1))
         wk = torch.cat(pieces)
-        rit = torch.arange(CORE_TR, dtype=torch.int64)
-        rows = (wk[:, 0:1] * CORE_TR + rit[None, :]).reshape(-1)
-        slots = (wk[:, 1:2] + rit[None, :]).reshape(-1)
-        seq = torch.arange(wk.shape[0], dtype=torch.int64).repeat_interleave(CORE_TR)
+        cntp = wk[:, 1]
+        startp = torch.cumsum(cntp, 0) - cntp
+        rit = torch.arange(int(cntp.sum()), dtype=torch.int64) - torch.repeat_interleave(startp, cntp)
+        rows = torch.repeat_interleave(wk[:, 0], cntp) + rit
+        slots = torch.repeat_interleave(wk[:, 2], cntp) + rit
+        seq = torch.repeat_interleave(torch.arange(wk.shape[0], dtype=torch.int64), cntp)
         ok = rows < csr.nrows
         rows, slots, seq = rows[ok], slots[ok], seq[ok]
         if fix_rem is not None and fix_rem.shape[0]:
@@ -267,7 +289,7 @@ class HipKernels:
         fix_all = torch.stack([urows, begin, counts, torch.zeros_like(urows)], 1).to(torch.int32)
         d.fix_all = fix_all.to(dev).contiguous()
         d.slot_ids = slots.to(torch.int32).to(dev).contiguous()
-        d.nslots_total = ns_rem + ns_core + (hd.nslots if hd is not None else 0)
+        d.nslots_total = ns_rem + ns_strip + ns_core + (hd.nslots if hd is not None else 0)
         d.nnz = csr.nnz
         if d.ntasks and d.val is not None and hc is not None:
             fw = fused_work_list(d.seg, d.nslices, d.ntasks, hc.npieces, gb=self.fused_gb)
@@ -315,7 +337,7 @@ class HipKernels:
         lib, check, stream = self.lib, _lib.check, self._stream
         if A.nrows == 0:
             return lambda B, C: None
-        if A.nnz == 0 and A.core is None and A.dense is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
+        if A.nnz == 0 and A.core is None and A.dense is None and A.strip is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
             if accumulate:
                 return lambda B, C: None
             if A.row_map is None:
@@ -323,7 +345,7 @@ class HipKernels:
             rows = A.row_map.long()
             return lambda B, C: C.index_fill_(0, rows, 0.0)
         rowptr, col, val, rmap = A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), _ptr(A.row_map)
-        if A.tasks is None and A.row_map is None and A.core is None and A.dense is None:
+        if A.tasks is None and A.row_map is None and A.core is None and A.dense is None and A.strip is None:
             nrows = A.nrows
             def simple(B, C):
                 check(lib.pgcn_spmm_csr_f32(rowptr, col, val, nrows, B.data_ptr(), ldb, C.data_ptr(), ldc, f,
@@ -334,9 +356,9 @@ class HipKernels:
             A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
             A.launch_cache.clear()              # other bindings hold the old work-space pointer
         ws, ws_n = _ptr(A.ws), (0 if A.ws is None else A.ws.numel())
-        tasks, ntasks, seg, nslices = A.tasks.data_ptr(), A.ntasks, A.seg, A.nslices
+        tasks, ntasks, seg, nslices = _ptr(A.tasks), A.ntasks, A.seg, A.nslices
         nslots = A.nslots
-        if A.core is None and A.dense is None:
+        if A.core is None and A.dense is None and A.strip is None:
             fix, nfix = _ptr(A.fix), A.nfix
             def planned(B, C):
                 check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, rmap,
@@ -344,7 +366,9 @@ class HipKernels:
                                                  stream()), "pgcn_spmm_csr_plan_f32")
             return planned
         # gather part (partial sums stay in the work-space) + LDS-tiled core + MFMA tiles + one combined fix-up
-        co, de = A.core, A.dense
+        co, de, st = A.core, A.dense, A.strip
+        if st is not None:
+            sw, sn, srec, spairs = st.work.data_ptr(), st.npieces, st.rec.data_ptr(), st.pairs.data_ptr()
         if co is not None:
             cw, cn, ctp, ctb, cso, ccol, cval = (co.work.data_ptr(), co.npieces, co.tile_panel.data_ptr(),
                                                  co.tile_base.data_ptr(), co.seg_off.data_ptr(), co.ccol.data_ptr(),
@@ -377,6 +401,9 @@ class HipKernels:
         side_first = os.environ.get("PGCN_CORE_OVERLAP", "0") == "2"
 
         def tiled(b, cs):
+            if st is not None:
+                check(lib.pgcn_spmm_strip_f32(sw, sn, srec, spairs, b, ldb, ncols, f, ws, ws_n, nst, cs),
+                      "pgcn_spmm_strip_f32")
             if de is not None:
                 check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, cs),
                       "pgcn_spmm_dense_f32")

@@ -44,12 +44,13 @@ class HostCSR:
     core: Optional["HostCore"] = None         # entries of dense tiles, stored for the LDS-tiled kernel
     row_flags: Optional[torch.Tensor] = None  # uint8 [nrows]: row also receives core partial sums
     dense: Optional["HostDense"] = None       # the densest tiles, stored dense for the fp32 matrix cores
+    strip: Optional["HostStrip"] = None       # entries of 512 x 128 strip tiles (LDS-staged, async pipeline)
 
     @property
     def nnz(self) -> int:
-        """Stored entries of the whole block (gather part + LDS core + MFMA tiles)."""
+        """Stored entries of the whole block (gather part + LDS core / strips + MFMA tiles)."""
         return int(self.col.numel()) + (self.core.nnz if self.core is not None else 0) + \
-            (self.dense.nnz if self.dense is not None else 0)
+            (self.dense.nnz if self.dense is not None else 0) + (self.strip.nnz if self.strip is not None else 0)
 
     def to_coo(self):
         """(row, col, val) of the whole block, core included (tests / checker only)."""
@@ -64,6 +65,9 @@ class HostCSR:
         if self.dense is not None:
             dr, dc, dv = self.dense.coo
             r, c, v = torch.cat([r, dr]), torch.cat([c, dc]), torch.cat([v, dv])
+        if self.strip is not None:
+            sr, sc, sv = self.strip.to_coo()
+            r, c, v = torch.cat([r, sr]), torch.cat([c, sc]), torch.cat([v, sv])
         return r, c, v
 
 
@@ -189,6 +193,146 @@ def build_dense(r64, c64, v, tkey_local, ntiles, tile_row, tile_panel, nrows, nc
                      (r64, c64, v.to(torch.float32)))
 
 
+# ---- strip tiles (pgcn_spmm_strip_f32) ---------------------------------------------------------
+# A gather through the vector L1 costs one 512 B row of the dense operand per stored entry and tops
+# out near 18 TB/s even when every row hits in L2 (r02 probe: uniform hot-set SpMM).  Staging a
+# 128-row panel once in LDS and serving every entry of a TALL tile from there costs 64 KB per tile
+# instead of 512 B per entry: a 512 x 128 tile pays off from 128 entries (0.2 % fill) on.
+STRIP_ON = os.environ.get("PGCN_STRIP", "1") != "0"
+STRIP_TR = 512     # rows per strip tile   (PGCN_STRIP_TR in include/pgcn_hip.h)
+STRIP_NG = 32      # 32-lane groups per workgroup (1024 threads)
+STRIP_RW = STRIP_TR // STRIP_NG   # 16 row slots per group, row-in-tile = j * NG + group
+STRIP_B = 2        # pair slots per row and record (PGCN_STRIP_B)
+STRIP_REC = STRIP_TR * STRIP_B    # pairs per record (8 KB)
+STRIP_PAD_OFF = 128 * 512         # byte offset of the all-zero LDS row: what an unused pair slot points at
+# Thresholds (measured, r02 sweep on the Reddit- and products-shaped graphs): a record costs ~6 k clk of LDS
+# time whatever it holds (1 024 slots), the gather kernel ~17-28 clk per entry, so a layer must hold a few
+# hundred stored entries to pay for itself.
+STRIP_MIN = int(os.environ.get("PGCN_STRIP_MIN", "512"))        # entries that make a 512 x 128 tile worth staging
+STRIP_LAYER_MIN = int(os.environ.get("PGCN_STRIP_LAYER_MIN", "384"))   # stored entries that make one more record of a tile worth it
+STRIP_THEN_CORE = os.environ.get("PGCN_STRIP_CORE", "0") != "0"   # legacy 128 x 128 LDS core on what the strips leave
+STRIP_PIECES = int(os.environ.get("PGCN_STRIP_PIECES", "1024"))  # target number of work pieces
+STRIP_STAGE_COST = float(os.environ.get("PGCN_STRIP_STAGE_COST", "1.0"))  # staging a panel ~ this many records of work
+
+
+@dataclass
+class HostStrip:
+    """Entries of the strip tiles, laid out for pgcn_spmm_strip_f32.
+
+    A RECORD is one LAYER of one 512 x 128 tile: the (2 l)-th and (2 l + 1)-th stored entry (column
+    order) of every row of the tile -- exactly 2 pair slots per row, rows in (group, row slot) order
+    with local row = j * 32 + group, so the kernel is straight-line code without counts.  A pair is
+    {byte offset of the column's row inside the staged panel (column * 512), value bits}; an unused
+    slot holds {STRIP_PAD_OFF (an all-zero LDS row), 0.0}."""
+    nrows: int
+    ncols: int
+    work: torch.Tensor      # int32 [npieces, 4] {tile row, first record, one-past-last record, first slot (local)}
+    rec: torch.Tensor       # int32 [nrec, 4]    {panel, flags (1 = panel of the previous record), stored entries, layer}
+    pairs: torch.Tensor     # int32 [nrec, STRIP_REC, 2]
+    rec_tile_row: torch.Tensor   # int32 [nrec] (host bookkeeping)
+    nnz_: int
+
+    @property
+    def nnz(self) -> int:
+        return self.nnz_
+
+    @property
+    def npieces(self) -> int:
+        return int(self.work.shape[0])
+
+    @property
+    def nslots(self) -> int:
+        return self.npieces * STRIP_TR
+
+    def to_coo(self):
+        """(row, col, val) of the stored entries, decoded from the device layout (tests / checker)."""
+        dev = self.pairs.device
+        nrec = int(self.rec.shape[0])
+        off = self.pairs[:, :, 0].reshape(-1).to(torch.int64)
+        real = off != STRIP_PAD_OFF
+        pos = torch.arange(nrec * STRIP_REC, device=dev)[real]
+        rec_id, inrec = pos // STRIP_REC, pos % STRIP_REC
+        g, j = inrec // (STRIP_RW * STRIP_B), (inrec // STRIP_B) % STRIP_RW
+        rows = self.rec_tile_row.to(torch.int64)[rec_id] * STRIP_TR + j * STRIP_NG + g
+        cols = self.rec[:, 0].to(torch.int64)[rec_id] * CORE_TC + off[real] // 512
+        vals = self.pairs[:, :, 1].reshape(-1)[real].contiguous().view(torch.float32)
+        return rows, cols, vals
+
+
+def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
+                 min_entries: int = None, pieces: int = None, layer_min: int = None):
+    """Split off the entries of 512 x 128 tiles holding at least ``min_entries`` stored entries, layer
+    by layer (2 entries per row and layer) while a layer holds at least ``layer_min`` entries.
+    Returns (keep_mask or None, HostStrip or None); ``keep_mask`` marks what stays in the gather part."""
+    import numpy as np
+    TR, TC, NG, RW, SB = STRIP_TR, CORE_TC, STRIP_NG, STRIP_RW, STRIP_B
+    min_entries = STRIP_MIN if min_entries is None else min_entries
+    layer_min = min(STRIP_LAYER_MIN, max(1, min_entries)) if layer_min is None else layer_min
+    pieces = STRIP_PIECES if pieces is None else pieces
+    dev = r64.device
+    if r64.numel() == 0:
+        return None, None
+    ncp = (ncols + TC - 1) // TC
+    tkey = (r64 // TR) * ncp + c64 // TC
+    # rank of every entry inside its (tile, row): position in (tile, row, column) order minus the run start
+    order = torch.argsort((tkey * TR + r64 % TR) * TC + c64 % TC, stable=True)
+    tk_s, rit_s = tkey[order], (r64 % TR)[order]
+    run = tk_s * TR + rit_s
+    newrun = torch.ones_like(run, dtype=torch.bool)
+    newrun[1:] = run[1:] != run[:-1]
+    idx = torch.arange(run.numel(), device=dev)
+    run_first = idx[newrun][torch.cumsum(newrun.to(torch.int64), 0) - 1]     # first position of every entry's run
+    layer = (idx - run_first) // SB
+    slot = (idx - run_first) % SB
+    # tiles worth staging, then their layers worth a record
+    ut, tinv, tcnt = torch.unique(tk_s, return_inverse=True, return_counts=True)
+    lkey = tk_s * 64 + torch.clamp(layer, max=63)                # a row holds at most 128 entries per panel = 64 layers
+    ul, linv, lcnt = torch.unique(lkey, return_inverse=True, return_counts=True)
+    lsel = (lcnt >= max(1, layer_min)) & (tcnt[torch.searchsorted(ut, ul // 64)] >= max(1, min_entries))
+    # layers of a tile shrink monotonically, so the kept layers of a tile are a prefix 0..L-1
+    nrec = int(lsel.sum())
+    if nrec == 0:
+        return None, None
+    in_s = lsel[linv]
+    rmap = torch.cumsum(lsel.to(torch.int64), 0) - 1
+    e_rec = rmap[linv[in_s]]                                     # record of every strip entry (tile major, layer minor)
+    rit = rit_s[in_s]
+    g_e, j_e = rit % NG, rit // NG
+    pairs = torch.zeros((nrec * STRIP_REC, 2), dtype=torch.int32, device=dev)
+    pairs[:, 0] = STRIP_PAD_OFF
+    dst = e_rec * STRIP_REC + (g_e * RW + j_e) * SB + slot[in_s]
+    cs, vs = c64[order][in_s], v[order][in_s].to(torch.float32)
+    pairs[dst, 0] = ((cs % TC) * 512).to(torch.int32)
+    pairs[dst, 1] = vs.contiguous().view(torch.int32)
+    rk = ul[lsel]
+    rec_tile, rec_layer = rk // 64, rk % 64
+    rec_row, rec_panel = rec_tile // ncp, rec_tile % ncp
+    rec_cnt = lcnt[lsel]
+    # pieces: runs of records of one tile row, cut at ~equal cost (host side, ~10^5 records)
+    rtr = rec_row.cpu().numpy()
+    rpn = rec_panel.cpu().numpy()
+    newpanel = np.r_[True, (rtr[1:] != rtr[:-1]) | (rpn[1:] != rpn[:-1])]
+    cost = 1.0 + STRIP_STAGE_COST * newpanel
+    target = max(cost.sum() / max(pieces, 1), 1.0 + STRIP_STAGE_COST)
+    run_start = np.r_[True, rtr[1:] != rtr[:-1]]
+    cum = np.cumsum(cost) - cost
+    run_base = np.maximum.accumulate(np.where(run_start, cum, 0))
+    pid_local = ((cum - run_base) // target).astype(np.int64)
+    newp = np.r_[True, run_start[1:] | (pid_local[1:] != pid_local[:-1])]
+    kbeg = np.nonzero(newp)[0]
+    kend = np.r_[kbeg[1:], nrec]
+    pcost = np.add.reduceat(cost, kbeg)
+    lpt = np.argsort(-pcost, kind="stable")
+    work = np.stack([rtr[kbeg][lpt], kbeg[lpt], kend[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
+    same = (~newpanel) & (~newp)                                 # panel already staged by the previous record of the piece
+    rec = torch.stack([rec_panel, torch.from_numpy(same.astype(np.int64)).to(dev), rec_cnt, rec_layer], 1).to(torch.int32)
+    strip = HostStrip(nrows, ncols, torch.from_numpy(work).to(dev), rec.contiguous(),
+                      pairs.view(nrec, STRIP_REC, 2).contiguous(), rec_row.to(torch.int32), int(in_s.sum()))
+    keep = torch.ones(r64.numel(), dtype=torch.bool, device=dev)
+    keep[order[in_s]] = False
+    return keep, strip
+
+
 def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
                tau: float = None, emax: int = None, dense_tau: float = None):
     """Separate the entries of dense tiles.  Returns (keep_mask, HostCore or None, HostDense or None):
@@ -287,31 +431,59 @@ def pick_ngroups(ncols: int, nslices: int) -> int:
 def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
                  compact_rows: bool = False, nslices: Optional[int] = None, core: bool = False,
                  tau: float = None, emax: int = None, ngroups: Optional[int] = None,
-                 dense_tau: float = None) -> HostCSR:
-    """Sort by (row, col % nslices, col) and build CSR.  Duplicate entries are kept as
+                 dense_tau: float = None, slice_bounds: Optional[torch.Tensor] = None,
+                 strip: Optional[bool] = None, strip_min: Optional[int] = None) -> HostCSR:
+    """Sort by (row, slice, col) and build CSR.  Duplicate entries are kept as
     separate stored entries (an uncoalesced COO sums them, PGCN.py:63).  With ``core``
-    the entries of dense 128 x 128 tiles are split off into a HostCore (LDS-tiled kernel)."""
+    the entries of dense 128 x 128 tiles are split off into a HostCore (LDS-tiled kernel).
+    slice of a column = col % nslices, or -- with ``slice_bounds`` (nslices+1 ascending column
+    bounds) -- the RANGE it falls in: then the rows of the dense operand that one XCD gathers are
+    contiguous in memory instead of 4 KB apart."""
     dev = r.device
+    if slice_bounds is not None:
+        slice_bounds = torch.as_tensor(slice_bounds, dtype=torch.int64, device=dev)
+        nslices = int(slice_bounds.numel()) - 1
     if nslices is None:
         nslices = pick_nslices(ncols)
     S = nslices
+
+    def slice_of(c64):
+        if slice_bounds is None:
+            return c64 % S
+        return torch.bucketize(c64, slice_bounds[1:-1], right=True)
     G = pick_ngroups(ncols, S) if ngroups is None else (ngroups if S > 1 else 1)
     gw = max(1, -(-ncols // G))          # columns per group
-    hcore, hdense, row_flags = None, None, None
+    hcore, hdense, hstrip, row_flags = None, None, None, None
     if core and not compact_rows and r.numel():
-        keep, hcore, hdense = split_core(r, c, v, nrows, ncols, tau, emax, dense_tau)
-        tiled = (hcore.nnz if hcore is not None else 0) + (hdense.nnz if hdense is not None else 0)
-        if tiled and tau is None and (tiled < CORE_MIN_NNZ or tiled < CORE_MIN_FRAC * r.numel()):
-            hcore = hdense = None     # a small tiled part does not pay for the extra kernel + fix-up launches
-        if hcore is not None or hdense is not None:
+        use_strip = STRIP_ON if strip is None else strip
+        keep, hcore, hdense = split_core(r, c, v, nrows, ncols, 2.0 if use_strip else tau, emax, dense_tau)
+        r0, c0, v0 = r, c, v
+        if keep is not None:
             r, c, v = r[keep], c[keep], v[keep]
+        if use_strip:
+            skeep, hstrip = build_strips(r.to(torch.int64), c.to(torch.int64), v, nrows, ncols, strip_min)
+            if skeep is not None:
+                r, c, v = r[skeep], c[skeep], v[skeep]
+            if STRIP_THEN_CORE and r.numel():
+                # what the strips left behind may still hold 128 x 128 tiles dense enough for the LDS core
+                ckeep, hcore, _ = split_core(r, c, v, nrows, ncols, tau, emax, 2.0)
+                if ckeep is not None and hcore is not None:
+                    r, c, v = r[ckeep], c[ckeep], v[ckeep]
+        tiled = sum(h.nnz for h in (hcore, hdense, hstrip) if h is not None)
+        if tiled and tau is None and strip_min is None and (tiled < CORE_MIN_NNZ or tiled < CORE_MIN_FRAC * r0.numel()):
+            hcore = hdense = hstrip = None     # a small tiled part does not pay for the extra kernel + fix-up launches
+            r, c, v = r0, c0, v0
+        if hcore is not None or hdense is not None or hstrip is not None:
             row_flags = torch.zeros(nrows, dtype=torch.uint8, device=dev)
-            trs = torch.unique(torch.cat([h.tile_row.to(torch.int64) for h in (hcore, hdense) if h is not None]))
-            rows = (trs[:, None] * CORE_TR + torch.arange(CORE_TR, device=dev)[None, :]).reshape(-1)
-            row_flags[rows[rows < nrows]] = 1
+            for h, tr in ((hcore, CORE_TR), (hdense, CORE_TR), (hstrip, STRIP_TR)):
+                if h is None:
+                    continue
+                trs = torch.unique((h.work[:, 0] if h is hstrip else h.tile_row).to(torch.int64))
+                rows = (trs[:, None] * tr + torch.arange(tr, device=dev)[None, :]).reshape(-1)
+                row_flags[rows[rows < nrows]] = 1
     if r.numel():
         r64, c64 = r.to(torch.int64), c.to(torch.int64)
-        key = (r64 * S + c64 % S) * max(ncols, 1) + c64      # (row, slice, col): col order = group order
+        key = (r64 * S + slice_of(c64)) * max(ncols, 1) + c64      # (row, slice, col): col order = group order
         order = torch.argsort(key, stable=True)
         r, c, v = r[order], c[order], v[order]
     row_map = None
@@ -328,7 +500,7 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
         V = S * G
         if r.numel():
             c64 = c.to(torch.int64)
-            vs = (c64 % S) * G + torch.clamp(c64 // gw, max=G - 1)
+            vs = slice_of(c64) * G + torch.clamp(c64 // gw, max=G - 1)
             slice_cnt = torch.bincount(r.to(torch.int64) * V + vs,
                                        minlength=nrows * V).to(torch.int32).reshape(nrows, V)
         else:
@@ -336,17 +508,19 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     else:
         G = 1
     return HostCSR(nrows, ncols, rowptr, c.to(torch.int32).contiguous(),
-                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, G, hcore, row_flags, hdense)
+                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, G, hcore, row_flags, hdense, hstrip)
 
 
 def csr_from_scipy(A, nslices: Optional[int] = None, core: bool = False, tau: float = None,
-                   emax: int = None, ngroups: Optional[int] = None, dense_tau: float = None) -> HostCSR:
+                   emax: int = None, ngroups: Optional[int] = None, dense_tau: float = None,
+                   strip: Optional[bool] = None, strip_min: Optional[int] = None) -> HostCSR:
     """Convenience for tests / tools: a scipy sparse matrix -> HostCSR (optionally sliced)."""
     import numpy as np
     A = A.tocoo()
     return csr_from_coo(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
                         torch.from_numpy(A.data.astype(np.float32)), A.shape[0], A.shape[1],
-                        nslices=nslices, core=core, tau=tau, emax=emax, ngroups=ngroups, dense_tau=dense_tau)
+                        nslices=nslices, core=core, tau=tau, emax=emax, ngroups=ngroups, dense_tau=dense_tau,
+                        strip=strip, strip_min=strip_min)
 
 
 @dataclass

@@ -132,7 +132,7 @@ def test_spmm_dense_core_lds_kernel(K, dev, f, nslices):
     r, c = rank[row], rank[col]
     A = sp.csr_matrix((val.numpy(), (r.numpy(), c.numpy())), shape=(n, n))
     h = partition.csr_from_coo(r, c, val, n, n, nslices=nslices, core=True, tau=0.05, emax=6000,
-                               ngroups=3 if nslices > 1 else None)
+                               ngroups=3 if nslices > 1 else None, strip=False)
     assert h.core is not None and h.core.nnz > 0.2 * A.nnz and h.ngroups == (3 if nslices > 1 else 1)
     d = K.prepare(h)
     assert d.core is not None
@@ -195,7 +195,7 @@ def test_spmm_mfma_dense_tiles(K, dev, f, nslices):
     D *= rng.standard_normal((n, m)).astype(np.float32)
     A = sp.csr_matrix(D)
     h = partition.csr_from_scipy(A, nslices=nslices, core=True, tau=0.05, emax=3000, dense_tau=0.2,
-                                 ngroups=2 if nslices > 1 else None)
+                                 ngroups=2 if nslices > 1 else None, strip=False)
     assert h.dense is not None and h.dense.tile_row.numel() == 5 and h.core is not None
     d = K.prepare(h)
     assert d.dense is not None and d.nslots_total == d.nslots + h.core.nslots + h.dense.nslots
@@ -233,6 +233,91 @@ def test_spmm_mfma_dense_tiles(K, dev, f, nslices):
     assert hit.sum() > 100                                   # column 17 crosses the dense tiles
     assert np.isinf(got[hit, 0]).all() and np.isfinite(got[~hit]).all() and np.isfinite(got[:, 1:]).all()
     assert rel_err(got[:, 1:], ref[:, 1:]) < TOL
+
+
+@pytest.mark.parametrize("f", [4, 30, 64, 128, 132, 256])
+@pytest.mark.parametrize("nslices", [1, 8])
+def test_spmm_strip_tiles(K, dev, f, nslices):
+    """512 x 128 strip tiles through the asynchronously staged LDS pipeline (pgcn_spmm_strip_f32): tiles of
+    one record, tiles cut into several records, several pieces per tile row, the densest 128 x 128 tiles on
+    the matrix cores and a sparse rest in the gather kernel; one fix-up.  Same tolerance as every SpMM path."""
+    partition = pkg("partition")
+    rng = np.random.default_rng(100 + f + nslices)
+    n, m = 1300, 700
+    D = (rng.random((n, m)) < 0.0007).astype(np.float32)            # sparse rest: ~45 entries per strip tile
+    D[:512, :128] = rng.random((512, 128)) < 0.08                    # 5 k entries -> 4 records of one tile
+    D[:512, 128:256] = rng.random((512, 128)) < 0.01                 # one record
+    D[512:1024, 256:640] = rng.random((512, 384)) < 0.03             # three panels of the second tile row
+    D[1024:1152, :128] = rng.random((128, 128)) < 0.5                # MFMA tile inside the third (ragged) tile row
+    D[1152:, 384:512] = rng.random((148, 128)) < 0.2                 # ragged last tile row (rows 1024..1299)
+    D[7, :] = 0                                                      # an empty row inside strip tiles
+    D[:, 300] = 0                                                    # a column nobody references
+    D *= rng.standard_normal((n, m)).astype(np.float32)
+    A = sp.csr_matrix(D)
+    h = partition.csr_from_scipy(A, nslices=nslices, core=True, dense_tau=0.2, strip=True, strip_min=64)
+    assert h.strip is not None and h.core is None and h.dense is not None
+    assert int(h.strip.rec[:, 3].max()) >= 4 and h.strip.rec.shape[0] >= 9      # tiles of several layers
+    assert h.strip.nnz > 0.4 * A.nnz and h.col.numel() > 0
+    assert h.nnz == A.nnz
+    d = K.prepare(h)
+    assert d.strip is not None and d.nslots_total == d.nslots + h.strip.nslots + h.dense.nslots
+    B = rng.random((m, f), dtype=np.float32) * 2 - 1
+    ref = oracle.spmm(A, B)
+    Bd = torch.from_numpy(B).to(dev)
+    C = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, Bd, C)
+    torch.cuda.synchronize()
+    assert rel_err(C.cpu().numpy(), ref) < TOL
+    C2 = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, Bd, C2)
+    assert torch.equal(C, C2)                                        # deterministic
+    base = rng.random((n, f), dtype=np.float32)
+    C3 = torch.from_numpy(base).to(dev)
+    K.spmm(d, Bd, C3, accumulate=True)
+    assert rel_err(C3.cpu().numpy(), ref + base) < TOL
+    # odd leading dimension / unaligned base: the plain (unstaged) strip kernel
+    wide = torch.zeros((m, f + 3), device=dev)
+    wide[:, 1:f + 1] = Bd
+    C4 = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, wide[:, 1:f + 1], C4)
+    assert rel_err(C4.cpu().numpy(), ref) < TOL
+    # Inf in a row of B no entry references must not leak out of a staged panel; Inf in a referenced row
+    # reaches exactly the rows that have an entry in that column
+    B2 = B.copy(); B2[300] = np.inf
+    C5 = torch.empty((n, f), device=dev)
+    K.spmm(d, torch.from_numpy(B2).to(dev), C5)
+    assert np.isfinite(C5.cpu().numpy()).all() and rel_err(C5.cpu().numpy(), ref) < TOL
+    B3 = B.copy(); B3[17, 0] = np.inf
+    C6 = torch.empty((n, f), device=dev)
+    K.spmm(d, torch.from_numpy(B3).to(dev), C6)
+    got = C6.cpu().numpy()
+    hit = np.asarray(A[:, 17].todense()).ravel() != 0
+    assert hit.sum() > 40
+    assert np.isinf(got[hit, 0]).all() and np.isfinite(got[~hit]).all() and np.isfinite(got[:, 1:]).all()
+    assert rel_err(got[:, 1:], ref[:, 1:]) < TOL
+
+
+def test_spmm_strip_pieces_and_panel_reuse(K, dev):
+    """A tile row whose records are cut into several pieces, with consecutive records (layers of one tile)
+    sharing a staged panel inside a piece (flag bit 0) and piece boundaries falling between layers of a tile."""
+    partition = pkg("partition")
+    rng = np.random.default_rng(5)
+    n, m, f = 512, 1024, 128
+    D = (rng.random((n, m)) < 0.06).astype(np.float32) * rng.standard_normal((n, m)).astype(np.float32)
+    A = sp.csr_matrix(D)
+    r, c = torch.from_numpy(A.tocoo().row.astype(np.int64)), torch.from_numpy(A.tocoo().col.astype(np.int64))
+    v = torch.from_numpy(A.tocoo().data.astype(np.float32))
+    keep, st = partition.build_strips(r, c, v, n, m, min_entries=1, pieces=5, layer_min=1)
+    assert st is not None and not bool(keep.any())
+    assert 3 <= st.npieces <= 8 and int(st.rec[:, 1].sum()) > 0       # some records reuse the staged panel
+    first_recs = st.work[:, 1].long()
+    assert bool((st.rec[first_recs, 1] == 0).all())                   # ... but never the first of a piece
+    h = partition.csr_from_scipy(A, nslices=1, core=True, dense_tau=2.0, strip=True, strip_min=1)
+    d = K.prepare(h)
+    B = rng.random((m, f), dtype=np.float32) * 2 - 1
+    C = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, torch.from_numpy(B).to(dev), C)
+    assert rel_err(C.cpu().numpy(), oracle.spmm(A, B)) < TOL
 
 
 def test_spmm_edge_cases(K, dev):
@@ -407,8 +492,8 @@ def test_engine_halo_dense_core(K, dev, P, f, monkeypatch):
     Hfull = rng.random((n, f), dtype=np.float32) * 2 - 1
     Gfull = rng.random((n, f), dtype=np.float32) * 2 - 1
     fwd, bwd, engines = _virtual_ranks_fwd_bwd(K, dev, A, part, P, Hfull, Gfull)
-    assert any(a.core is not None for e, _, _ in engines for a in e.A_halo)
-    assert any(a.core is not None for e, _, _ in engines for a in e.A_halo_T)
+    assert any((a.core or a.strip) is not None for e, _, _ in engines for a in e.A_halo)
+    assert any((a.core or a.strip) is not None for e, _, _ in engines for a in e.A_halo_T)
     assert all(e.rounds == 2 for e, _, _ in engines)
     Ac = sp.csr_matrix(A)
     assert rel_err(fwd, oracle.spmm(Ac, Hfull)) < TOL

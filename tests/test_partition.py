@@ -134,7 +134,7 @@ def test_dense_core_split_roundtrip():
     rank = torch.empty(n, dtype=torch.int64)
     rank[torch.argsort(-deg, stable=True)] = torch.arange(n)
     r, c = rank[row], rank[col]
-    h = partition.csr_from_coo(r, c, val, n, n, nslices=8, core=True, tau=0.05, emax=5000)
+    h = partition.csr_from_coo(r, c, val, n, n, nslices=8, core=True, tau=0.05, emax=5000, strip=False)
     assert h.core is not None and h.core.nnz > 0.2 * r.numel() and h.core.npieces > h.core.tile_row.unique().numel()
     assert h.nnz == r.numel()
     A = sp.csr_matrix((val.numpy(), (r.numpy(), c.numpy())), shape=(n, n))
@@ -191,7 +191,7 @@ def test_mfma_tiles_layout_and_bookkeeping():
     D[640:, 384:] = rng.random((60, 136)) < 0.5             # ragged corner: 60 x 128 (dense) and 60 x 8 (sparse)
     D *= rng.standard_normal((n, m)).astype(np.float32)
     A = sp.coo_matrix(D)
-    h = partition.csr_from_scipy(A, nslices=1, core=True, tau=0.05, emax=3000, dense_tau=0.2)
+    h = partition.csr_from_scipy(A, nslices=1, core=True, tau=0.05, emax=3000, dense_tau=0.2, strip=False)
     assert h.dense is not None and h.core is not None and h.col.numel() > 0
     hd = h.dense
     nt = hd.tile_row.numel()
@@ -217,7 +217,7 @@ def test_mfma_tiles_layout_and_bookkeeping():
     flagged = np.nonzero(h.row_flags.numpy())[0]
     assert set(flagged) == set(range(0, 384)) | set(range(640, 700))
     # switched off: everything dense goes to the LDS core
-    h2 = partition.csr_from_scipy(A, nslices=1, core=True, tau=0.05, emax=3000, dense_tau=2.0)
+    h2 = partition.csr_from_scipy(A, nslices=1, core=True, tau=0.05, emax=3000, dense_tau=2.0, strip=False)
     assert h2.dense is None and h2.core.nnz == hd.nnz + h.core.nnz
 
 
