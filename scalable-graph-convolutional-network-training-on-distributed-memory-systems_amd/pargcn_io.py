@@ -111,3 +111,88 @@ def load_directory(directory: str, config_path: str = None):
     if not (part[A.row] == np.repeat(np.arange(k), [len(r) for r in rows])).all():
         raise ValueError("an A.k file holds rows of another part")
     return {"L": L, "d": d, "A": A, "part": part, "Y": Y, "Ymask": Ymask, "conn": conn, "buff": buff, "k": k}
+
+
+# --------------------------------------------------------------------------------------------
+# Writers: the same files the reference's tools write, so that directories produced
+# here feed the reference's CPU engine and vice versa.
+
+
+def write_partvec(path: str, partvec) -> None:
+    """GPU/hypergraph/main.cpp:51-63 (`print_partvec`), GPU/graph/main.cpp:53-65: ONE line, every part id followed
+    by a space, then a newline.  File name convention: <matrix file name>.<k>.{hp,gp,rp}."""
+    pv = np.asarray(partvec, dtype=np.int64)
+    with open(path, "w") as f:
+        f.write("".join("%d " % p for p in pv.tolist()))
+        f.write("\n")
+
+
+def write_config(path: str, L: int, n: int, f: int, nout: int = 2) -> None:
+    """GCN-HP/main.cpp:117-131 (`print_config`): "L n f .. f nout " (L-1 times f), newline."""
+    with open(path, "w") as fh:
+        fh.write("%d %d " % (L, n) + "%d " % f * (L - 1) + "%d \n" % nout)
+
+
+def _write_triples(path: str, n: int, rows, cols, vals, value_format: str) -> None:
+    with open(path, "w") as fh:
+        fh.write("%d %d\n" % (n, len(rows)))
+        fmt = "%d %d " + value_format + "\n"
+        fh.write("".join(fmt % (int(i), int(j), float(x)) for i, j, x in zip(rows, cols, vals)))
+
+
+def communication_lists(A: sp.spmatrix, partvec, k: int):
+    """GCN-HP/main.cpp:147-176: Hsend[source][target] = ascending ids of the rows i of `source` that hold an entry
+    whose COLUMN belongs to `target` (the reference derives who needs H[i] from row i itself: valid for the
+    symmetric matrices `preprocess` writes); Hrecv[target][source] is the same list seen from the receiver."""
+    A = sp.csr_matrix(A)
+    part = np.asarray(partvec, dtype=np.int64)
+    coo = A.tocoo()
+    src, tgt = part[coo.row], part[coo.col]
+    cut = src != tgt
+    key = np.unique((src[cut] * k + tgt[cut]) * A.shape[0] + coo.row[cut])
+    pair, ids = key // A.shape[0], key % A.shape[0]
+    send = [dict() for _ in range(k)]
+    recv = [dict() for _ in range(k)]
+    for pr in np.unique(pair):
+        s, t = int(pr // k), int(pr % k)
+        lst = ids[pair == pr]
+        send[s][t] = lst
+        recv[t][s] = lst
+    return send, recv
+
+
+def write_directory(directory: str, A: sp.spmatrix, partvec, k: int, L: int, f: int, Y: sp.spmatrix = None,
+                    nout: int = 2, value_format: str = "%.2f") -> None:
+    """Everything GCN-HP's main() leaves in its output directory (GCN-HP/main.cpp:103-110):
+    A.p / Y.p (print_parts, :213-249: header "n nnz_p", then "i j %.2f" for the rows of part p), H.p (print_parts2,
+    :251-282: number of owned rows, then their ids), conn.p / buff.p (print_connectivity, :147-211) and config.
+    ``Y`` defaults to the reference preprocess' label matrix (column 1 set for every vertex,
+    preprocess/GrB-GNN-IDG.py:76-78).  ``value_format="%.2f"`` is what the reference prints (it rounds the
+    normalised values to two decimals); pass "%.9g" for a lossless directory."""
+    os.makedirs(directory, exist_ok=True)
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    n = A.shape[0]
+    part = np.asarray(partvec, dtype=np.int64)
+    if part.shape[0] != n or part.min() < 0 or part.max() >= k:
+        raise ValueError("part vector does not fit the matrix / the number of parts")
+    if Y is None:
+        Y = sp.csr_matrix((np.ones(n, dtype=np.float32), (np.arange(n), np.ones(n, dtype=np.int64))), shape=(n, nout))
+    Y = sp.csr_matrix(Y)
+    Y.sort_indices()
+    write_config(os.path.join(directory, "config"), L, n, f, nout)
+    send, recv = communication_lists(A, part, k)
+    for p in range(k):
+        own = np.nonzero(part == p)[0]
+        for name, M in (("A", A), ("Y", Y)):
+            sub = M[own].tocoo()
+            _write_triples(os.path.join(directory, "%s.%d" % (name, p)), n, own[sub.row], sub.col, sub.data, value_format)
+        with open(os.path.join(directory, "H.%d" % p), "w") as fh:
+            fh.write("%d\n" % own.size + "".join("%d\n" % i for i in own.tolist()))
+        with open(os.path.join(directory, "conn.%d" % p), "w") as fh:
+            fh.write("%d %d\n" % (len(send[p]), len(recv[p])))
+            for t in sorted(send[p]):
+                fh.write("%d %d " % (t, send[p][t].size) + "".join("%d " % i for i in send[p][t].tolist()) + "\n")
+        with open(os.path.join(directory, "buff.%d" % p), "w") as fh:
+            fh.write("%d " % len(send[p]) + "".join("%d %d " % (t, send[p][t].size) for t in sorted(send[p])))
+            fh.write("\n%d " % len(recv[p]) + "".join("%d %d " % (s, recv[p][s].size) for s in sorted(recv[p])))
