@@ -184,6 +184,123 @@ def cpu_baseline(part, f, budget_s=20.0):
     return out
 
 
+class GatKernelTimer:
+    """HIP events around every launch of the dominant GAT kernel (the edge gradient: SDDMM + softmax backward)."""
+
+    def __init__(self, kernels, device):
+        self.k, self.device, self.records, self.on = kernels, device, [], False
+        self._fn = kernels.gat_edge_grad_sliced
+        kernels.gat_edge_grad_sliced = self.call
+
+    def call(self, *a, **kw):
+        if not self.on:
+            return self._fn(*a, **kw)
+        s = torch.cuda.current_stream(self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        out = self._fn(*a, **kw)
+        e1.record(s)
+        if out:
+            self.records.append((e0, e1))
+        return out
+
+    def mean_ms(self):
+        ts = [a.elapsed_time(b) for a, b in self.records]
+        return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
+
+
+def bench_gat(args, rank, world, dev, backend, stage):
+    """BASELINE config 5: Reddit-shaped 3-layer GAT, 4 heads x 64 (the reference's PGAT.py layer on the stored
+    entries: edge softmax + multi-head weighted SpMM + their backward).  One step = one epoch of GPU/PGAT.py:
+    205-221 (forward, loss, backward, gradient all-reduce, Adam)."""
+    synth, partition, engine, kernels = pkg("synth"), pkg("partition"), pkg("engine"), pkg("kernels")
+    G, gat = pkg("PGAT"), pkg("gat")
+    base = args.workload[:-4]
+    n, _, _, _ = synth.SHAPES[base]
+    heads, dh, L = args.heads, args.features or 64, args.layers or 3
+    F = heads * dh
+    t0 = time.time()
+    n, row, col, val = synth.make_graph(base, seed=0, device=dev, generator=args.generator)
+    nnz = int(row.numel())
+    partvec = synth.random_partvec(n, world, seed=0) if world > 1 else torch.zeros(n, dtype=torch.int64)
+    part = partition.build_partition(row, col, val, n, partvec, rank, world, with_transpose=False)
+    del row, col, val
+    K = kernels.HipKernels(dev)
+    exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
+    eng = gat.GatEngine(part, K, dev, exch, mode="standard")
+    G.device, G.myrank, G.world_size, G.heads, G._engine_current = dev, rank, world, heads, eng
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    stage("gat engine ready")
+    torch.manual_seed(0)
+    model = nn.Sequential(*[G.PGAT(eng, F, F, heads=heads) for _ in range(L)]).to(dev)
+    G.initiliaze_parameters(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+    H = torch.rand(part.n_local, F, device=dev, generator=gen).requires_grad_(True)
+    labels = part.owned.to(dev) % F
+
+    def step():
+        logits = model(H)
+        loss = G.local_loss(logits, labels, n)
+        opt.zero_grad()
+        loss.backward()
+        G.sum_gradients(model)
+        opt.step()
+        return loss
+
+    timer = GatKernelTimer(K, dev)
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        pkg("PGCN")._all_reduce(t, dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms = 1e3 * elapsed / args.steps
+    roofline = None
+    avg, launches = timer.mean_ms()
+    if avg:
+        n_r, n_c = part.n_local, part.n_local + part.n_halo
+        alg = (4 + 8 * heads) * eng.nnz + 4 * F * (n_c + n_r)      # col + alpha + de per entry and head; Z and dOut panels
+        ach = alg / (avg * 1e-3)
+        roofline = {"bound": "hbm", "kernel": "gat_edge_grad_heads_kernel (XCD-sliced SDDMM <dOut_i, Z_j> + softmax / "
+                                              "LeakyReLU backward, one pass over the stored entries)",
+                    "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
+                    "alg_bytes_per_launch": alg, "avg_launch_ms": avg, "launches_timed": launches,
+                    "gather_model_GBs": 4.0 * F * eng.nnz / (avg * 1e-3) / 1e9}
+    out = {"metric": "edges aggregated/sec (%s-shaped %d-layer GAT, %d heads x %d, full training epoch)" % (
+               base.capitalize(), L, heads, dh),
+           "value": 2 * L * nnz * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s-like graph n=%d nnz=%d, %d-layer GAT %d heads x %d (edge softmax + multi-head weighted "
+                                  "SpMM, PGAT.py layer on the stored entries), %d GPU(s)" % (base, n, nnz, L, heads, dh, world),
+                      "n": n, "nnz": nnz, "heads": heads, "head_dim": dh, "layers": L, "generator": args.generator,
+                      "multi_head_spmm": bool(eng.multi_head), "vertex_order": part.order_info},
+           "roofline": roofline, "ms_per_epoch": ms, "ms_per_layer_fwd_bwd": ms / L, "loss": float(loss), "setup_s": setup_s,
+           "cpu_baseline": None}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        exch.close()
+        dist.destroy_process_group()
+
+
 def self_launch(nproc):
     import socket
     import subprocess
@@ -209,6 +326,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--heads", type=int, default=4, help="attention heads of the *-gat workloads")
     ap.add_argument("--partvec", default="random",
                     help="random | block | a part-vector file as written by the reference's partitioners "
                          "(GPU/hypergraph/main.cpp:51-63, GPU/graph/main.cpp: one line of n part ids) for N > 1")
@@ -236,7 +354,10 @@ def main():
             sys.exit(self_launch(args.gpus))
         args.gpus = world
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X (no CPU fallback in the product path) [rank %d of %d]" % (rank, world))
+        print("bench.py needs an MI355X (no CPU fallback in the product path) [rank %d of %d]" % (rank, world),
+              file=sys.stderr, flush=True)
+        time.sleep(3.0 if world > 1 else 0.0)     # let every rank say so before the launcher tears the job down
+        sys.exit(1)
     dev = torch.device("cuda:%d" % (local_rank % torch.cuda.device_count()))   # (gloo dry-run: ranks share cuda:0)
     torch.cuda.set_device(dev)
     backend = os.environ.get("PGCN_BENCH_BACKEND", "nccl")   # "gloo": dry-run of the N>1 path on one GPU
@@ -247,6 +368,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.workload.endswith("-gat"):
+        return bench_gat(args, rank, world, dev, backend, stage)
     synth, partition, engine, kernels, P = pkg("synth"), pkg("partition"), pkg("engine"), pkg("kernels"), pkg("PGCN")
     n, nnz_dir, f, L = synth.SHAPES[args.workload]
     f = args.features or f
@@ -399,8 +522,9 @@ def main():
         "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s-like " + ("R-MAT" if args.generator == "rmat" else "planted-partition (SBM)") + " n=%d nnz=%d (incl. self loops), %d-layer GCN f=%d, "
-                               "1D partition (%s) over %d GPU(s), 1 step = 1 epoch (fwd+loss+bwd+allreduce+Adam)"
+        "config": {"workload": ("%s-like " + ("R-MAT" if args.generator == "rmat" else "planted-partition (SBM)")
+                                + " n=%d nnz=%d (incl. self loops), %d-layer GCN f=%d, "
+                                "1D partition (%s) over %d GPU(s), 1 step = 1 epoch (fwd+loss+bwd+allreduce+Adam)")
                                % (args.workload, n, nnz, L, f, partition_name, world),
                    "n": n, "nnz": nnz, "f": f, "layers": L, "spmm_per_epoch": 2 * L,
                    "partition": partition_name, "generator": args.generator,
@@ -408,7 +532,9 @@ def main():
                    "xcd_slices": eng.A_loc.nslices, "chunk": K.chunk,
                    "core_tile_fill_min": partition.CORE_TAU,
                    "mfma_tile_fill_min": partition.DENSE_TAU if partition.DENSE_ON else None,
-                   "exchange_rounds": part.rounds},
+                   "exchange_rounds": part.rounds, "vertex_order": part.order_info,
+                   "strip_tiles": {"min_entries": partition.STRIP_MIN, "layer_min": partition.STRIP_LAYER_MIN}
+                   if partition.STRIP_ON else None},
         "roofline": roofline, "ms_per_epoch": ms_per_step, "loss": loss_val, "setup_s": setup_s,
     }
     if world > 1:

@@ -88,6 +88,21 @@ int pgcn_load_mtx_partition(const char *path, const int32_t *partvec, int64_t n,
                             int64_t cap, int64_t *row, int64_t *col, float *val, int64_t *nnz_out,
                             int32_t nthreads);
 
+/* ---- binary CSR shards (host only; "next" row N1, papers100M-scale ingest) ---------------------
+ * One file per rank with ONLY that rank's rows, in the layout the engine consumes: replaces the text parse
+ * of the whole matrix on every rank (GPU/PGCN.py:171 mmread, :37-64) and lifts the 32-bit pin arrays of the
+ * reference's partitioner front-end (GCN-HP/main.cpp:286-307).  Little endian:
+ *   8 x int64 {magic "PGCSR001", n_global, nrows, nnz, rank, nparts, flags = 0, 0}
+ *   int64 rows[nrows] (global ids, ascending) | int64 rowptr[nrows + 1] | int32 col[nnz] (global ids,
+ *   padded to 8 bytes) | fp32 val[nnz].
+ * pgcn_shard_info: out = {n_global, nrows, nnz, rank, nparts, flags}.  pgcn_shard_read fills caller arrays
+ * (capacities in elements) and validates the structure.                                                  */
+int pgcn_shard_write(const char *path, int64_t n_global, int32_t rank, int32_t nparts, int64_t nrows,
+                     const int64_t *rows, const int64_t *rowptr, const int32_t *col, const float *val);
+int pgcn_shard_info(const char *path, int64_t out[6]);
+int pgcn_shard_read(const char *path, int64_t cap_rows, int64_t cap_nnz, int64_t *rows, int64_t *rowptr,
+                    int32_t *col, float *val);
+
 /* ---- CSR SpMM ------------------------------------------------------------
  * C[nrows x f] (+)= A[nrows x *] . B[* x f]
  * replaces  torch.sparse.mm(A, H)            GPU/PGCN.py:127
@@ -154,6 +169,20 @@ int pgcn_spmm_core_f32(const int32_t *work, int64_t nwork, const int32_t *tile_p
                        const float *cval, const float *B, int64_t ldb, int64_t ncols, int32_t f,
                        float *partial_ws, int64_t partial_ws_elems, int64_t nslots_total,
                        pgcn_stream_t stream);
+
+/* ---- multi-head weighted SpMM (GAT, "next" row N3) --------------------------------------------
+ *   C[i, k*d .. (k+1)*d) (+)= sum over the stored entries e of row i:  alpha[k * plane_stride + e] * B[col[e], k*d ..]
+ * for all `heads` heads in ONE launch: replaces `attention @ Z` of GPU/PGAT.py:148 on the stored entries
+ * (the reference multiplies a dense n x n attention matrix).  alpha: head-major planes in the storage
+ * order of `col`.  tasks / seg / nslices / fix / nslots: the plan of pgcn_spmm_plan_host on the same
+ * structure (tasks == NULL: one task per row, nrows rows).  One wave gathers a whole heads * d wide row.
+ * Supported: heads <= 8, heads * d <= 256, d % 4 == 0, ldb % 4 == 0, ldc % 4 == 0, 16-byte aligned
+ * B / C / work-space; otherwise PGCN_EUNSUPPORTED (run one pgcn_spmm_csr_plan_f32 per head instead). */
+int pgcn_spmm_heads_f32(const int64_t *rowptr, const int32_t *col, const float *alpha, int64_t plane_stride,
+                        int32_t heads, int32_t d, int64_t nrows, const int32_t *tasks, int64_t ntasks,
+                        const int64_t *seg, int32_t nslices, const int32_t *fix, int64_t nfix,
+                        const float *B, int64_t ldb, float *C, int64_t ldc, float *partial_ws,
+                        int64_t partial_ws_elems, int64_t nslots, uint32_t flags, pgcn_stream_t stream);
 
 /* ---- strip tiles: 512 x 128, LDS-staged, asynchronous double-buffered pipeline -------------
  * Same product (torch.sparse.mm, GPU/PGCN.py:127,132) for the entries of TALL tiles: a 1024-thread

@@ -187,9 +187,12 @@ class PGAT(nn.Module):
         Zh = Z.view(Z.shape[0], K, d)
         s1 = torch.einsum("nkd,dk->nk", Zh, self.attention[:d])        # z1, :141
         s2 = torch.einsum("nkd,dk->nk", Zh, self.attention[d:])        # z2, :142
-        if self._state is None:
-            self._state = self.A.new_layer_state(K, d)
-        return _gat.GatAggregate.apply(self.A, self._state, Z, s1, s2)  # :144-149 on the stored entries
+        # the buffers that live from forward to backward belong to ONE forward: a second forward of this layer
+        # before the first one's backward (evaluation pass in between, shared weights, two graphs) gets its own
+        st = self._state
+        if st is None or st.busy or (st.heads, st.d) != (K, d):
+            st = self._state = self.A.new_layer_state(K, d)
+        return _gat.GatAggregate.apply(self.A, st, Z, s1, s2)           # :144-149 on the stored entries
 
 
 _all_reduce = _pgcn._all_reduce

@@ -310,12 +310,25 @@ def run(rank, size, nlayers, nfeatures, path_A, path_partvec, backend):
         raise _kernels._lib.PgcnError("no HIP device visible: refusing to run (no CPU fallback); "
                                       "backend=%s only selects the transport" % backend)
 
-    with open(path_partvec) as f:
-        partvec = list(map(int, f.readline().split()))
+    partvec = _partition.read_partvec(path_partvec)       # first line: n part ids (PGCN.py:172-173); .gz accepted
     _partition_cache.clear()
-    if os.environ.get("PGCN_INGEST", "global") == "rows" and size > 1:
+    if _ingest.is_shard_prefix(path_A, rank):
+        # binary CSR shards written ahead of time (ingest.write_shards / tools/mtx_to_shards.py): this rank reads
+        # ONLY its own rows -- no text, no global matrix anywhere (papers100M-scale path)
+        sh = _ingest.read_shard(_ingest.shard_path(path_A, rank))
+        if sh["nparts"] != size or sh["rank"] != rank or sh["n"] != len(partvec):
+            raise ValueError("shard %s was written for rank %d of %d, n = %d" % (path_A, sh["rank"], sh["nparts"], sh["n"]))
+        r_, c_, v_ = _ingest.shard_coo(sh)
+        import scipy.sparse as _sp
+        A = _sp.coo_matrix((v_, (r_, c_)), shape=(sh["n"], sh["n"]))
+        row, col, val = _coo_tensors(A)
+        build = _partition.build_partition_local if size > 1 else _partition.build_partition
+        _seed_partition_cache(A, partvec, rank, size, build(row, col, val, A.shape[0],
+                                                            torch.as_tensor(partvec, dtype=torch.int64), rank, size))
+    elif os.environ.get("PGCN_INGEST", "rows") == "rows" and size > 1:
         # every rank keeps ONLY its rows (pgcn_load_mtx_partition) and the partition is completed by two
-        # small collectives instead of a scan of the whole matrix on every rank (PGCN.py:37-64)
+        # small collectives instead of a scan of the whole matrix on every rank (PGCN.py:37-64).  Default since
+        # r02; PGCN_INGEST=global restores the reference's behaviour (every rank parses everything)
         A = _ingest.load_partition(path_A, partvec, rank)
         row, col, val = _coo_tensors(A)
         _seed_partition_cache(A, partvec, rank, size, _partition.build_partition_local(

@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpgcn_hip.so")
 
 PGCN_OK = 0
+PGCN_EUNSUPPORTED = -5
 SPMM_ACCUMULATE = 1
 SPMM_XCD_SWIZZLE = 2
 SPMM_OFFSETS32 = 4
@@ -40,12 +41,17 @@ SIGNATURES = {
     "pgcn_build_comm_maps": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i32]),
     "pgcn_load_mtx_partition": (ctypes.c_int, [ctypes.c_char_p, _vp, _i64, _i32, _i64, _vp, _vp, _vp,
                                                ctypes.POINTER(_i64), _i32]),
+    "pgcn_shard_write": (ctypes.c_int, [ctypes.c_char_p, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "pgcn_shard_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64)]),
+    "pgcn_shard_read": (ctypes.c_int, [ctypes.c_char_p, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pgcn_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _u32, _vp]),
     "pgcn_spmm_csr_plan_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp,
                                               _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),
     "pgcn_spmm_core_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp,
                                           _i64, _i64, _vp]),
     "pgcn_spmm_strip_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
+    "pgcn_spmm_heads_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64,
+                                           _vp, _i64, _vp, _i64, _i64, _u32, _vp]),
     "pgcn_spmm_dense_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
     "pgcn_spmm_fused_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                            _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),

@@ -109,6 +109,7 @@ class GatLayerState:
     s2c: Optional[torch.Tensor] = None   # [(n_local + n_halo), heads] s2 of local and halo rows, compact (L2 resident)
     s1: Optional[torch.Tensor] = None
     out: Optional[torch.Tensor] = None
+    busy: bool = False                   # a forward whose backward has not run yet owns these buffers
 
 
 class GatEngine(BoundaryExchange):
@@ -129,6 +130,8 @@ class GatEngine(BoundaryExchange):
         self.perm = g.perm.to(self.device)
         self._scratch = {}
         self.sliced_grad = os.environ.get("PGCN_GAT_SLICED", "1") != "0"   # XCD-sliced edge gradient where the shape allows
+        # all heads of `attention @ Z` (and of its transpose) in one launch (pgcn_spmm_heads_f32)
+        self.multi_head = os.environ.get("PGCN_GAT_MULTIHEAD", "1") != "0" and hasattr(kernels, "spmm_heads")
 
     # -- buffers ---------------------------------------------------------
     def _plane_scratch(self, name: str, heads: int) -> torch.Tensor:
@@ -179,8 +182,9 @@ class GatEngine(BoundaryExchange):
         self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,
                                 st.alpha, st.beta, st.rowstat)
         out = torch.empty((n_p, F), dtype=torch.float32, device=self.device)
-        for k in range(K):
-            self.k.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], out[:, k * d:(k + 1) * d])
+        if not (self.multi_head and self.k.spmm_heads(self.fwd, st.alpha, Zc, out, K, d)):
+            for k in range(K):            # shapes the one-launch kernel does not cover: one SpMM per head
+                self.k.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], out[:, k * d:(k + 1) * d])
         if self.mode_id == 1:                               # + beta_i * (sum over ALL vertices of Z_j)
             zsum = self._allreduce(Z.sum(0))
             out.view(n_p, K, d).addcmul_(st.beta.view(n_p, K, 1), zsum.view(1, K, d))
@@ -212,8 +216,9 @@ class GatEngine(BoundaryExchange):
             bwd_heads = [self.k.with_values(self.bwd, alpha_t[k]) for k in range(K)]
             self._scratch[("bwd_heads", K)] = bwd_heads
         dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
-        for k in range(K):
-            self.k.spmm(bwd_heads[k], dOut[:, k * d:(k + 1) * d], dZc[:, k * d:(k + 1) * d])
+        if not (self.multi_head and self.k.spmm_heads(self.bwd, alpha_t, dOut, dZc, K, d)):
+            for k in range(K):
+                self.k.spmm(bwd_heads[k], dOut[:, k * d:(k + 1) * d], dZc[:, k * d:(k + 1) * d])
         self.k.csr_row_sums(self.bwd, self.perm, de, K, dZc[:, F:F + K])
         if Fp > F + K:
             dZc[:, F + K:].zero_()
@@ -236,10 +241,15 @@ class GatAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine: GatEngine, state: GatLayerState, Z, s1, s2):
+        if state.busy:
+            raise RuntimeError("GAT layer state is still owned by a forward whose backward has not run; "
+                               "use a fresh state (GatEngine.new_layer_state) for a second forward")
         ctx.engine, ctx.state = engine, state
+        state.busy = any(ctx.needs_input_grad)
         return engine.forward(state, Z.contiguous(), s1, s2)
 
     @staticmethod
     def backward(ctx, grad_output):
         dZ, ds1, ds2 = ctx.engine.backward(ctx.state, grad_output)
+        ctx.state.busy = False
         return None, None, dZ, ds1, ds2

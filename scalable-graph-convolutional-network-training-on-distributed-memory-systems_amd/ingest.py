@@ -85,3 +85,73 @@ def load_partition(path: str, partvec, rank: int, nthreads: int = 0) -> sp.coo_m
     _lib.check(L.pgcn_load_mtx_partition(*a, k, row.ctypes.data, col.ctypes.data, val.ctypes.data, ctypes.byref(n),
                                          nthreads), "pgcn_load_mtx_partition")
     return sp.coo_matrix((val[:k], (row[:k], col[:k])), shape=(info["nrows"], info["ncols"]))
+
+
+# --------------------------------------------------------------------------------------------
+# Binary CSR shards (pgcn_shard_*): one file per rank with only that rank's rows.
+
+SHARD_SUFFIX = ".pgcsr"
+
+
+def shard_path(prefix: str, rank: int) -> str:
+    return "%s.%d%s" % (prefix, rank, SHARD_SUFFIX)
+
+
+def is_shard_prefix(path: str, rank: int = 0) -> bool:
+    return os.path.exists(shard_path(path, rank))
+
+
+def write_shard(path: str, n_global: int, rank: int, nparts: int, rows, rowptr, col, val) -> None:
+    """One rank's row block: ``rows`` ascending global ids, CSR over them with GLOBAL int32 column ids."""
+    L = _lib.lib()
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float32)
+    if rowptr.shape[0] != rows.shape[0] + 1 or col.shape[0] != val.shape[0] or (rowptr.size and rowptr[-1] != col.shape[0]):
+        raise ValueError("inconsistent CSR arrays")
+    _lib.check(L.pgcn_shard_write(os.fsencode(path), n_global, rank, nparts, rows.shape[0], rows.ctypes.data,
+                                  rowptr.ctypes.data, col.ctypes.data, val.ctypes.data), "pgcn_shard_write")
+
+
+def shard_info(path: str) -> dict:
+    L = _lib.lib()
+    out = (ctypes.c_int64 * 6)()
+    _lib.check(L.pgcn_shard_info(os.fsencode(path), out), "pgcn_shard_info")
+    return {"n": out[0], "nrows": out[1], "nnz": out[2], "rank": out[3], "nparts": out[4], "flags": out[5]}
+
+
+def read_shard(path: str) -> dict:
+    """{n, rank, nparts, rows int64, rowptr int64, col int32, val fp32} of one shard."""
+    L = _lib.lib()
+    info = shard_info(path)
+    rows = np.empty(max(info["nrows"], 1), dtype=np.int64)
+    rowptr = np.empty(info["nrows"] + 1, dtype=np.int64)
+    col = np.empty(max(info["nnz"], 1), dtype=np.int32)
+    val = np.empty(max(info["nnz"], 1), dtype=np.float32)
+    _lib.check(L.pgcn_shard_read(os.fsencode(path), info["nrows"], info["nnz"], rows.ctypes.data, rowptr.ctypes.data,
+                                 col.ctypes.data, val.ctypes.data), "pgcn_shard_read")
+    info.update(rows=rows[:info["nrows"]], rowptr=rowptr, col=col[:info["nnz"]], val=val[:info["nnz"]])
+    return info
+
+
+def shard_coo(shard: dict):
+    """(row, col, val) of a shard in GLOBAL coordinates (int64 rows and columns) -- what
+    partition.build_partition_local takes."""
+    counts = np.diff(shard["rowptr"])
+    return np.repeat(shard["rows"], counts), shard["col"].astype(np.int64), shard["val"]
+
+
+def write_shards(prefix: str, A, partvec, nparts: int) -> list:
+    """Split a (scipy) matrix into ``nparts`` shards by the part vector; returns the paths."""
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    part = np.asarray(partvec, dtype=np.int64)
+    paths = []
+    for p in range(nparts):
+        own = np.nonzero(part == p)[0]
+        sub = A[own]
+        path = shard_path(prefix, p)
+        write_shard(path, A.shape[0], p, nparts, own, sub.indptr, sub.indices, sub.data)
+        paths.append(path)
+    return paths

@@ -470,6 +470,34 @@ class HipKernels:
             raise _lib.PgcnError("%s must be an fp32 CUDA matrix with >= %d rows and %d unit-stride columns"
                                  % (what, rows, cols))
 
+    def spmm_heads(self, A: DeviceCSR, alpha: torch.Tensor, B: torch.Tensor, C: torch.Tensor, heads: int, d: int,
+                   accumulate: bool = False) -> bool:
+        """C[:, k*d:(k+1)*d] (+)= A_{alpha_k} . B[:, k*d:(k+1)*d] for all heads in one launch
+        (pgcn_spmm_heads_f32).  Returns False when the shape is not covered (the caller then runs one SpMM
+        per head)."""
+        F = heads * d
+        nnz = A.col.numel()
+        if not (alpha.is_cuda and alpha.dtype is torch.float32 and alpha.dim() == 2 and alpha.shape[0] == heads
+                and alpha.stride(1) == 1 and (nnz == 0 or alpha.shape[1] >= nnz)):
+            raise _lib.PgcnError("alpha must be [heads, nnz] fp32 CUDA planes")
+        self._check_dense(B, A.ncols, "B")
+        self._check_dense(C, A.nrows, "C")
+        if B.shape[1] < F or C.shape[1] < F or A.row_map is not None:
+            raise _lib.PgcnError("B / C narrower than heads * d, or a compact-row structure")
+        need = A.nslots * F
+        if need and (A.ws is None or A.ws.numel() < need):
+            A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            A.launch_cache.clear()
+        flags = _lib.SPMM_ACCUMULATE if accumulate else 0
+        rc = self.lib.pgcn_spmm_heads_f32(
+            A.rowptr.data_ptr(), A.col.data_ptr(), alpha.data_ptr(), alpha.stride(0), heads, d, A.nrows, _ptr(A.tasks),
+            A.ntasks, A.seg, A.nslices, _ptr(A.fix), A.nfix, B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0),
+            _ptr(A.ws), 0 if A.ws is None else A.ws.numel(), A.nslots, flags, self._stream())
+        if rc == _lib.PGCN_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "pgcn_spmm_heads_f32")
+        return True
+
     def gat_edge_softmax(self, A: DeviceCSR, s1, s2, heads: int, slope: float, mode: int, n_global: int,
                          alpha: torch.Tensor, beta: torch.Tensor, rowstat: Optional[torch.Tensor] = None) -> None:
         self._check_rows(s1, A.nrows, heads, "s1")

@@ -748,6 +748,9 @@ ORDER_LPA_ITERS = int(os.environ.get("PGCN_ORDER_ITERS", "8"))
 ORDER_MIN_INSIDE = float(os.environ.get("PGCN_ORDER_MIN_INSIDE", "0.25"))   # share of entries inside communities
 ORDER_MAX_SHARE = float(os.environ.get("PGCN_ORDER_MAX_SHARE", "0.125"))    # largest community / n
 ORDER_MIN_N = int(os.environ.get("PGCN_ORDER_MIN_N", "4096"))
+ORDER_HUBS = float(os.environ.get("PGCN_ORDER_HUBS", "0.0"))    # share of vertices numbered first as hubs; measured on the
+                                                                 # SBM stand-in (r02): 0 is best, pulling hubs out of their
+                                                                 # communities costs more intra-community density than it buys
 
 
 def label_propagation(row: torch.Tensor, col: torch.Tensor, n: int, iters: int = None, seed: int = 12345) -> torch.Tensor:
@@ -791,11 +794,20 @@ def vertex_order(row: torch.Tensor, col: torch.Tensor, n: int, gdeg: Optional[to
     info.update(communities=int(ul.numel()), inside=inside, largest_share=share)
     if mode == "auto" and not (inside >= ORDER_MIN_INSIDE and share <= ORDER_MAX_SHARE):
         return _degree_order(gdeg, n, dev) + (info,)
-    # communities by decreasing total degree, vertices of a community by decreasing degree
+    # hubs first (the top ORDER_HUBS share by degree, from all communities: the entries that leave a community
+    # mostly point at them, so they become a few dense column panels every tile row shares), then communities by
+    # decreasing total degree, vertices of a community by decreasing degree
     cdeg = torch.zeros(ul.numel(), dtype=torch.int64, device=dev).index_add_(0, linv, gdeg)
     crank = torch.empty_like(cdeg)
     crank[torch.argsort(-cdeg, stable=True)] = torch.arange(ul.numel(), dtype=torch.int64, device=dev)
-    gorder = torch.argsort(crank[linv] * (int(gdeg.max()) + 1) + (int(gdeg.max()) - gdeg), stable=True)
+    dmax = int(gdeg.max())
+    key = (crank[linv] + 1) * (dmax + 1) + (dmax - gdeg)
+    nh = int(ORDER_HUBS * n)
+    if nh > 0:
+        hubs = torch.argsort(-gdeg, stable=True)[:nh]
+        key[hubs] = dmax - gdeg[hubs]                       # "community 0": all hubs, by degree
+    info["hubs"] = nh
+    gorder = torch.argsort(key, stable=True)
     grank = torch.empty(n, dtype=torch.int64, device=dev)
     grank[gorder] = torch.arange(n, dtype=torch.int64, device=dev)
     info["order"] = "community"
@@ -874,5 +886,9 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
 
 def read_partvec(path: str) -> List[int]:
     """``-p`` file: FIRST line = n space separated part ids (PGCN.py:172-173)."""
+    if path.endswith(".gz"):            # committed fixtures are compressed; the reference reads plain text
+        import gzip
+        with gzip.open(path, "rt") as f:
+            return list(map(int, f.readline().split()))
     with open(path) as f:
         return list(map(int, f.readline().split()))

@@ -5,6 +5,7 @@ PSpMM forward/backward structure, accumulate-on-receive, statistics, run().  The
 kernels are replaced by the checker-backed provider in tests/oracle_kernels.py (the only
 way to execute on a box without a GPU; the real kernels are covered by -m gpu tests).
 Outputs are compared with golden vectors produced by the reference's own PGCN.py."""
+import os
 import re
 
 import numpy as np
@@ -14,7 +15,7 @@ import torch.multiprocessing as mp
 from scipy.io import mmread
 
 import _workers
-from conftest import SPMM_CASES, TRAIN_CASES, golden, golden_inputs, gpath, read_partvec, rel_err
+from conftest import SPMM_CASES, TRAIN_CASES, golden, golden_inputs, gpath, pkg, read_partvec, rel_err
 from oracle import oracle
 
 TOL = 1e-5
@@ -151,12 +152,31 @@ def test_run_with_row_block_ingest_is_identical(monkeypatch):
     """PGCN_INGEST=rows: run() where no rank parses more than its own rows into memory -- same printed
     losses, same statistics, bit-identical weights as the default (global) ingest."""
     mtx, pv, P, L, f = "gemat11p.A.mtx", "gemat11.mtx.3.hp", 3, 2, 8
+    monkeypatch.setenv("PGCN_INGEST", "global")           # the reference's way: every rank parses the whole matrix
     base = _spawn(_workers.run_worker, P, gpath(mtx), gpath(pv), L, f, 7)
-    monkeypatch.setenv("PGCN_INGEST", "rows")
+    monkeypatch.setenv("PGCN_INGEST", "rows")             # (the default since r02)
     rows = _spawn(_workers.run_worker, P, gpath(mtx), gpath(pv), L, f, 7)
     assert rows[0]["stdout"].split("Elapsed")[0] == base[0]["stdout"].split("Elapsed")[0]      # env echo, losses, stats
     vol = re.findall(r"total_vol: \d+ total_nmsg: \d+", rows[0]["stdout"])
     assert len(vol) == 1 and vol == re.findall(r"total_vol: \d+ total_nmsg: \d+", base[0]["stdout"])
     for a, b in zip(rows, base):
+        for wa, wb in zip(a["weights"], b["weights"]):
+            np.testing.assert_array_equal(wa, wb)
+
+
+def test_run_from_binary_csr_shards_is_identical(tmp_path, monkeypatch):
+    """`-a PREFIX` with PREFIX.<rank>.pgcsr shards (pgcn_shard_*): every rank reads only its own binary row block;
+    same printed losses / statistics / weights as the MatrixMarket run."""
+    from scipy.io import mmread
+    ingest = pkg("ingest")
+    mtx, pv, P, L, f = "gemat11p.A.mtx", "gemat11.mtx.3.hp", 3, 2, 8
+    monkeypatch.setenv("PGCN_INGEST", "global")
+    base = _spawn(_workers.run_worker, P, gpath(mtx), gpath(pv), L, f, 7)
+    prefix = str(tmp_path / "gemat11p")
+    paths = ingest.write_shards(prefix, mmread(gpath(mtx)), read_partvec(gpath(pv)), P)
+    assert [os.path.basename(x) for x in paths] == ["gemat11p.%d.pgcsr" % r for r in range(P)]
+    sh = _spawn(_workers.run_worker, P, prefix, gpath(pv), L, f, 7)
+    assert sh[0]["stdout"].split("Elapsed")[0] == base[0]["stdout"].split("Elapsed")[0]
+    for a, b in zip(sh, base):
         for wa, wb in zip(a["weights"], b["weights"]):
             np.testing.assert_array_equal(wa, wb)

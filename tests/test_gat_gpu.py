@@ -310,3 +310,74 @@ def test_pgat_cli_spawns_all_ranks(dev):
     losses = _losses(out.stdout)
     assert len(losses) == 50 and all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert out.stdout.count("Elapsed time") == 1
+
+
+@pytest.mark.parametrize("heads,d", [(4, 64), (2, 32), (1, 128), (8, 32), (3, 20), (1, 4)])
+@pytest.mark.parametrize("nslices,chunk", [(1, 1024), (8, 1024), (8, 64)])
+def test_multi_head_spmm_one_launch(K, dev, heads, d, nslices, chunk):
+    """pgcn_spmm_heads_f32: all heads of `attention @ Z` (PGAT.py:148 on the stored entries) in one launch ==
+    one SpMM per head (bit for bit the same fmaf chains per row piece) == the float64 shadow; long rows split
+    into slots, XCD-sliced structures, accumulate, panels wider than heads * d."""
+    n, m = 500, 420
+    A, rng = _graph(n, m, 7 * heads + d)
+    A.sort_indices()
+    old, K.chunk = K.chunk, chunk
+    try:
+        dA, dT, perm, er, ec = _structure(K, A, nslices, 1 << 30)
+    finally:
+        K.chunk = old
+    nnz, F = A.nnz, heads * d
+    ld = F + heads + (4 - (F + heads) % 4) % 4
+    alpha = torch.from_numpy(rng.random((heads, nnz), dtype=np.float32)).to(dev)
+    Zd = torch.from_numpy((rng.standard_normal((m, ld))).astype(np.float32)).to(dev)
+    out = torch.full((n, F), float("nan"), device=dev)
+    assert K.spmm_heads(dA, alpha, Zd, out, heads, d)
+    ref = torch.full((n, F), float("nan"), device=dev)
+    for k in range(heads):
+        K.spmm(K.with_values(dA, alpha[k]), Zd[:, k * d:(k + 1) * d], ref[:, k * d:(k + 1) * d])
+    torch.cuda.synchronize()
+    assert float((out - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    a = alpha.cpu().numpy()
+    Z = Zd.cpu().numpy().astype(np.float64)
+    exp = np.zeros((n, F))
+    for k in range(heads):
+        Ak = sp.csr_matrix((a[k].astype(np.float64), (er, ec)), shape=A.shape)
+        exp[:, k * d:(k + 1) * d] = Ak @ Z[:, k * d:(k + 1) * d]
+    assert rel_err(out.cpu().numpy(), exp) < TOL
+    out2 = torch.full((n, F), float("nan"), device=dev)
+    K.spmm_heads(dA, alpha, Zd, out2, heads, d)
+    assert torch.equal(out, out2)                                   # deterministic
+    base = torch.from_numpy(rng.random((n, F), dtype=np.float32)).to(dev)
+    acc = base.clone()
+    K.spmm_heads(dA, alpha, Zd, acc, heads, d, accumulate=True)
+    assert rel_err(acc.cpu().numpy(), exp + base.cpu().numpy()) < TOL
+    # the transposed structure with its own planes (the backward pass of the layer)
+    at = alpha[:, perm].contiguous()
+    G = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(dev)
+    dZ = torch.full((m, ld), float("nan"), device=dev)
+    assert K.spmm_heads(dT, at, G, dZ, heads, d)
+    expT = np.zeros((m, F))
+    Gn = G.cpu().numpy().astype(np.float64)
+    for k in range(heads):
+        Ak = sp.csr_matrix((a[k].astype(np.float64), (er, ec)), shape=A.shape)
+        expT[:, k * d:(k + 1) * d] = Ak.T @ Gn[:, k * d:(k + 1) * d]
+    assert rel_err(dZ[:, :F].cpu().numpy(), expT) < TOL
+    # Inf in a row of B nobody references must not leak
+    free = np.setdiff1d(np.arange(m), A.indices)
+    if free.size:
+        Z2 = Zd.clone(); Z2[int(free[0])] = float("inf")
+        o3 = torch.empty((n, F), device=dev)
+        K.spmm_heads(dA, alpha, Z2, o3, heads, d)
+        assert torch.isfinite(o3).all()
+
+
+def test_multi_head_spmm_unsupported_shapes_fall_back(K, dev):
+    A, rng = _graph(100, 90, 3, hub=False)
+    A.sort_indices()
+    dA, _, _, _, _ = _structure(K, A, 1, 1 << 30)
+    alpha = torch.rand((5, A.nnz), device=dev)
+    Z = torch.rand((90, 5 * 64), device=dev)
+    out = torch.empty((100, 5 * 64), device=dev)
+    assert K.spmm_heads(dA, alpha, Z, out, 5, 64) is False          # 320 features: one SpMM per head instead
+    alpha = torch.rand((2, A.nnz), device=dev)
+    assert K.spmm_heads(dA, alpha, torch.rand((90, 12), device=dev), torch.empty((100, 12), device=dev), 2, 6) is False

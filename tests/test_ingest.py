@@ -157,3 +157,59 @@ def test_native_partition_loader(name, mtx, pv, P):
         assert got.nnz == meta["ranks"][r]["nnz_local"]
     with pytest.raises(_lib.PgcnError):
         ingest.load_partition(gpath(mtx), part[:-1], 0)                   # part vector length mismatch
+
+
+def test_binary_csr_shards_round_trip(tmp_path):
+    """pgcn_shard_write / _info / _read: one file per rank with only its rows, int64 row pointers, validated."""
+    import scipy.sparse as sp
+    ingest, _lib = pkg("ingest"), pkg("_lib")
+    rng = np.random.default_rng(0)
+    A = sp.random(300, 300, 0.05, random_state=2, dtype=np.float32, format="csr")
+    A.sort_indices()
+    part = rng.integers(0, 4, 300)
+    paths = ingest.write_shards(str(tmp_path / "g"), A, part, 4)
+    tot = 0
+    for p, path in enumerate(paths):
+        info = ingest.shard_info(path)
+        own = np.nonzero(part == p)[0]
+        assert (info["n"], info["rank"], info["nparts"], info["nrows"]) == (300, p, 4, own.size)
+        sh = ingest.read_shard(path)
+        assert np.array_equal(sh["rows"], own) and sh["rowptr"].dtype == np.int64 and sh["col"].dtype == np.int32
+        r, c, v = ingest.shard_coo(sh)
+        B = sp.csr_matrix((v, (r, c)), shape=A.shape)
+        assert (abs(B - sp.csr_matrix(A.multiply((part == p)[:, None]))) > 0).nnz == 0
+        tot += info["nnz"]
+        assert os.path.getsize(path) == 64 + 8 * own.size + 8 * (own.size + 1) + 4 * (info["nnz"] + info["nnz"] % 2) + 4 * info["nnz"]
+    assert tot == A.nnz
+    # an empty part, bad inputs, a truncated file
+    ingest.write_shard(str(tmp_path / "e.0.pgcsr"), 10, 0, 1, [], [0], [], [])
+    assert ingest.read_shard(str(tmp_path / "e.0.pgcsr"))["nnz"] == 0
+    with pytest.raises(_lib.PgcnError):
+        ingest.write_shard(str(tmp_path / "bad.pgcsr"), 10, 0, 1, [3, 2], [0, 1, 2], [1, 1], [1.0, 1.0])     # rows not ascending
+    with pytest.raises(_lib.PgcnError):
+        ingest.write_shard(str(tmp_path / "bad.pgcsr"), 10, 2, 2, [1], [0, 0], [], [])                        # rank >= nparts
+    data = open(paths[0], "rb").read()
+    open(tmp_path / "cut.pgcsr", "wb").write(data[:len(data) // 2])
+    with pytest.raises(_lib.PgcnError):
+        ingest.read_shard(str(tmp_path / "cut.pgcsr"))
+    open(tmp_path / "junk.pgcsr", "wb").write(b"x" * 100)
+    with pytest.raises(_lib.PgcnError):
+        ingest.shard_info(str(tmp_path / "junk.pgcsr"))
+
+
+def test_plan_host_keeps_64_bit_entry_offsets():
+    """papers100M-scale blocks hold more than 2^31 stored entries per rank: the plan's task records carry the
+    absolute entry offset as two 32-bit words.  A row block whose row pointers START beyond 2^33 (the stride
+    trick: no 8 G-entry arrays needed for the host plan) must come back with exact 64-bit offsets."""
+    kernels = pkg("kernels")
+    base = (1 << 33) + 12345
+    lens = np.array([5, 0, 3000, 17, 1, 2500], dtype=np.int64)
+    rowptr = base + np.concatenate([[0], np.cumsum(lens)])
+    tasks, fix, nslots, seg = kernels.build_plan(rowptr, chunk=1024, force=True)
+    kbeg = (tasks[:, 1].astype(np.int64) << 32) | (tasks[:, 0].astype(np.int64) & 0xFFFFFFFF)
+    assert kbeg.min() == base and (kbeg >= base).all() and kbeg.max() < base + lens.sum()
+    cover = np.zeros(int(lens.sum()), dtype=np.int64)
+    for k, ln in zip(kbeg, tasks[:, 2]):
+        cover[k - base:k - base + ln] += 1
+    assert (cover == 1).all()                                        # every stored entry in exactly one task
+    assert int(tasks[:, 2].max()) <= 1024 and nslots == 3 + 3 and fix.shape[0] == 2      # the two long rows are split in 3

@@ -142,3 +142,35 @@ def test_pgcn_main_three_ranks_share_the_gpu():
         if r == 0:
             totals = tot
     assert totals == [rows_total * 5 * L * 2, P * (P - 1) * 5 * L * 2]
+
+
+@pytest.mark.gpu
+def test_bench_with_reference_hypergraph_part_vector():
+    """`bench.py --partvec FILE`: a part vector written by the reference's GPU/hypergraph tool (PaToH) for the
+    `mid` workload (tests/golden/partvec, tools/make_partvecs.py).  The exchanged volume is the tool's cut."""
+    from conftest import GOLDEN
+    pv = os.path.join(GOLDEN, "partvec", "mid.A.mtx.2.hp.gz")
+    with open(os.path.join(GOLDEN, "partvec", "mid.stats.json")) as fh:
+        stats = json.load(fh)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "mid", "--partvec", pv,
+                          "--steps", "2", "--warmup", "1"], env=_env(PGCN_BENCH_BACKEND="gloo"),
+                         capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["config"]["partition"] == "file:mid.A.mtx.2.hp.gz" and rec["n_gpus"] == 2
+    rows = stats["parts"]["2"]["hp"]["boundary_rows_per_aggregation"]
+    L = rec["config"]["layers"]
+    assert rec["exchange_rows_total"] == rows * 2 * L * 3          # (warm-up + steps) epochs x 2L aggregations
+    assert rows < stats["parts"]["2"]["rp"]["boundary_rows_per_aggregation"]
+
+
+@pytest.mark.gpu
+def test_bench_sbm_generator_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "mid", "--generator", "sbm",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=_env(),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["config"]["generator"] == "sbm" and "planted-partition" in rec["config"]["workload"]
+    assert rec["config"]["vertex_order"]["order"] == "community"
+    assert rec["roofline"]["split_us"] and "error" not in rec["roofline"]["split_us"]

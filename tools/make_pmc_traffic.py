@@ -2,9 +2,20 @@
 """profiles/pmc_traffic.json from a pmc_summary.py text (tools/final_profile.sh): per-launch L2<->fabric bytes of the
 SpMM launch group.  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md: the
 counter tallies 128-byte fabric reads at 64 B).  usage: make_pmc_traffic.py SUMMARY.txt OUT.json [source-name]"""
+import importlib.util
 import json
+import os
 import re
 import sys
+
+
+def source_stamp():
+    """bench.kernel_source_stamp(): the kernel sources this PMC record is valid for."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.kernel_source_stamp()
 
 
 def main():
@@ -25,7 +36,7 @@ def main():
                 per.setdefault(m.group(1), {}).setdefault("mean_us", float(m.group(2)))
     read = sum(2 * 1024 * v.get("FETCH_SIZE", 0) for v in per.values())
     write = sum(1024 * v.get("WRITE_SIZE", 0) for v in per.values())
-    out = {"workload": "reddit", "n_gpus": 1, "f": 128,
+    out = {"workload": "reddit", "n_gpus": 1, "f": 128, "generator": "rmat", "source_stamp": source_stamp(),
            "kernel": "A_loc.H launch group: " + " + ".join(sorted(per)),
            "hbm_bytes_per_launch": int(read + write), "read_bytes": int(read), "write_bytes": int(write),
            "per_kernel": per,
