@@ -210,6 +210,7 @@ STRIP_PAD_OFF = 128 * 512         # byte offset of the all-zero LDS row: what an
 # hundred stored entries to pay for itself.
 STRIP_MIN = int(os.environ.get("PGCN_STRIP_MIN", "512"))        # entries that make a 512 x 128 tile worth staging
 STRIP_LAYER_MIN = int(os.environ.get("PGCN_STRIP_LAYER_MIN", "384"))   # stored entries that make one more record of a tile worth it
+STRIP_MIN_RECORDS = int(os.environ.get("PGCN_STRIP_MIN_RECORDS", "16384"))   # blocks with fewer strip records use the 128 x 128 LDS core
 STRIP_THEN_CORE = os.environ.get("PGCN_STRIP_CORE", "0") != "0"   # legacy 128 x 128 LDS core on what the strips leave
 STRIP_PIECES = int(os.environ.get("PGCN_STRIP_PIECES", "1024"))  # target number of work pieces
 STRIP_STAGE_COST = float(os.environ.get("PGCN_STRIP_STAGE_COST", "1.0"))  # staging a panel ~ this many records of work
@@ -462,6 +463,14 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
             r, c, v = r[keep], c[keep], v[keep]
         if use_strip:
             skeep, hstrip = build_strips(r.to(torch.int64), c.to(torch.int64), v, nrows, ncols, strip_min)
+            if hstrip is not None and strip_min is None and hstrip.rec.shape[0] < STRIP_MIN_RECORDS:
+                # a small block (a rank's shard of an 8-way run): too few records to fill 256 one-workgroup CUs with
+                # pieces long enough to amortise their 512-row partial block -- the finer-grained 128 x 128 LDS core
+                # (two workgroups per CU, 128-row pieces) serves it better (measured: tools/rank_probe.py, r02)
+                skeep = hstrip = None
+                ckeep, hcore, _ = split_core(r, c, v, nrows, ncols, tau, emax, 2.0)
+                if ckeep is not None and hcore is not None:
+                    r, c, v = r[ckeep], c[ckeep], v[ckeep]
             if skeep is not None:
                 r, c, v = r[skeep], c[skeep], v[skeep]
             if STRIP_THEN_CORE and r.numel():

@@ -27,9 +27,10 @@ def main():
     def frac(d):
         ds = d if isinstance(d, list) else [d]
         tot = sum(x.nnz for x in ds if x is not None)
-        return 100.0 * sum(x.core.nnz for x in ds if x is not None and x.core is not None) / max(tot, 1)
+        return 100.0 * sum((x.core.nnz if x.core is not None else 0) + (x.strip.nnz if getattr(x, "strip", None) is not None else 0)
+                           + (x.dense.nnz if getattr(x, "dense", None) is not None else 0) for x in ds if x is not None) / max(tot, 1)
     print("rounds=%d " % p.rounds, end="")
-    print("P=%d rank=%d n_local=%d n_halo=%d n_send=%d nnz_loc=%d nnz_halo=%d | build %.2fs prepare %.2fs | core%%: loc %.0f halo %.0f locT %.0f haloT %.0f"
+    print("P=%d rank=%d n_local=%d n_halo=%d n_send=%d nnz_loc=%d nnz_halo=%d | build %.2fs prepare %.2fs | tiled%% (strips + core + MFMA): loc %.0f halo %.0f locT %.0f haloT %.0f"
           % (a.world, a.rank, p.n_local, p.n_halo, p.n_send, p.A_loc.nnz, sum(x.nnz for x in p.A_halo), tb, tp,
              frac(eng.A_loc), frac(eng.A_halo), frac(eng.A_loc_T), frac(eng.A_halo_T)))
     H = torch.rand(p.n_local, a.f, device=dev)
