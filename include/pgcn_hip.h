@@ -302,7 +302,9 @@ int pgcn_csr_permute_f32(const float *src, const int64_t *perm, int64_t nnz, int
  * out[r,:] = H[idx[r],:]                      replaces H[indices]   GPU/PGCN.py:104
  * H[idx[r],:] (+)= in[r,:]                    replaces X[indices] = buf   :115
  *                                             (accumulate: main.c:295,400 semantics)
- * idx entries must be unique within one call when accumulate != 0.            */
+ * accumulate != 0 adds with atomics: repeated indices (a boundary row that comes back from several peers)
+ * are all added; only the ORDER of the adds of a repeated index is not fixed.  accumulate == 0 with a
+ * repeated index keeps one of the rows (like the reference's assignment, quirk Q3).                 */
 int pgcn_gather_rows_f32(const float *H, int64_t ldh, const int32_t *idx, int64_t nidx,
                          float *out, int64_t ldo, int32_t f, pgcn_stream_t stream);
 int pgcn_scatter_rows_f32(float *H, int64_t ldh, const int32_t *idx, int64_t nidx,

@@ -39,11 +39,13 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(
             } else if constexpr (!ACC) {
                 pi[v] = pp[v];
             } else {
-                V a = pi[v];
+                // accumulate: an index may occur several times (a boundary row that comes back from several
+                // peers) -- atomic adds, so no partial sum is lost (the order of the adds is then not fixed; the
+                // engine's own reverse exchange uses a deterministic pattern SpMM instead, partition.unpack)
                 const V b = pp[v];
-                if constexpr (VEC == 1) { a += b; }
-                else { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-                pi[v] = a;
+                float *pf = reinterpret_cast<float *>(pi + v);
+                if constexpr (VEC == 1) { atomicAdd(pf, b); }
+                else { atomicAdd(pf, b.x); atomicAdd(pf + 1, b.y); atomicAdd(pf + 2, b.z); atomicAdd(pf + 3, b.w); }
             }
         }
     }

@@ -132,11 +132,13 @@ extern "C" int pgcn_spmm_core_f32(const int32_t *work, int64_t nwork, const int3
         static long pad = -1;   // experiment knob: extra dynamic LDS => one workgroup per CU
         if (pad < 0) { const char *e = getenv("PGCN_CORE_LDS_PAD"); pad = e ? atol(e) : 0; }
         smem += (size_t)pad;
-        static bool attr_set = false;
-        if (!attr_set) {
+        int dev = 0;
+        PGCN_HIP_CHECK(hipGetDevice(&dev));
+        static bool attr_set[64] = {false};              // the attribute is per device
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
             PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_core_kernel<4>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr_set = true;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         const int ntiles = (f + 127) / 128;
         hipLaunchKernelGGL((spmm_core_kernel<4>), dim3((unsigned)nwork, ntiles), dim3(kCoreThreads), smem, s,

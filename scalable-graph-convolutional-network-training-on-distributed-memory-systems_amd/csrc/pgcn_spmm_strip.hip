@@ -115,7 +115,9 @@ __device__ __forceinline__ void fma_row(f32x2 (&acc)[2], float w, const f32x4 &x
 }
 
 // work: int4 {tile row, first record, one-past-last record, first slot}; recs: int4 {panel, flags, -, -}
-template <int dbg>
+// PROBE: 0 = the product kernel; 1 = no compute phase, 2 = no panel staging (compile-time variants used once to
+// separate the LDS-bound compute from the staging pipeline: DESIGN.md 4; selected by PGCN_STRIP_PROBE)
+template <int PROBE>
 __global__ __launch_bounds__(kThreads, 1) void spmm_strip_kernel(
     const int4 *__restrict__ work, const int4 *__restrict__ recs, const int32_t *__restrict__ pairs,
     const float *__restrict__ B, int64_t ldb, int64_t ncols, int32_t f, float *__restrict__ partial) {
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(kThreads, 1) void spmm_strip_kernel(
         int pbn = pb;
         if (k + 1 < wk.z) {
             const int4 nx = recs[k + 1];
-            const bool stage = (nx.y & 1) == 0 && !(dbg & 2);
+            const bool stage = (nx.y & 1) == 0 && !(PROBE & 2);
             pbn = stage ? pb ^ 1 : pb;
             issue_record(nx.x, stage, smem, pbn, qb ^ 1, B, ldb, ncols, fcol0, fw, pairs, k + 1, wave, lane);
             wait_for_previous(stage, extra);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(kThreads, 1) void spmm_strip_kernel(
             wait_vm<0>();
         }
         __builtin_amdgcn_s_barrier();      // every thread's copies of record k have landed
-        if constexpr (!(dbg & 1)) {
+        if constexpr (!(PROBE & 1)) {
             const uint32_t pa = lds0 + kOffPairs + qb * kRecBytes + group * (RW * SB * 8);   // this group's 16 x 2 pairs
             const uint32_t rowbase = lds0 + pb * kPanelBytes + sub * 16;
             // software pipeline over pairs of row slots: the pair reads of slots J+2, J+3 are in flight
@@ -251,7 +253,7 @@ extern "C" int pgcn_spmm_strip_f32(const int32_t *work, int64_t nwork, const int
     const int4 *w4 = reinterpret_cast<const int4 *>(work);
     const int4 *r4 = reinterpret_cast<const int4 *>(recs);
     const bool vec = f % 4 == 0 && ldb % 4 == 0 && (uintptr_t)B % 16 == 0 && (uintptr_t)partial_ws % 16 == 0;
-    static const int dbg = getenv("PGCN_STRIP_DBG") ? atoi(getenv("PGCN_STRIP_DBG")) : 0;   // probes: 1 = no compute, 2 = no staging
+    static const int probe = getenv("PGCN_STRIP_PROBE") ? atoi(getenv("PGCN_STRIP_PROBE")) : 0;   // measurement aid, see the kernel
     if (vec) {
         int dev = 0;
         PGCN_HIP_CHECK(hipGetDevice(&dev));
@@ -264,7 +266,7 @@ extern "C" int pgcn_spmm_strip_f32(const int32_t *work, int64_t nwork, const int
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         const dim3 grid((unsigned)nwork, (unsigned)((f + 127) / 128));
-        switch (dbg) {
+        switch (probe) {
             case 1: hipLaunchKernelGGL(spmm_strip_kernel<1>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws); break;
             case 2: hipLaunchKernelGGL(spmm_strip_kernel<2>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws); break;
             case 3: hipLaunchKernelGGL(spmm_strip_kernel<3>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws); break;

@@ -384,6 +384,14 @@ def test_gather_scatter_bit_exact(K, dev, f):
         oracle.scatter_rows(ref, idx, src, acc)
         np.testing.assert_array_equal(X.cpu().numpy(), ref)
     K.gather_rows(Hd, idxd[:0], out)                               # empty index list is a no-op
+    # accumulate with REPEATED indices (a boundary row that comes back from several peers): every row is added
+    dup = np.concatenate([idx[:400], idx[:400], idx[:100]]).astype(np.int32)
+    srcd = rng.random((dup.size, f), dtype=np.float32)
+    X = torch.from_numpy(H).to(dev)
+    K.scatter_rows(X, torch.from_numpy(dup).to(dev), torch.from_numpy(srcd).to(dev), True)
+    ref = H.astype(np.float64)
+    np.add.at(ref, dup, srcd.astype(np.float64))
+    assert rel_err(X.cpu().numpy(), ref) < 1e-6
 
 
 class _PrecomputedExchanger:
