@@ -189,20 +189,22 @@ class GatKernelTimer:
 
     def __init__(self, kernels, device):
         self.k, self.device, self.records, self.on = kernels, device, [], False
-        self._fn = kernels.gat_edge_grad_sliced
-        kernels.gat_edge_grad_sliced = self.call
+        for name in ("gat_edge_grad_tasks", "gat_edge_grad_sliced"):      # whichever variant the engine uses
+            setattr(kernels, name, self._wrap(getattr(kernels, name)))
 
-    def call(self, *a, **kw):
-        if not self.on:
-            return self._fn(*a, **kw)
-        s = torch.cuda.current_stream(self.device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(s)
-        out = self._fn(*a, **kw)
-        e1.record(s)
-        if out:
-            self.records.append((e0, e1))
-        return out
+    def _wrap(self, fn):
+        def call(*a, **kw):
+            if not self.on:
+                return fn(*a, **kw)
+            s = torch.cuda.current_stream(self.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            out = fn(*a, **kw)
+            e1.record(s)
+            if out:
+                self.records.append((e0, e1))
+            return out
+        return call
 
     def mean_ms(self):
         ts = [a.elapsed_time(b) for a, b in self.records]
@@ -278,8 +280,8 @@ def bench_gat(args, rank, world, dev, backend, stage):
         n_r, n_c = part.n_local, part.n_local + part.n_halo
         alg = (4 + 8 * heads) * eng.nnz + 4 * F * (n_c + n_r)      # col + alpha + de per entry and head; Z and dOut panels
         ach = alg / (avg * 1e-3)
-        roofline = {"bound": "hbm", "kernel": "gat_edge_grad_heads_kernel (XCD-sliced SDDMM <dOut_i, Z_j> + softmax / "
-                                              "LeakyReLU backward, one pass over the stored entries)",
+        roofline = {"bound": "hbm", "kernel": "gat_edge_grad_%s_kernel (XCD-sliced SDDMM <dOut_i, Z_j> + softmax / LeakyReLU "
+                                              "backward, one pass over the stored entries)" % ("tasks" if eng.task_grad else "heads"),
                     "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
                     "alg_bytes_per_launch": alg, "avg_launch_ms": avg, "launches_timed": launches,
                     "gather_model_GBs": 4.0 * F * eng.nnz / (avg * 1e-3) / 1e9}

@@ -291,6 +291,19 @@ int pgcn_gat_edge_grad_sliced_f32(const int64_t *rowptr, const int32_t *col, con
                                   const float *dOut, int64_t ldo, const float *t, int32_t heads,
                                   int32_t d, float slope, int32_t mode, float *de, float *ds1_slices,
                                   pgcn_stream_t stream);
+/* The edge gradient over the TASKS of the SpMM plan of the same structure (pgcn_spmm_plan_host: XCD slices,
+ * chunks of long rows, longest first) instead of one wave per (row, slice): the hub rows of a power-law graph
+ * no longer form a tail of a few very long waves.  ds1 [nrows x heads] is complete on return (stream order):
+ * single-task rows are written directly, the others go through `nslots` slots of `heads` floats in partial_ws
+ * and pgcn_spmm_fixup_f32 (fixed order).  Same shape limits as the sliced variant.                       */
+int pgcn_gat_edge_grad_tasks_f32(const int64_t *rowptr, const int32_t *col, int64_t nrows, int64_t nnz,
+                                 const int32_t *tasks, int64_t ntasks, const int64_t *seg, int32_t nslices,
+                                 const int32_t *fix, int64_t nfix, const float *s1, int64_t lds1,
+                                 const float *s2, int64_t lds2, const float *alpha, const float *beta,
+                                 const float *Z, int64_t ldz, const float *dOut, int64_t ldo, const float *t,
+                                 int32_t heads, int32_t d, float slope, int32_t mode, float *de, float *ds1,
+                                 float *partial_ws, int64_t partial_ws_elems, int64_t nslots,
+                                 pgcn_stream_t stream);
 int pgcn_csr_row_sums_f32(const int64_t *rowptr, const int64_t *perm, int64_t nrows, int64_t nnz,
                           const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
                           int64_t nrows_block, const float *src, int32_t planes, float *out,

@@ -68,6 +68,9 @@ SIGNATURES = {
     "pgcn_gat_edge_grad_sliced_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                                                      _vp, _i64, _vp, _i64, _vp, _i32, _i32, ctypes.c_float, _i32, _vp, _vp,
                                                      _vp]),
+    "pgcn_gat_edge_grad_tasks_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64,
+                                                    _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, ctypes.c_float, _i32,
+                                                    _vp, _vp, _vp, _i64, _i64, _vp]),
     "pgcn_csr_row_sums_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "pgcn_csr_permute_f32": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "pgcn_gather_rows_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp]),

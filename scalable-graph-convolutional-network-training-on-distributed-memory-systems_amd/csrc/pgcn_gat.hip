@@ -356,6 +356,112 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_heads_kernel(
     }
 }
 
+// The same pass over the TASKS of the SpMM plan (pgcn_spmm_plan_host: a task is a row, or an XCD slice / a chunk
+// of <= `chunk` entries of a long row; workgroup b takes tasks of slice b % nslices = its XCD; longest first).
+// One wave per (row, slice) leaves the hub rows of a power-law graph as a tail of a few very long waves
+// (Reddit shape: 13 k entries in one wave); chunked tasks balance like the SpMM.  A task's row is found by
+// binary search of its first entry in rowptr; its sum over de goes to ds1 directly (the row's only task) or to a
+// slot that pgcn_spmm_fixup_f32 adds in slot order (deterministic).
+struct GatSeg { int64_t v[PGCN_MAX_SLICES + 1]; };
+
+template <int MODE, int U>
+__global__ __launch_bounds__(kThreads) void gat_edge_grad_tasks_kernel(
+    const int64_t *__restrict__ rowptr, int64_t nrows, const int32_t *__restrict__ col, const int4 *__restrict__ tasks,
+    int64_t ntasks, int32_t nslices, GatSeg seg, const float *__restrict__ s1, int64_t lds1, const float *__restrict__ s2,
+    int64_t lds2, const float *__restrict__ alpha, const float *__restrict__ beta, const float *__restrict__ Z, int64_t ldz,
+    const float *__restrict__ dOut, int64_t ldo, const float *__restrict__ t, int32_t heads, int32_t d, int32_t lpe,
+    float slope, float *__restrict__ de, float *__restrict__ ds1, float *__restrict__ partial, int64_t nnz) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int64_t tid;
+    if (nslices > 1) {
+        const int sl = blockIdx.x % nslices;
+        tid = seg.v[sl] + (int64_t)(blockIdx.x / nslices) * (kThreads / 64) + wave;
+        ntasks = seg.v[sl + 1];
+    } else {
+        tid = (int64_t)blockIdx.x * (kThreads / 64) + wave;
+    }
+    if (tid >= ntasks) return;
+    int64_t b, i;
+    int32_t len, dst;
+    if (tasks) {
+        const int4 tk = tasks[tid];
+        b = (int64_t)(((uint64_t)(uint32_t)tk.y << 32) | (uint32_t)tk.x);
+        len = tk.z;
+        dst = tk.w;
+        if (dst < 0) {
+            i = ~dst;
+        } else {                             // largest i with rowptr[i] <= b (a split row is never empty)
+            int64_t lo = 0, hi = nrows - 1;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi + 1) >> 1;
+                if (rowptr[mid] <= b) lo = mid; else hi = mid - 1;
+            }
+            i = lo;
+        }
+    } else {
+        i = tid;
+        b = rowptr[i];
+        len = (int32_t)(rowptr[i + 1] - b);
+        dst = -1;
+    }
+    const int64_t e = b + len;
+    const int nvec = heads * d / 4;
+    const int hl = d / 4;
+    const int sub = lane & (lpe - 1);
+    const int team = lane / lpe;
+    const int nteam = 64 / lpe;
+    const int hk = sub / hl;
+    const int u_mine = sub % hl;
+    const bool live = sub < nvec;
+    const bool fin = live && u_mine < U;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) g0 = reinterpret_cast<const float4 *>(dOut + i * ldo)[sub];
+    float a = 0.f, ti = 0.f, bi = 0.f;
+    if (fin) {
+        a = s1[i * lds1 + hk];
+        ti = t[i * heads + hk];
+        if (MODE == 1) bi = beta[i * heads + hk];
+    }
+    const float *ak = alpha + (int64_t)hk * nnz;
+    float *dk = de + (int64_t)hk * nnz;
+    float acc = 0.f;
+    for (int64_t p0 = b + (int64_t)team * U; p0 < e; p0 += (int64_t)nteam * U) {
+        int64_t c[U];
+        float dot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = col[p0 + u < e ? p0 + u : e - 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dot[u] = 0.f;
+            if (live) dot[u] = Vec<4>::dot(g0, reinterpret_cast<const float4 *>(Z + c[u] * ldz)[sub]);
+        }
+        for (int o = hl >> 1; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+        }
+        float dm = dot[0];
+        int64_t cm = c[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u) {
+            dm = u_mine == u ? dot[u] : dm;
+            cm = u_mine == u ? c[u] : cm;
+        }
+        const int64_t p = p0 + u_mine;
+        if (fin && p < e) {
+            float g = (ak[p] + bi) * (dm - ti);
+            if (MODE == 0) g *= (a + s2[cm * lds2 + hk]) > 0.f ? 1.f : slope;
+            dk[p] = g;
+            acc += g;
+        }
+    }
+    float *outp = dst >= 0 ? partial + (int64_t)dst * heads : ds1 + i * heads;
+    for (int k = 0; k < heads; ++k) {
+        const float v = wave_sum((fin && hk == k) ? acc : 0.f, 64);
+        if (lane == 0) outp[k] = v;
+    }
+}
+
 template <int TPR>
 __global__ __launch_bounds__(kThreads) void csr_row_sums_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ perm, const int32_t *__restrict__ rows,
@@ -555,6 +661,65 @@ extern "C" int pgcn_gat_edge_grad_sliced_f32(const int64_t *rowptr, const int32_
     }
 #undef PGCN_EGRAD_S
     PGCN_HIP_CHECK(hipGetLastError());
+    return PGCN_OK;
+}
+
+extern "C" int pgcn_gat_edge_grad_tasks_f32(const int64_t *rowptr, const int32_t *col, int64_t nrows, int64_t nnz,
+                                            const int32_t *tasks, int64_t ntasks, const int64_t *seg, int32_t nslices,
+                                            const int32_t *fix, int64_t nfix, const float *s1, int64_t lds1,
+                                            const float *s2, int64_t lds2, const float *alpha, const float *beta,
+                                            const float *Z, int64_t ldz, const float *dOut, int64_t ldo, const float *t,
+                                            int32_t heads, int32_t d, float slope, int32_t mode, float *de, float *ds1,
+                                            float *partial_ws, int64_t partial_ws_elems, int64_t nslots,
+                                            pgcn_stream_t stream) {
+    const char *who = "pgcn_gat_edge_grad_tasks_f32";
+    if (nrows < 0 || nnz < 0 || ntasks < 0 || nfix < 0 || nslots < 0 || heads < 1 || d < 1 || lds1 < heads || lds2 < heads ||
+        ldz < (int64_t)heads * d || ldo < (int64_t)heads * d || (mode != 0 && mode != 1) || nslices < 1 ||
+        nslices > PGCN_MAX_SLICES || (nslices > 1 && (!seg || !tasks)))
+        return pgcn_set_error2(PGCN_EINVAL, who, "bad sizes");
+    const int F4 = heads * d / 4, hl = d / 4;
+    const bool v4 = d % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 && (uintptr_t)Z % 16 == 0 && (uintptr_t)dOut % 16 == 0;
+    if (!v4 || F4 > 64 || (hl & (hl - 1)) != 0)
+        return pgcn_set_error2(PGCN_EUNSUPPORTED, who, "needs heads*d <= 256, d a power of two >= 4, 16-byte aligned panels");
+    const int64_t nt = tasks ? ntasks : nrows;
+    if (nrows == 0 || nt == 0) return PGCN_OK;
+    if (!rowptr || !s1 || !t || !ds1 || !dOut || (nnz && (!col || !s2 || !alpha || !Z || !de)) || (mode == 1 && !beta) ||
+        (nfix > 0 && !fix) || (nslots > 0 && !partial_ws))
+        return pgcn_set_error2(PGCN_EINVAL, who, "null pointer");
+    if (partial_ws_elems < nslots * (int64_t)heads) return pgcn_set_error2(PGCN_ENOMEM, who, "partial work-space too small");
+    GatSeg sg{};
+    int64_t grid;
+    if (nslices > 1) {
+        if (seg[0] != 0 || seg[nslices] != ntasks) return pgcn_set_error2(PGCN_EINVAL, who, "seg does not cover the task list");
+        int64_t longest = 0;
+        for (int q = 0; q <= nslices; ++q) sg.v[q] = seg[q];
+        for (int q = 0; q < nslices; ++q) longest = sg.v[q + 1] - sg.v[q] > longest ? sg.v[q + 1] - sg.v[q] : longest;
+        grid = ((longest + 3) / 4) * nslices;
+    } else {
+        grid = (nt + 3) / 4;
+    }
+    if (grid > 0x7fffffffLL) return pgcn_set_error2(PGCN_EINVAL, who, "too many tasks");
+    hipStream_t s = (hipStream_t)stream;
+    int team = 1;
+    while (team < F4) team *= 2;
+    const int4 *t4 = reinterpret_cast<const int4 *>(tasks);
+#define PGCN_EGRAD_T(MODE, UU)                                                                                       \
+    hipLaunchKernelGGL((gat_edge_grad_tasks_kernel<MODE, UU>), dim3((unsigned)grid), dim3(kThreads), 0, s, rowptr, nrows, \
+                       col, t4, nt, nslices, sg, s1, lds1, s2, lds2, alpha, beta, Z, ldz, dOut, ldo, t, heads, d, team,   \
+                       slope, de, ds1, partial_ws, nnz)
+    if (hl >= 8) {
+        if (mode == 0) PGCN_EGRAD_T(0, 8);
+        else PGCN_EGRAD_T(1, 8);
+    } else if (hl >= 4) {
+        if (mode == 0) PGCN_EGRAD_T(0, 4);
+        else PGCN_EGRAD_T(1, 4);
+    } else {
+        if (mode == 0) PGCN_EGRAD_T(0, 1);
+        else PGCN_EGRAD_T(1, 1);
+    }
+#undef PGCN_EGRAD_T
+    PGCN_HIP_CHECK(hipGetLastError());
+    if (nfix > 0) return pgcn_spmm_fixup_f32(fix, nfix, nullptr, nullptr, partial_ws, ds1, heads, heads, 0, stream);
     return PGCN_OK;
 }
 

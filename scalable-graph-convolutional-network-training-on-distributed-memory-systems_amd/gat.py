@@ -130,6 +130,8 @@ class GatEngine(BoundaryExchange):
         self.perm = g.perm.to(self.device)
         self._scratch = {}
         self.sliced_grad = os.environ.get("PGCN_GAT_SLICED", "1") != "0"   # XCD-sliced edge gradient where the shape allows
+        # the edge gradient over the balanced tasks of the SpMM plan (pgcn_gat_edge_grad_tasks_f32)
+        self.task_grad = os.environ.get("PGCN_GAT_TASK_GRAD", "1") != "0" and hasattr(kernels, "gat_edge_grad_tasks")
         # all heads of `attention @ Z` (and of its transpose) in one launch (pgcn_spmm_heads_f32)
         self.multi_head = os.environ.get("PGCN_GAT_MULTIHEAD", "1") != "0" and hasattr(kernels, "spmm_heads")
 
@@ -201,8 +203,16 @@ class GatEngine(BoundaryExchange):
         dOut = dOut.contiguous()
         t = (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
         de = self._plane_scratch("de", K)
-        ds1p = torch.empty((n_p, 8, K), dtype=torch.float32, device=self.device)
-        if self.sliced_grad and self.k.gat_edge_grad_sliced(self.fwd, st.s1, st.s2c, st.alpha, st.beta, st.Zc, dOut, t,
+        ds1 = None
+        if self.task_grad:
+            ds1t = torch.empty((n_p, K), dtype=torch.float32, device=self.device)
+            if self.k.gat_edge_grad_tasks(self.fwd, st.s1, st.s2c, st.alpha, st.beta, st.Zc, dOut, t, K, d, self.slope,
+                                          self.mode_id, de, ds1t):
+                ds1 = ds1t
+        ds1p = torch.empty((n_p, 8, K), dtype=torch.float32, device=self.device) if ds1 is None else None
+        if ds1 is not None:
+            pass
+        elif self.sliced_grad and self.k.gat_edge_grad_sliced(self.fwd, st.s1, st.s2c, st.alpha, st.beta, st.Zc, dOut, t,
                                                             K, d, self.slope, self.mode_id, de, ds1p):
             ds1 = ds1p.sum(1)               # 8 per-XCD partials per row (plumbing: n_p x 8 x K floats)
         else:

@@ -575,6 +575,38 @@ class HipKernels:
             ds1_slices.data_ptr(), self._stream()), "pgcn_gat_edge_grad_sliced_f32")
         return True
 
+    def gat_edge_grad_tasks(self, A: DeviceCSR, s1, s2, alpha, beta, Z, dOut, t, heads: int, d: int, slope: float,
+                            mode: int, de: torch.Tensor, ds1: torch.Tensor) -> bool:
+        """The edge gradient over the tasks of A's SpMM plan (balanced like the SpMM: pgcn_gat_edge_grad_tasks_f32).
+        Returns False when the shape is not covered; ds1: [nrows, heads] contiguous, complete on return."""
+        F = heads * d
+        if d % 4 or F > 256 or (d // 4) & (d // 4 - 1) or Z.stride(0) % 4 or dOut.stride(0) % 4 \
+                or Z.data_ptr() % 16 or dOut.data_ptr() % 16 or A.row_map is not None:
+            return False
+        self._check_rows(s1, A.nrows, heads, "s1")
+        self._check_rows(s2, A.ncols, heads, "s2")
+        self._check_rows(t, A.nrows, heads, "t")
+        self._check_rows(ds1, A.nrows, heads, "ds1")
+        self._check_rows(dOut, A.nrows, F, "dOut")
+        nnz = A.col.numel()
+        if de.shape != alpha.shape or not de.is_contiguous() or not alpha.is_contiguous() or (nnz and alpha.shape[1] != nnz) \
+                or t.stride(0) != heads or ds1.stride(0) != heads or beta.stride(0) != heads or Z.shape[0] < A.ncols \
+                or Z.shape[1] < F:
+            raise _lib.PgcnError("bad operand shapes for the task-based edge gradient")
+        need = A.nslots * max(F, heads)
+        if need and (A.ws is None or A.ws.numel() < need):
+            A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            A.launch_cache.clear()
+        rc = self.lib.pgcn_gat_edge_grad_tasks_f32(
+            A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, _ptr(A.tasks), A.ntasks, A.seg, A.nslices, _ptr(A.fix),
+            A.nfix, s1.data_ptr(), s1.stride(0), s2.data_ptr(), s2.stride(0), alpha.data_ptr(), beta.data_ptr(), Z.data_ptr(),
+            Z.stride(0), dOut.data_ptr(), dOut.stride(0), t.data_ptr(), heads, d, slope, mode, de.data_ptr(), ds1.data_ptr(),
+            _ptr(A.ws), 0 if A.ws is None else A.ws.numel(), A.nslots, self._stream())
+        if rc == _lib.PGCN_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "pgcn_gat_edge_grad_tasks_f32")
+        return True
+
     def csr_row_sums(self, A: DeviceCSR, perm: Optional[torch.Tensor], src: torch.Tensor, planes: int,
                      out: torch.Tensor) -> None:
         self._check_rows(out, A.nrows, planes, "out")

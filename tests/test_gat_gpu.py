@@ -381,3 +381,44 @@ def test_multi_head_spmm_unsupported_shapes_fall_back(K, dev):
     assert K.spmm_heads(dA, alpha, Z, out, 5, 64) is False          # 320 features: one SpMM per head instead
     alpha = torch.rand((2, A.nnz), device=dev)
     assert K.spmm_heads(dA, alpha, torch.rand((90, 12), device=dev), torch.empty((100, 12), device=dev), 2, 6) is False
+
+
+@pytest.mark.parametrize("mode", ["standard", "reference"])
+@pytest.mark.parametrize("heads,d", [(4, 64), (2, 32), (1, 16), (8, 32)])
+@pytest.mark.parametrize("nslices,chunk", [(1, 1024), (8, 1024), (8, 32)])
+def test_edge_gradient_over_plan_tasks(K, dev, mode, heads, d, nslices, chunk):
+    """pgcn_gat_edge_grad_tasks_f32 (balanced tasks of the SpMM plan, split rows through slots) == the per-row
+    kernel: de bit for bit (the same per-entry arithmetic), ds1 up to the summation order."""
+    n, m = 400, 360
+    A, rng = _graph(n, m, 11 * heads + d)
+    A.sort_indices()
+    mode_id = {"standard": 0, "reference": 1}[mode]
+    old, K.chunk = K.chunk, chunk
+    try:
+        dA, _, _, er, ec = _structure(K, A, nslices, 1 << 30)
+    finally:
+        K.chunk = old
+    nnz, F = A.nnz, heads * d
+    ld = F + heads + (4 - (F + heads) % 4) % 4
+    Zd = torch.from_numpy((rng.standard_normal((m, ld)) * 0.7).astype(np.float32)).to(dev)
+    s1 = torch.from_numpy((rng.standard_normal((n, heads)) * 1.5).astype(np.float32)).to(dev)
+    s2 = Zd[:, F:F + heads].contiguous()
+    alpha = torch.empty((heads, nnz), device=dev)
+    beta = torch.zeros((n, heads), device=dev)
+    rowstat = torch.empty((n, heads, 4), device=dev)
+    K.gat_edge_softmax(dA, s1, s2, heads, 0.2, mode_id, 1000, alpha, beta, rowstat)
+    if mode == "standard":
+        beta.zero_()
+    dOut = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(dev)
+    t = torch.from_numpy(rng.standard_normal((n, heads)).astype(np.float32)).to(dev)
+    de0, ds0 = torch.full((heads, nnz), float("nan"), device=dev), torch.full((n, heads), float("nan"), device=dev)
+    K.gat_edge_grad(dA, s1, s2, alpha, beta, Zd, dOut, t, heads, d, 0.2, mode_id, de0, ds0)
+    de1, ds1 = torch.full((heads, nnz), float("nan"), device=dev), torch.full((n, heads), float("nan"), device=dev)
+    assert K.gat_edge_grad_tasks(dA, s1, s2, alpha, beta, Zd, dOut, t, heads, d, 0.2, mode_id, de1, ds1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(de1).all() and torch.isfinite(ds1).all()
+    assert float((de1 - de0).abs().max()) <= 1e-6 * float(de0.abs().max())
+    assert rel_err(ds1.cpu().numpy(), ds0.cpu().numpy()) < TOL
+    de2, ds2 = torch.empty_like(de1), torch.empty_like(ds1)
+    K.gat_edge_grad_tasks(dA, s1, s2, alpha, beta, Zd, dOut, t, heads, d, 0.2, mode_id, de2, ds2)
+    assert torch.equal(de1, de2) and torch.equal(ds1, ds2)            # deterministic
