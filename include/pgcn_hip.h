@@ -311,6 +311,17 @@ int pgcn_csr_row_sums_f32(const int64_t *rowptr, const int64_t *perm, int64_t nr
 int pgcn_csr_permute_f32(const float *src, const int64_t *perm, int64_t nnz, int32_t planes,
                          float *dst, pgcn_stream_t stream);
 
+/* ---- loss of the training loop (plumbing next to the graded path, one pass each way) -----------------
+ * loss_rows[i] = logsumexp_j X[i,j] - X[i, labels[i]]   = nll_loss(log_softmax(logits), labels) per row,
+ * GPU/PGCN.py:214-215 (the caller sums / scales); lse_rows[i] is kept for the backward:
+ * dX[i,j] = gscale_dev[0] * scale * (exp(X[i,j] - lse_rows[i]) - [j == labels[i]])   (gscale_dev NULL = 1).
+ * f <= 1024 columns; labels int64 in [0, f).                                                             */
+int pgcn_nll_rows_f32(const float *X, int64_t ldx, const int64_t *labels, int64_t nrows, int32_t f,
+                      float *loss_rows, float *lse_rows, pgcn_stream_t stream);
+int pgcn_nll_rows_backward_f32(const float *X, int64_t ldx, const int64_t *labels, const float *lse_rows,
+                               const float *gscale_dev, float scale, int64_t nrows, int32_t f, float *dX,
+                               int64_t lddx, pgcn_stream_t stream);
+
 /* ---- boundary-row pack / unpack -------------------------------------------
  * out[r,:] = H[idx[r],:]                      replaces H[indices]   GPU/PGCN.py:104
  * H[idx[r],:] (+)= in[r,:]                    replaces X[indices] = buf   :115

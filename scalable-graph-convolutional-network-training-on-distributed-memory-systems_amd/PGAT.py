@@ -242,6 +242,10 @@ def initiliaze_parameters(model):
 
 def local_loss(logits, labels, n_global):
     """PGAT.py:214-215 split over the ranks: (sum over OWNED rows of nll) / n."""
+    k = _kernel_provider if _kernel_provider is not None else getattr(_engine_current, "k", None)
+    if (k is not None and hasattr(k, "nll_rows") and logits.is_cuda and logits.dtype is torch.float32 and logits.shape[1] <= 1024
+            and logits.stride(1) == 1 and labels.dtype is torch.int64 and labels.is_contiguous()):
+        return _pgcn._RowNLLSum.apply(logits, labels, k) / n_global          # one-pass HIP kernels
     picked = logits.gather(1, labels.unsqueeze(1)).squeeze(1)
     return (torch.logsumexp(logits, 1) - picked).sum() / n_global
 

@@ -203,14 +203,41 @@ class _LinearNoBias(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = g @ weight
         if ctx.needs_input_grad[1]:
-            n, S = x.shape[0], _LinearNoBias.SLABS
-            m = (n // S) * S
-            if m >= 8 * S and g.is_contiguous() and x.is_contiguous():
-                gw = torch.bmm(g[:m].view(S, m // S, -1).transpose(1, 2), x[:m].view(S, m // S, -1)).sum(0)
-                if m < n:
-                    gw = gw + g[m:].t() @ x[m:]
-            else:
-                gw = g.t() @ x
+            gw = _LinearNoBias.weight_grad(g, x)
+        return gx, gw
+
+    @staticmethod
+    def weight_grad(g, x):
+        n, S = x.shape[0], _LinearNoBias.SLABS
+        m = (n // S) * S
+        if m >= 8 * S and g.is_contiguous() and x.is_contiguous():
+            gw = torch.bmm(g[:m].view(S, m // S, -1).transpose(1, 2), x[:m].view(S, m // S, -1)).sum(0)
+            if m < n:
+                gw = gw + g[m:].t() @ x[m:]
+            return gw
+        return g.t() @ x
+
+
+class _LinearReluNoBias(torch.autograd.Function):
+    """relu(x . W^T) as one autograd node (PGCN.py:146-147): the ReLU is applied in place on the GEMM output and
+    its backward is ONE masked copy (threshold_backward) instead of the compare + multiply pair autograd records
+    for F.relu here (0.7 ms of a 13 ms epoch at the benchmark size).  Same arithmetic, relu'(0) = 0."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        y = (x @ weight.t()).clamp_min_(0.0)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = g @ weight
+        if ctx.needs_input_grad[1]:
+            gw = _LinearNoBias.weight_grad(g, x)
         return gx, gw
 
 
@@ -226,9 +253,7 @@ class PGCN(nn.Module):
 
     def forward(self, H):
         H = PSpMM.apply(self.A, H)
-        H = _LinearNoBias.apply(H, self.linear.weight)      # == self.linear(H)
-        H = F.relu(H)
-        return H
+        return _LinearReluNoBias.apply(H, self.linear.weight)      # == F.relu(self.linear(H)), PGCN.py:146-147
 
 
 def _all_reduce(t, op=dist.ReduceOp.SUM):
@@ -283,16 +308,37 @@ def initiliaze_parameters(model):
         o += p.numel()
 
 
+class _RowNLLSum(torch.autograd.Function):
+    """sum_i nll(log_softmax(x_i), y_i) through the one-pass HIP kernels (pgcn_nll_rows_f32 / _backward_f32)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, kernels):
+        loss_rows, lse = kernels.nll_rows(logits, labels)
+        ctx.k = kernels
+        ctx.save_for_backward(logits, labels, lse)
+        return loss_rows.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse = ctx.saved_tensors
+        return ctx.k.nll_rows_backward(logits, labels, lse, g, 1.0), None, None
+
+
 def local_loss(logits, labels, n_global):
     """PGCN.py:214-215 on a rank that holds only its owned rows: the reference takes
     the mean of nll over ALL n rows of an n x f matrix whose non-owned rows are zero,
     i.e. each missing row contributes log(f) (quirk Q4, kept for comparable output)."""
     f = logits.shape[1]
     missing = n_global - logits.shape[0]
-    # sum_i nll(log_softmax(x_i), y_i) = sum_i (logsumexp(x_i) - x_i[y_i]); same value as
-    # F.nll_loss(F.log_softmax(.), reduction="sum") without its single-workgroup reduction kernel
-    picked = logits.gather(1, labels.unsqueeze(1)).squeeze(1)
-    nll_sum = (torch.logsumexp(logits, 1) - picked).sum()
+    k = _kernel_provider if _kernel_provider is not None else getattr(_engine_current, "k", None)
+    if (k is not None and hasattr(k, "nll_rows") and logits.is_cuda and logits.dtype is torch.float32 and f <= 1024
+            and logits.stride(1) == 1 and labels.dtype is torch.int64 and labels.is_contiguous()):
+        nll_sum = _RowNLLSum.apply(logits, labels, k)
+    else:
+        # sum_i nll(log_softmax(x_i), y_i) = sum_i (logsumexp(x_i) - x_i[y_i]): the framework's composition
+        # (hosts without the HIP provider: the CPU-only tests of the host logic)
+        picked = logits.gather(1, labels.unsqueeze(1)).squeeze(1)
+        nll_sum = (torch.logsumexp(logits, 1) - picked).sum()
     return (nll_sum + missing * math.log(f)) / n_global
 
 

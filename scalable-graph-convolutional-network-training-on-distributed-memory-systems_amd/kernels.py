@@ -631,6 +631,28 @@ class HipKernels:
         _lib.check(self.lib.pgcn_csr_permute_f32(src.data_ptr(), perm.data_ptr(), n, src.shape[0], dst.data_ptr(),
                                                  self._stream()), "pgcn_csr_permute_f32")
 
+    def nll_rows(self, X: torch.Tensor, labels: torch.Tensor):
+        """(loss_rows, lse_rows) of nll_loss(log_softmax(X), labels) per row, or None when the shape is not covered."""
+        if X.dim() != 2 or X.shape[1] > 1024 or X.stride(1) != 1 or labels.dtype is not torch.int64 or not labels.is_contiguous():
+            return None
+        self._check_dense(X, labels.numel(), "X")
+        n, f = labels.numel(), X.shape[1]
+        loss = torch.empty(n, dtype=torch.float32, device=self.device)
+        lse = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pgcn_nll_rows_f32(X.data_ptr(), X.stride(0), labels.data_ptr(), n, f, loss.data_ptr(),
+                                              lse.data_ptr(), self._stream()), "pgcn_nll_rows_f32")
+        return loss, lse
+
+    def nll_rows_backward(self, X: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor, gscale: torch.Tensor,
+                          scale: float) -> torch.Tensor:
+        n, f = labels.numel(), X.shape[1]
+        dX = torch.empty((X.shape[0], f), dtype=torch.float32, device=self.device)
+        g = gscale.reshape(1).to(torch.float32).contiguous()
+        _lib.check(self.lib.pgcn_nll_rows_backward_f32(X.data_ptr(), X.stride(0), labels.data_ptr(), lse.data_ptr(),
+                                                       g.data_ptr(), scale, n, f, dX.data_ptr(), dX.stride(0),
+                                                       self._stream()), "pgcn_nll_rows_backward_f32")
+        return dX
+
     def gather_rows(self, H: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         n = idx.numel()
         if n == 0:

@@ -716,3 +716,32 @@ def test_minibatch_driver_real_kernels(dev, name, P, tmp_path):
         assert got[-1] < got[0]
         for a, b in zip(res[0]["weights"], res[1]["weights"]):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("n,f,ld", [(1, 1, 1), (513, 16, 16), (4000, 128, 128), (777, 100, 104), (300, 1024, 1024), (50, 65, 65)])
+def test_row_nll_kernels_vs_torch(K, dev, n, f, ld):
+    """pgcn_nll_rows_f32 / _backward_f32 == F.nll_loss(F.log_softmax(x), y, reduction='sum') and its gradient
+    (GPU/PGCN.py:214-215), incl. rows with -inf entries and large magnitudes."""
+    import torch.nn.functional as F
+    P = pkg("PGCN")
+    g = torch.Generator(device=dev); g.manual_seed(n + f)
+    buf = torch.randn((n, ld), device=dev, generator=g) * 8
+    if n > 3 and f > 2:
+        buf[1, 0] = float("-inf")
+        buf[2, :f] = 300.0
+        buf[3, 1] = -300.0
+    x = buf[:, :f].detach().requires_grad_(True)
+    y = torch.randint(0, f, (n,), device=dev, generator=g)
+    if n > 3 and f > 2:
+        y[1] = 1
+    out = K.nll_rows(x.detach(), y)
+    assert out is not None
+    ref_rows = F.nll_loss(F.log_softmax(x.detach().double(), 1), y, reduction="none")
+    assert float((out[0].double() - ref_rows).abs().max()) <= 1e-5 * max(1.0, float(ref_rows.abs().max()))
+    loss = P._RowNLLSum.apply(x, y, K) / 7.0
+    loss.backward()
+    xr = x.detach().double().requires_grad_(True)
+    (F.nll_loss(F.log_softmax(xr, 1), y, reduction="sum") / 7.0).backward()
+    assert abs(float(loss) - float(ref_rows.sum() / 7.0)) <= 1e-5 * max(1.0, abs(float(ref_rows.sum() / 7.0)))
+    assert float((x.grad.double() - xr.grad).abs().max()) <= 2e-6
+    assert K.nll_rows(torch.zeros((4, 1025), device=dev), torch.zeros(4, dtype=torch.int64, device=dev)) is None
