@@ -43,6 +43,8 @@ typedef void *pgcn_stream_t; /* hipStream_t */
 #define PGCN_SPMM_OFFSETS32 4u   /* caller guarantees (max col + 1) * ldb * 4 < 2^32 bytes */
 #define PGCN_SPMM_NO_FIXUP 8u    /* plan call: leave partial sums in the work-space; the caller
                                     combines them with pgcn_spmm_fixup_f32                  */
+#define PGCN_SPMM_FPASS64 16u   /* gather kernels: 64 features per pass (grid y = passes, pass-major order) */
+#define PGCN_SPMM_FPASS32 32u   /* gather kernels: 32 features per pass                                     */
 #define PGCN_MAX_SLICES 8        /* = XCDs of an MI355X */
 #define PGCN_MAX_COL_GROUPS 64   /* column groups per slice (time slicing of the column space) */
 #define PGCN_CORE_TR 128         /* rows per tile of the LDS-tiled core kernel    */
@@ -186,15 +188,21 @@ int pgcn_spmm_heads_f32(const int64_t *rowptr, const int32_t *col, const float *
 
 /* ---- strip tiles: 512 x 128, LDS-staged, asynchronous double-buffered pipeline -------------
  * Same product (torch.sparse.mm, GPU/PGCN.py:127,132) for the entries of TALL tiles: a 1024-thread
- * workgroup stages the 128 feature rows of a column panel in LDS once (global_load_lds, one record
- * ahead) and serves all entries of its 512 matrix rows from LDS; pays from 128 entries per tile on.
+ * workgroup stages the 128 feature rows of a column panel in LDS once (global_load_lds, one run of
+ * records ahead) and serves all entries of its 512 matrix rows from LDS; pays from a few hundred
+ * entries per tile on.
  *   work  4 x int32 per piece {tile row, first record, one-past-last record, first slot}
- *   recs  4 x int32 per record {panel, flags, stored entries, layer}; flags bit 0: the panel is the
- *         one the previous record of the piece staged.  A record is one LAYER of a tile: the
- *         (2 l)-th and (2 l + 1)-th stored entry (column order) of every one of its 512 rows
+ *   recs  4 x int32 per record {panel, flags, next panel, layer}; flags bit 0: the panel is the one
+ *         of the previous record of the piece; `next panel`: on a record that starts a run of one
+ *         panel, the panel of the piece's NEXT run (-1: none), else -1.  A record is one LAYER of a
+ *         tile: the (2 l)-th and (2 l + 1)-th stored entry (column order) of every one of its 512 rows
  *   pairs 512 x 2 int32 pairs per record {byte offset of the column's row in the staged panel
  *         (= column-in-panel * 512), value bits}, rows in (group, row slot) order with local row =
- *         row slot * 32 + group; an unused slot holds {65536 (an all-zero LDS row), 0.0f}
+ *         row slot * 64 + group (64 groups of 16 lanes, 8 row slots); an unused slot holds
+ *         {65536 (an all-zero LDS row), 0.0f}
+ * The staged panel of column block p is the 128 rows of B starting at p * 128 -- except the last
+ * block of an operand with ncols % 128 != 0, which is the window [ncols - 128, ncols) (offsets are
+ * relative to the window; ncols >= 128 required).
  * A piece leaves 512 partial rows in slots [first slot, first slot + 512) of partial_ws for
  * pgcn_spmm_fixup_f32.  All three arrays 16-byte aligned.  f % 4 == 0 with 16-byte aligned B /
  * partial_ws takes the LDS pipeline (128 features per workgroup); anything else a plain kernel. */

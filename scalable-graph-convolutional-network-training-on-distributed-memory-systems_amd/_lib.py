@@ -24,6 +24,8 @@ SPMM_ACCUMULATE = 1
 SPMM_XCD_SWIZZLE = 2
 SPMM_OFFSETS32 = 4
 SPMM_NO_FIXUP = 8
+SPMM_FPASS64 = 16
+SPMM_FPASS32 = 32
 MAX_SLICES = 8
 
 _vp = ctypes.c_void_p

@@ -213,7 +213,12 @@ int dispatch(const int64_t *rowptr, const int32_t *col, const float *val, const 
              const int32_t *row_map,
              const float *B, int64_t ldb, float *C, int64_t ldc, int32_t f, float *partial,
              uint32_t flags, hipStream_t s) {
-    const Shape sh = pick_shape(f, B, ldb, C, ldc, partial);
+    Shape sh = pick_shape(f, B, ldb, C, ldc, partial);
+    // feature passes: fewer lanes per task -> the grid's y dimension walks the features 64 / 32 at a time
+    // (pass-major dispatch order), so the rows of B one pass touches are 256 / 128 B each and a pass's
+    // working set is a half / a quarter of the panel
+    if (sh.vec == 4 && (flags & PGCN_SPMM_FPASS64) && sh.lpr > 16) sh.lpr = 16;
+    if (sh.vec == 4 && (flags & PGCN_SPMM_FPASS32) && sh.lpr > 8) sh.lpr = 8;
 #define PGCN_CASE(L, V)                                                                       \
     if (sh.lpr == L && sh.vec == V)                                                           \
         return launch<L, V>(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, row_map, \

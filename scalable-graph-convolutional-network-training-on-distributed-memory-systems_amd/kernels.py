@@ -196,6 +196,8 @@ class HipKernels:
         if xcd_swizzle is None:
             xcd_swizzle = os.environ.get("PGCN_XCD_SWIZZLE", "1") != "0"
         self.base_flags = _lib.SPMM_XCD_SWIZZLE if xcd_swizzle else 0
+        # feature passes of the gather kernels (64 / 32 features per pass; 0 = whole rows)
+        self.base_flags |= {"64": _lib.SPMM_FPASS64, "32": _lib.SPMM_FPASS32}.get(os.environ.get("PGCN_FPASS", "0"), 0)
         self.chunk = chunk
         self.small_row = small_row
         # the LDS-tiled core kernel (LDS-bound) and the gather kernel (L1/L2-bound) use different

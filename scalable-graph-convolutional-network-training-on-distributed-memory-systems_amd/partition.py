@@ -200,12 +200,12 @@ def build_dense(r64, c64, v, tkey_local, ntiles, tile_row, tile_panel, nrows, nc
 # instead of 512 B per entry: a 512 x 128 tile pays off from 128 entries (0.2 % fill) on.
 STRIP_ON = os.environ.get("PGCN_STRIP", "1") != "0"
 STRIP_TR = 512     # rows per strip tile   (PGCN_STRIP_TR in include/pgcn_hip.h)
-STRIP_NG = 32      # 32-lane groups per workgroup (1024 threads)
-STRIP_RW = STRIP_TR // STRIP_NG   # 16 row slots per group, row-in-tile = j * NG + group
+STRIP_NG = 64      # 16-lane groups per workgroup (1024 threads)
+STRIP_RW = STRIP_TR // STRIP_NG   # 8 row slots per group, row-in-tile = j * NG + group
 STRIP_B = 2        # pair slots per row and record (PGCN_STRIP_B)
 STRIP_REC = STRIP_TR * STRIP_B    # pairs per record (8 KB)
 STRIP_PAD_OFF = 128 * 512         # byte offset of the all-zero LDS row: what an unused pair slot points at
-# Thresholds (measured, r02 sweep on the Reddit- and products-shaped graphs): a record costs ~6 k clk of LDS
+# Thresholds (measured, r02 sweep on the Reddit- and products-shaped graphs): a record costs 5-6 k clk of LDS
 # time whatever it holds (1 024 slots), the gather kernel ~17-28 clk per entry, so a layer must hold a few
 # hundred stored entries to pay for itself.
 STRIP_MIN = int(os.environ.get("PGCN_STRIP_MIN", "512"))        # entries that make a 512 x 128 tile worth staging
@@ -222,15 +222,19 @@ class HostStrip:
 
     A RECORD is one LAYER of one 512 x 128 tile: the (2 l)-th and (2 l + 1)-th stored entry (column
     order) of every row of the tile -- exactly 2 pair slots per row, rows in (group, row slot) order
-    with local row = j * 32 + group, so the kernel is straight-line code without counts.  A pair is
-    {byte offset of the column's row inside the staged panel (column * 512), value bits}; an unused
-    slot holds {STRIP_PAD_OFF (an all-zero LDS row), 0.0}."""
+    with local row = j * 64 + group, so the kernel is straight-line code without counts.  A pair is
+    {byte offset of the column's row inside the staged panel (column-in-panel * 512), value bits}; an unused
+    slot holds {STRIP_PAD_OFF (an all-zero LDS row), 0.0}.  The staged panel of column block p is the window of
+    128 operand rows starting at ``strip_panel_base(p, ncols)``: p * 128, except that the last block of an operand
+    whose row count is not a multiple of 128 is the window [ncols - 128, ncols) (no copy reads past the operand)."""
     nrows: int
     ncols: int
     work: torch.Tensor      # int32 [npieces, 4] {tile row, first record, one-past-last record, first slot (local)}
-    rec: torch.Tensor       # int32 [nrec, 4]    {panel, flags (1 = panel of the previous record), stored entries, layer}
+    rec: torch.Tensor       # int32 [nrec, 4]    {panel, flags (1 = panel of the previous record), panel of the piece's
+    #                         NEXT run of records (-1: none; only on records that start a run), layer}
     pairs: torch.Tensor     # int32 [nrec, STRIP_REC, 2]
     rec_tile_row: torch.Tensor   # int32 [nrec] (host bookkeeping)
+    rec_nnz: torch.Tensor        # int32 [nrec] stored entries per record (host bookkeeping)
     nnz_: int
 
     @property
@@ -255,9 +259,17 @@ class HostStrip:
         rec_id, inrec = pos // STRIP_REC, pos % STRIP_REC
         g, j = inrec // (STRIP_RW * STRIP_B), (inrec // STRIP_B) % STRIP_RW
         rows = self.rec_tile_row.to(torch.int64)[rec_id] * STRIP_TR + j * STRIP_NG + g
-        cols = self.rec[:, 0].to(torch.int64)[rec_id] * CORE_TC + off[real] // 512
+        cols = strip_panel_base(self.rec[:, 0].to(torch.int64)[rec_id], self.ncols) + off[real] // 512
         vals = self.pairs[:, :, 1].reshape(-1)[real].contiguous().view(torch.float32)
         return rows, cols, vals
+
+
+def strip_panel_base(panel, ncols: int):
+    """First operand row of the staged window of column block ``panel`` (tensor or int)."""
+    base = panel * CORE_TC
+    if isinstance(base, torch.Tensor):
+        return torch.where(base + CORE_TC <= ncols, base, torch.full_like(base, ncols - CORE_TC))
+    return base if base + CORE_TC <= ncols else ncols - CORE_TC
 
 
 def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
@@ -271,7 +283,7 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     layer_min = min(STRIP_LAYER_MIN, max(1, min_entries)) if layer_min is None else layer_min
     pieces = STRIP_PIECES if pieces is None else pieces
     dev = r64.device
-    if r64.numel() == 0:
+    if r64.numel() == 0 or ncols < TC:       # (a panel is a window of 128 operand rows)
         return None, None
     ncp = (ncols + TC - 1) // TC
     tkey = (r64 // TR) * ncp + c64 // TC
@@ -303,7 +315,7 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     pairs[:, 0] = STRIP_PAD_OFF
     dst = e_rec * STRIP_REC + (g_e * RW + j_e) * SB + slot[in_s]
     cs, vs = c64[order][in_s], v[order][in_s].to(torch.float32)
-    pairs[dst, 0] = ((cs % TC) * 512).to(torch.int32)
+    pairs[dst, 0] = ((cs - strip_panel_base(cs // TC, ncols)) * 512).to(torch.int32)
     pairs[dst, 1] = vs.contiguous().view(torch.int32)
     rk = ul[lsel]
     rec_tile, rec_layer = rk // 64, rk % 64
@@ -326,9 +338,17 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     lpt = np.argsort(-pcost, kind="stable")
     work = np.stack([rtr[kbeg][lpt], kbeg[lpt], kend[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
     same = (~newpanel) & (~newp)                                 # panel already staged by the previous record of the piece
-    rec = torch.stack([rec_panel, torch.from_numpy(same.astype(np.int64)).to(dev), rec_cnt, rec_layer], 1).to(torch.int32)
+    # records that start a run carry the panel of the piece's next run (the kernel copies it one run ahead)
+    starts = np.nonzero(~same)[0]
+    piece_of = np.cumsum(newp) - 1
+    nxt = np.full(nrec, -1, dtype=np.int64)
+    if len(starts) > 1:
+        follows = piece_of[starts[1:]] == piece_of[starts[:-1]]
+        nxt[starts[:-1][follows]] = rpn[starts[1:][follows]]
+    rec = torch.stack([rec_panel, torch.from_numpy(same.astype(np.int64)).to(dev), torch.from_numpy(nxt).to(dev), rec_layer], 1).to(torch.int32)
     strip = HostStrip(nrows, ncols, torch.from_numpy(work).to(dev), rec.contiguous(),
-                      pairs.view(nrec, STRIP_REC, 2).contiguous(), rec_row.to(torch.int32), int(in_s.sum()))
+                      pairs.view(nrec, STRIP_REC, 2).contiguous(), rec_row.to(torch.int32), rec_cnt.to(torch.int32),
+                      int(in_s.sum()))
     keep = torch.ones(r64.numel(), dtype=torch.bool, device=dev)
     keep[order[in_s]] = False
     return keep, strip

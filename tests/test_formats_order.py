@@ -108,17 +108,26 @@ def test_strip_layout_round_trip(min_entries, layer_min):
     k_got = torch.sort(torch.cat([rr * n + cc, (r * n + c)[keep]]))
     assert torch.equal(k_all.values, k_got.values)
     assert torch.equal(torch.cat([vv, val[keep]])[k_got.indices], val[k_all.indices])
-    assert st.nnz == int((~keep).sum()) == int(st.rec[:, 2].sum())
+    assert st.nnz == int((~keep).sum()) == int(st.rec_nnz.sum())
     off = st.pairs[:, :, 0]
     assert bool(((off == partition.STRIP_PAD_OFF) | ((off % 512 == 0) & (off >= 0) & (off < 128 * 512))).all())
     assert bool((st.pairs[:, :, 1][off == partition.STRIP_PAD_OFF] == 0).all())
-    assert bool((st.rec[:, 2] >= layer_min).all())
+    assert bool((st.rec_nnz >= layer_min).all())
     assert bool((st.rec[st.work[:, 1].long(), 1] == 0).all())
     # layers of a tile are consecutive records 0, 1, 2, ... with non-increasing counts
     tile = st.rec_tile_row.long() * (1 << 20) + st.rec[:, 0].long()
     same = tile[1:] == tile[:-1]
     assert bool((st.rec[1:, 3][same] == st.rec[:-1, 3][same] + 1).all())
-    assert bool((st.rec[1:, 2][same] <= st.rec[:-1, 2][same]).all())
+    assert bool((st.rec_nnz[1:][same] <= st.rec_nnz[:-1][same]).all())
+    # a record that starts a run of one panel names the panel of its piece's next run (-1: none), the others -1
+    rec, work = st.rec.long(), st.work.long()
+    for p in range(work.shape[0]):
+        ks = list(range(int(work[p, 1]), int(work[p, 2])))
+        starts = [k for k in ks if int(rec[k, 1]) == 0]
+        for i, k in enumerate(starts):
+            want = int(rec[starts[i + 1], 0]) if i + 1 < len(starts) else -1
+            assert int(rec[k, 2]) == want
+        assert all(int(rec[k, 2]) == -1 for k in ks if int(rec[k, 1]) == 1)
     # pieces tile the record list
     w = st.work[torch.argsort(st.work[:, 1])]
     assert int(w[0, 1]) == 0 and int(w[-1, 2]) == st.rec.shape[0] and bool((w[1:, 1] == w[:-1, 2]).all())

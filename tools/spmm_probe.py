@@ -86,8 +86,12 @@ def main():
     for name in names:
         # name: s<slices>[g<groups>]c<chunk>[x][k[tau]] (g = column groups; x = xcd swizzle for
         # unsliced; k = degree sort + LDS core)
-        fused = name.endswith("F")
         name0 = name
+        fpass = 0                        # _p64 / _p32: feature passes of the gather part
+        if "_p" in name:
+            name, fp = name.split("_p")
+            fpass = {"64": 16, "32": 32}[fp]
+        fused = name.endswith("F")
         name = name.rstrip("F")
         smode = ""                       # "r:" range slicing (uniform bounds), "d:" dealt order + range slicing
         if ":" in name:
@@ -126,13 +130,16 @@ def main():
         if d is None:
             d = prepared[smode + name] = K.prepare(h)
         for tag, L in libs.items():
-            variants[name0 + ("@" + tag if tag else "")] = (d, sw, L, fused)
+            variants[name0 + ("@" + tag if tag else "")] = (d, sw, L, fused, fpass)
     alg = 8 * nnz + 8 * (n + 1) + 2 * 4 * f * n
     C = torch.empty(n, f, device=dev)
 
     def run(name):
-        d, sw, L, K.fused = variants[name]
-        K.base_flags = 2 if sw else 0
+        d, sw, L, K.fused, fpass = variants[name]
+        K.base_flags = (2 if sw else 0) | fpass
+        if getattr(d, "_fpass", 0) != fpass:
+            d.launch_cache.clear()
+            d._fpass = fpass
         K.lib = L
         K.spmm(d, B, C)
 
@@ -160,15 +167,15 @@ def main():
     split = {}
     if args.split:
         for name in variants:
-            d, sw, L, fz = variants[name]
+            d, sw, L, fz, fp = variants[name]
             tl = TimingLib(L)
-            variants[name] = (d, sw, tl, fz)
+            variants[name] = (d, sw, tl, fz, fp)
             d.launch_cache.clear()
             for _ in range(5):
                 run(name)
             torch.cuda.synchronize()
             split[name] = tl.summary()
-            variants[name] = (d, sw, L, fz)
+            variants[name] = (d, sw, L, fz, fp)
             d.launch_cache.clear()
     out = {}
     for name, ts in times.items():
