@@ -98,7 +98,7 @@ CORE_MIN_NNZ = int(os.environ.get("PGCN_CORE_MIN_NNZ", "262144"))  # smaller cor
 CORE_MIN_FRAC = float(os.environ.get("PGCN_CORE_MIN_FRAC", "0.1"))
 DEGREE_SORT = os.environ.get("PGCN_DEGREE_SORT", "1") != "0"
 DENSE_ON = os.environ.get("PGCN_DENSE", "1") != "0"
-DENSE_TAU = float(os.environ.get("PGCN_DENSE_TAU", "0.20"))       # tiles at least this full go to the matrix cores
+DENSE_TAU = float(os.environ.get("PGCN_DENSE_TAU", "0.30"))       # tiles at least this full go to the matrix cores (0.20 before the r02 strips)
 DENSE_PIECE = int(os.environ.get("PGCN_DENSE_PIECE", "0"))        # tiles per work piece (one 128-row partial block each);
                                                                   # 0 = adaptive: ~1024 pieces, between 1 and 16 tiles
 
