@@ -481,7 +481,9 @@ def main():
                     traffic_note = "PMC record is stale (kernel sources changed since it was taken): dropped"
             except Exception:
                 traffic = None
-        kname = "A_loc.H forward SpMM = spmm_tasks_kernel<32,4,1,1> (gather part)"
+        fpass = os.environ.get("PGCN_FPASS", "64")
+        kname = "A_loc.H forward SpMM = spmm_tasks_kernel<%s,4,1,1> (gather part%s)" % (
+            {"64": "16", "32": "8"}.get(fpass, "32") if f > 64 else "16", {"64": ", 64 features per pass", "32": ", 32 features per pass"}.get(fpass, "") if f > 64 else "")
         if getattr(eng.A_loc, "strip", None) is not None:
             kname += " + spmm_strip_kernel (512x128 strip tiles, async LDS pipeline, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.strip.nnz / max(eng.A_loc.nnz, 1))

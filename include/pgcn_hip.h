@@ -45,6 +45,8 @@ typedef void *pgcn_stream_t; /* hipStream_t */
                                     combines them with pgcn_spmm_fixup_f32                  */
 #define PGCN_SPMM_FPASS64 16u   /* gather kernels: 64 features per pass (grid y = passes, pass-major order) */
 #define PGCN_SPMM_FPASS32 32u   /* gather kernels: 32 features per pass                                     */
+#define PGCN_SPMM_PERSIST 64u   /* gather kernels: a fixed population of 2 workgroups per CU walks the task list (leaves
+                                   room on every CU for the strip kernel launched next to it on another stream)  */
 #define PGCN_MAX_SLICES 8        /* = XCDs of an MI355X */
 #define PGCN_MAX_COL_GROUPS 64   /* column groups per slice (time slicing of the column space) */
 #define PGCN_CORE_TR 128         /* rows per tile of the LDS-tiled core kernel    */
@@ -207,6 +209,15 @@ int pgcn_spmm_heads_f32(const int64_t *rowptr, const int32_t *col, const float *
  * pgcn_spmm_fixup_f32.  All three arrays 16-byte aligned.  f % 4 == 0 with 16-byte aligned B /
  * partial_ws takes the LDS pipeline (128 features per workgroup); anything else a plain kernel. */
 int pgcn_spmm_strip_f32(const int32_t *work, int64_t nwork, const int32_t *recs, const int32_t *pairs,
+                        const float *B, int64_t ldb, int64_t ncols, int32_t f, float *partial_ws,
+                        int64_t partial_ws_elems, int64_t nslots_total, pgcn_stream_t stream);
+
+/* The same product on the same records in half the footprint (512 threads, 64 features per workgroup, 81 KB of
+ * LDS, 2 waves per SIMD): one such workgroup and three workgroups of the gather kernel (pgcn_spmm_csr_plan_f32)
+ * are resident on a CU together, so the LDS-bound strips and the latency-bound gather part overlap when the two
+ * are launched on two streams.  Bit-identical to pgcn_spmm_strip_f32.  Needs f % 4 == 0 and 16-byte aligned
+ * B / partial_ws (PGCN_EUNSUPPORTED otherwise: use pgcn_spmm_strip_f32).                                       */
+int pgcn_spmm_strip_half_f32(const int32_t *work, int64_t nwork, const int32_t *recs, const int32_t *pairs,
                         const float *B, int64_t ldb, int64_t ncols, int32_t f, float *partial_ws,
                         int64_t partial_ws_elems, int64_t nslots_total, pgcn_stream_t stream);
 

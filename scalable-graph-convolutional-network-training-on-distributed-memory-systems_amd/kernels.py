@@ -197,7 +197,7 @@ class HipKernels:
             xcd_swizzle = os.environ.get("PGCN_XCD_SWIZZLE", "1") != "0"
         self.base_flags = _lib.SPMM_XCD_SWIZZLE if xcd_swizzle else 0
         # feature passes of the gather kernels (64 / 32 features per pass; 0 = whole rows)
-        self.base_flags |= {"64": _lib.SPMM_FPASS64, "32": _lib.SPMM_FPASS32}.get(os.environ.get("PGCN_FPASS", "0"), 0)
+        self.base_flags |= {"64": _lib.SPMM_FPASS64, "32": _lib.SPMM_FPASS32}.get(os.environ.get("PGCN_FPASS", "64"), 0)
         self.chunk = chunk
         self.small_row = small_row
         # the LDS-tiled core kernel (LDS-bound) and the gather kernel (L1/L2-bound) use different
@@ -383,6 +383,8 @@ class HipKernels:
         fixp, nfa, slots = A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr()
         gflags, fflags = flags | _lib.SPMM_NO_FIXUP, flags & _lib.SPMM_ACCUMULATE
         overlap = self.core_overlap and ntasks
+        if (overlap and st is not None) or os.environ.get("PGCN_GATHER_PERSIST", "0") != "0":
+            gflags |= _lib.SPMM_PERSIST        # a fixed 2 gather workgroups per CU: the strip workgroup fits next to them
         if (self.fused and A.fused_work is not None and co is not None and f <= 128 and f % 4 == 0 and ldb % 4 == 0 and ldc % 4 == 0
                 and B.data_ptr() % 16 == 0 and C.data_ptr() % 16 == 0):
             fw, nfw = A.fused_work.data_ptr(), A.fused_work.shape[0]
@@ -402,10 +404,14 @@ class HipKernels:
 
         side_first = os.environ.get("PGCN_CORE_OVERLAP", "0") == "2"
 
+        # overlapped with the gather kernel the strips run in their half-footprint shape (one workgroup per CU next
+        # to three gather workgroups); alone, the 1024-thread kernel is faster
+        half_ok = f % 4 == 0 and ldb % 4 == 0 and B.data_ptr() % 16 == 0 and ldb < (1 << 24)
+        strip_fn = lib.pgcn_spmm_strip_half_f32 if ((overlap or os.environ.get("PGCN_STRIP_HALF", "0") != "0") and half_ok) else lib.pgcn_spmm_strip_f32
+
         def tiled(b, cs):
             if st is not None:
-                check(lib.pgcn_spmm_strip_f32(sw, sn, srec, spairs, b, ldb, ncols, f, ws, ws_n, nst, cs),
-                      "pgcn_spmm_strip_f32")
+                check(strip_fn(sw, sn, srec, spairs, b, ldb, ncols, f, ws, ws_n, nst, cs), "pgcn_spmm_strip_f32")
             if de is not None:
                 check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, cs),
                       "pgcn_spmm_dense_f32")
@@ -418,7 +424,7 @@ class HipKernels:
             cs = s
             if overlap:
                 if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device)
+                    self._side = torch.cuda.Stream(device=self.device, priority=-1 if os.environ.get("PGCN_SIDE_PRIO", "0") != "0" else 0)
                 main = torch.cuda.current_stream(self.device)
                 ev = torch.cuda.Event()
                 ev.record(main)

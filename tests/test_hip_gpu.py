@@ -250,6 +250,7 @@ def test_spmm_strip_tiles(K, dev, f, nslices):
     D[512:1024, 256:640] = rng.random((512, 384)) < 0.03             # three panels of the second tile row
     D[1024:1152, :128] = rng.random((128, 128)) < 0.5                # MFMA tile inside the third (ragged) tile row
     D[1152:, 384:512] = rng.random((148, 128)) < 0.2                 # ragged last tile row (rows 1024..1299)
+    D[:512, 640:] = rng.random((512, 60)) < 0.05                     # last, partial column block: the windowed panel [572, 700)
     D[7, :] = 0                                                      # an empty row inside strip tiles
     D[:, 300] = 0                                                    # a column nobody references
     D *= rng.standard_normal((n, m)).astype(np.float32)
@@ -295,6 +296,51 @@ def test_spmm_strip_tiles(K, dev, f, nslices):
     assert hit.sum() > 40
     assert np.isinf(got[hit, 0]).all() and np.isfinite(got[~hit]).all() and np.isfinite(got[:, 1:]).all()
     assert rel_err(got[:, 1:], ref[:, 1:]) < TOL
+
+
+def test_spmm_variants_bit_identical(K, dev):
+    """The opt-in shapes of the launch group leave the SAME bits as the default one: the gather kernel in 64- / 32-
+    feature passes and as a persistent grid (PGCN_SPMM_FPASS64 / FPASS32 / PERSIST), and the half-footprint strip
+    kernel (pgcn_spmm_strip_half_f32) on a second stream next to it (PGCN_CORE_OVERLAP)."""
+    partition, _lib = pkg("partition"), pkg("_lib")
+    rng = np.random.default_rng(77)
+    n, m, f = 2100, 1500, 128
+    D = (rng.random((n, m)) < 0.004).astype(np.float32)
+    D[:1024, :256] = rng.random((1024, 256)) < 0.05                  # strip tiles of several layers, two tile rows
+    D[1024:1536, 1408:] = rng.random((512, 92)) < 0.06               # ... one of them in the last, partial column block
+    D[:128, 256:384] = rng.random((128, 128)) < 0.6                  # an MFMA tile
+    D[40, :] = rng.random(m) < 0.7                                   # a hub row: several gather tasks per slice
+    D *= rng.standard_normal((n, m)).astype(np.float32)
+    A = sp.csr_matrix(D)
+    h = partition.csr_from_scipy(A, nslices=8, core=True, dense_tau=0.3, strip=True, strip_min=64)
+    assert h.strip is not None and h.dense is not None and h.col.numel() > 0
+    d = K.prepare(h)
+    Bd = torch.from_numpy(rng.random((m, f), dtype=np.float32) * 2 - 1).to(dev)
+    flags0, ov0 = K.base_flags, K.core_overlap
+    try:
+        K.base_flags = flags0 & ~(_lib.SPMM_FPASS64 | _lib.SPMM_FPASS32 | _lib.SPMM_PERSIST)
+        d.launch_cache.clear()
+        ref = torch.full((n, f), float("nan"), device=dev)
+        K.spmm(d, Bd, ref)
+        assert rel_err(ref.cpu().numpy(), oracle.spmm(A, Bd.cpu().numpy())) < TOL
+        for extra, overlap in ((_lib.SPMM_FPASS64, False), (_lib.SPMM_FPASS32, False), (_lib.SPMM_PERSIST, False),
+                               (_lib.SPMM_FPASS64 | _lib.SPMM_PERSIST, False), (0, True), (_lib.SPMM_FPASS64, True)):
+            K.base_flags = (flags0 & ~(_lib.SPMM_FPASS64 | _lib.SPMM_FPASS32 | _lib.SPMM_PERSIST)) | extra
+            K.core_overlap = overlap
+            d.launch_cache.clear()
+            C = torch.full((n, f), float("nan"), device=dev)
+            K.spmm(d, Bd, C)
+            torch.cuda.synchronize()
+            assert torch.equal(C, ref), (extra, overlap)
+    finally:
+        K.base_flags, K.core_overlap = flags0, ov0
+        d.launch_cache.clear()
+    # the half-footprint kernel refuses what it cannot stage (the caller then uses pgcn_spmm_strip_f32)
+    st = d.strip
+    ws = torch.empty(d.nslots_total * 6, device=dev)
+    rc = K.lib.pgcn_spmm_strip_half_f32(st.work.data_ptr(), st.npieces, st.rec.data_ptr(), st.pairs.data_ptr(), Bd.data_ptr(), f,
+                                        m, 6, ws.data_ptr(), ws.numel(), d.nslots_total, None)
+    assert rc == _lib.PGCN_EUNSUPPORTED
 
 
 def test_spmm_strip_pieces_and_panel_reuse(K, dev):

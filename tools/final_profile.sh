@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- py
 rm -f $out/prof/*kernel_trace.csv $out/prof/*/*kernel_trace.csv
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   t=$(echo "$set" | tr ' ' '+')
-  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm" --output-format csv -d $out/pmc/$t -- python tools/spmm_probe.py --once s8c1024k > $out/pmc_$t.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm" --output-format csv -d $out/pmc/$t -- python tools/spmm_probe.py --once s8c1024k_p64 > $out/pmc_$t.log 2>&1
 done
 python tools/pmc_summary.py $out/pmc spmm > $out/pmc_summary.txt; grep -v kernel_trace $out/pmc_summary.txt | head -40
 python tools/make_pmc_traffic.py $out/pmc_summary.txt $out/pmc_traffic.json profiles/${tag}_pmc_final.txt

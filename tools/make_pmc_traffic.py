@@ -41,7 +41,7 @@ def main():
            "hbm_bytes_per_launch": int(read + write), "read_bytes": int(read), "write_bytes": int(write),
            "per_kernel": per,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes with --kernel-trace "
-                   "only (tools/final_profile.sh), mean over the dispatches of `tools/spmm_probe.py --once s8c1024k` (same plan "
+                   "only (tools/final_profile.sh), mean over the dispatches of `tools/spmm_probe.py --once s8c1024k_p64` (same plan and flags "
                    "as bench.py).  FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B fabric reads at 64 B). "
                    "These are L2<->fabric bytes: Infinity-Cache (MALL) hits are included, so true HBM traffic is <= this figure.",
            "source": sys.argv[3] if len(sys.argv) > 3 else sys.argv[1]}

@@ -12,6 +12,10 @@
 #include <vector>
 #include <random>
 
+#ifdef WITH_NEXT
+extern "C" int pgcn_spmm_strip3_f32(const int32_t *, int64_t, const int32_t *, const int32_t *, const float *, int64_t, int64_t,
+                                    int32_t, float *, int64_t, int64_t, void *);
+#endif
 extern "C" int pgcn_spmm_strip_f32(const int32_t *, int64_t, const int32_t *, const int32_t *, const float *, int64_t, int64_t,
                                     int32_t, float *, int64_t, int64_t, void *);
 extern "C" const char *pgcn_last_error(void);
@@ -25,7 +29,7 @@ int main(int argc, char **argv) {
     const double fill = 0.72;
     std::mt19937 rng(7);
     std::vector<int32_t> work, recs;
-    std::vector<int32_t> pairs_new;
+    std::vector<int32_t> pairs_new, pairs_next;
     int64_t nrec = 0;
     const int npanels = (int)(n / 128);   // full panels only (v2 windows the last partial panel differently from v1)
     for (int p = 0; p < npieces; ++p) {
@@ -46,7 +50,7 @@ int main(int argc, char **argv) {
         }
         nrec += R;
     }
-    pairs_new.resize((size_t)nrec * 2048);
+    pairs_new.resize((size_t)nrec * 2048); pairs_next.resize((size_t)nrec * 2048);
     for (int64_t r = 0; r < nrec; ++r) {
         const int panel = recs[r * 4];
         const int rows_in_panel = (int)std::min<int64_t>(getenv("STRIP_BENCH_ROWS") ? atoi(getenv("STRIP_BENCH_ROWS")) : 128, n - (int64_t)panel * 128);
@@ -57,17 +61,28 @@ int main(int argc, char **argv) {
                 int32_t vb; memcpy(&vb, &v, 4);
                 const size_t in = (size_t)r * 2048 + (((row % 64) * 8 + row / 64) * 2 + u) * 2;
                 pairs_new[in] = off; pairs_new[in + 1] = vb;
+                // next-generation format: 256-byte rows, unused slot = {0, -0.0f}
+                pairs_next[in] = off == PADOFF ? 0 : off / 2; pairs_next[in + 1] = off == PADOFF ? (int32_t)0x80000000 : vb;
             }
     }
+    // ... and the header of record k + 1 in the low bytes of the four offsets of every group's row slots 0 and 1
+    for (int p = 0; p < npieces; ++p)
+        for (int64_t k = work[p * 4 + 1]; k < work[p * 4 + 2]; ++k) {
+            uint32_t hu = 0;
+            if (k + 1 < work[p * 4 + 2]) hu = (uint32_t)recs[(k + 1) * 4 + 1] | ((uint32_t)(recs[(k + 1) * 4 + 2] + 1) << 1);
+            for (int g = 0; g < 64; ++g)
+                for (int b = 0; b < 4; ++b) pairs_next[(size_t)k * 2048 + ((g * 8 + b / 2) * 2 + b % 2) * 2] |= (int32_t)((hu >> (8 * b)) & 255u);
+        }
     std::vector<float> hB((size_t)n * f);
     for (auto &x : hB) x = (float)(rng() % 2001) / 1000.f - 1.f;
-    int32_t *dwork, *drecs, *dpn; float *dB, *dws_n;
+    int32_t *dwork, *drecs, *dpn, *dpx; float *dB, *dws_n, *dws_x;
     const int64_t nslots = (int64_t)npieces * 512;
     CHECK(hipMalloc(&dwork, work.size() * 4)); CHECK(hipMemcpy(dwork, work.data(), work.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&drecs, recs.size() * 4)); CHECK(hipMemcpy(drecs, recs.data(), recs.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&dpn, pairs_new.size() * 4)); CHECK(hipMemcpy(dpn, pairs_new.data(), pairs_new.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&dB, hB.size() * 4)); CHECK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
-    CHECK(hipMalloc(&dws_n, nslots * f * 4));
+    CHECK(hipMalloc(&dws_n, nslots * f * 4)); CHECK(hipMalloc(&dws_x, nslots * f * 4)); CHECK(hipMemset(dws_x, 0xdd, nslots * f * 4));
+    CHECK(hipMalloc(&dpx, pairs_next.size() * 4)); CHECK(hipMemcpy(dpx, pairs_next.data(), pairs_next.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemset(dws_n, 0xee, nslots * f * 4));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     auto timeit = [&](const char *name, int which) {
@@ -75,7 +90,12 @@ int main(int argc, char **argv) {
         const int reps = 6;
         for (int it = 0; it < reps + 1; ++it) {
             CHECK(hipEventRecord(e0));
-            int rc = pgcn_spmm_strip_f32(dwork, npieces, drecs, dpn, dB, f, n, f, dws_n, nslots * f, nslots, nullptr);
+            int rc;
+#ifdef WITH_NEXT
+            if (which == 2) rc = pgcn_spmm_strip3_f32(dwork, npieces, drecs, dpx, dB, f, n, f, dws_x, nslots * f, nslots, nullptr);
+            else
+#endif
+            rc = pgcn_spmm_strip_f32(dwork, npieces, drecs, dpn, dB, f, n, f, dws_n, nslots * f, nslots, nullptr);
             if (rc) { printf("%s failed: %s\n", name, pgcn_last_error()); exit(1); }
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -86,6 +106,19 @@ int main(int argc, char **argv) {
                (long long)nrec, sum / reps, best, clk);
     };
     timeit("strip", 1);
+#ifdef WITH_NEXT
+    timeit("strip next", 2);
+    if (!(getenv("PGCN_STRIP_PROBE") && atoi(getenv("PGCN_STRIP_PROBE")))) {
+        std::vector<float> ha((size_t)nslots * f), hb((size_t)nslots * f);
+        CHECK(hipMemcpy(ha.data(), dws_n, ha.size() * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(hb.data(), dws_x, hb.size() * 4, hipMemcpyDeviceToHost));
+        size_t nd = 0;
+        for (size_t i = 0; i < ha.size(); ++i)
+            if (memcmp(&ha[i], &hb[i], 4)) { if (nd < 5) printf("  mismatch at slot %zu col %zu: %g vs %g\n", i / f, i % f, ha[i], hb[i]); ++nd; }
+        printf("current vs next: %zu differing values of %zu\n", nd, ha.size());
+    }
+    CHECK(hipMemcpy(dws_n, dws_x, (size_t)nslots * f * 4, hipMemcpyDeviceToDevice));   // the checks below look at the next kernel
+#endif
     std::vector<float> hn((size_t)nslots * f);
     CHECK(hipMemcpy(hn.data(), dws_n, hn.size() * 4, hipMemcpyDeviceToHost));
     if (getenv("PGCN_STRIP_PROBE") && (atoi(getenv("PGCN_STRIP_PROBE")) & 4)) {
