@@ -481,7 +481,9 @@ def main():
                     traffic_note = "PMC record is stale (kernel sources changed since it was taken): dropped"
             except Exception:
                 traffic = None
-        fpass = os.environ.get("PGCN_FPASS", "64")
+        fpass = os.environ.get("PGCN_FPASS", "auto")
+        if fpass == "auto":
+            fpass = "64" if (f > 64 and eng.A_loc.ncols * f * 4 >= (96 << 20) and eng.A_loc.col.numel() >= 8_000_000) else "0"
         kname = "A_loc.H forward SpMM = spmm_tasks_kernel<%s,4,1,1> (gather part%s)" % (
             {"64": "16", "32": "8"}.get(fpass, "32") if f > 64 else "16", {"64": ", 64 features per pass", "32": ", 32 features per pass"}.get(fpass, "") if f > 64 else "")
         if getattr(eng.A_loc, "strip", None) is not None:

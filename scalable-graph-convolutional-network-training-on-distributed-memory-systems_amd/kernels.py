@@ -196,8 +196,11 @@ class HipKernels:
         if xcd_swizzle is None:
             xcd_swizzle = os.environ.get("PGCN_XCD_SWIZZLE", "1") != "0"
         self.base_flags = _lib.SPMM_XCD_SWIZZLE if xcd_swizzle else 0
-        # feature passes of the gather kernels (64 / 32 features per pass; 0 = whole rows)
-        self.base_flags |= {"64": _lib.SPMM_FPASS64, "32": _lib.SPMM_FPASS32}.get(os.environ.get("PGCN_FPASS", "64"), 0)
+        # feature passes of the gather kernels (PGCN_FPASS = 64 / 32 features per pass, 0 = whole rows; default "auto":
+        # 64 where the operand panel (>= 96 MB) is several times the aggregate L2 and the gather part holds >= 8 M
+        # entries -- whole graphs; a rank's shard of an 8-way run loses 15 % with them: tools/rank_probe.py, r02)
+        self.fpass = os.environ.get("PGCN_FPASS", "auto")
+        self.base_flags |= {"64": _lib.SPMM_FPASS64, "32": _lib.SPMM_FPASS32}.get(self.fpass, 0)
         self.chunk = chunk
         self.small_row = small_row
         # the LDS-tiled core kernel (LDS-bound) and the gather kernel (L1/L2-bound) use different
@@ -334,6 +337,8 @@ class HipKernels:
             raise _lib.PgcnError("B and C widths differ")
         ldb, ldc = B.stride(0), C.stride(0)
         flags = self.base_flags | (_lib.SPMM_ACCUMULATE if accumulate else 0)
+        if self.fpass == "auto" and f > 64 and A.ncols * f * 4 >= (96 << 20) and A.col.numel() >= 8_000_000:
+            flags |= _lib.SPMM_FPASS64
         if (A.ncols + 1) * ldb * 4 < 2 ** 32:
             flags |= _lib.SPMM_OFFSETS32
         lib, check, stream = self.lib, _lib.check, self._stream

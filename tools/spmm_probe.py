@@ -75,6 +75,7 @@ def main():
     gen = torch.Generator(device=dev); gen.manual_seed(1)
     B = torch.rand(n, f, device=dev, generator=gen) * 2 - 1
     K = kernels.HipKernels(dev)
+    K.fpass = "manual"               # feature passes only where a variant name asks for them (_p64 / _p32)
     variants = {}
     names = [args.once] if args.once else args.variants.split(",")
     _lib = pkg("_lib")
