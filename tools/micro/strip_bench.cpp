@@ -12,6 +12,8 @@
 #include <vector>
 #include <random>
 
+extern "C" int pgcn_spmm_strip_half_f32(const int32_t *, int64_t, const int32_t *, const int32_t *, const float *, int64_t, int64_t,
+                                        int32_t, float *, int64_t, int64_t, void *);
 #ifdef WITH_NEXT
 extern "C" int pgcn_spmm_strip3_f32(const int32_t *, int64_t, const int32_t *, const int32_t *, const float *, int64_t, int64_t,
                                     int32_t, float *, int64_t, int64_t, void *);
@@ -44,9 +46,13 @@ int main(int argc, char **argv) {
             for (int i = 0; i < len && k < R; ++i, ++k) { panel[k] = pn; flag[k] = i > 0; }
         }
         for (k = 0; k < R; ++k) {
-            int nextp = -1;
-            if (!flag[k]) { int q = k + 1; while (q < R && flag[q]) ++q; if (q < R) nextp = panel[q]; }
-            recs.insert(recs.end(), {panel[k], flag[k], nextp, 0});
+            int nextp = -1, next2 = -1;   // panels of the piece's next run and of the one after it (the latter only read by the
+                                          // three-buffer experiment of the half-footprint kernel, profiles/r02_strip_bench.txt)
+            if (!flag[k]) {
+                int q = k + 1; while (q < R && flag[q]) ++q;
+                if (q < R) { nextp = panel[q]; ++q; while (q < R && flag[q]) ++q; if (q < R) next2 = panel[q]; }
+            }
+            recs.insert(recs.end(), {panel[k], flag[k], nextp, next2});
         }
         nrec += R;
     }
@@ -91,6 +97,8 @@ int main(int argc, char **argv) {
         for (int it = 0; it < reps + 1; ++it) {
             CHECK(hipEventRecord(e0));
             int rc;
+            if (which == 3) rc = pgcn_spmm_strip_half_f32(dwork, npieces, drecs, dpn, dB, f, n, f, dws_x, nslots * f, nslots, nullptr);
+            else
 #ifdef WITH_NEXT
             if (which == 2) rc = pgcn_spmm_strip3_f32(dwork, npieces, drecs, dpx, dB, f, n, f, dws_x, nslots * f, nslots, nullptr);
             else
@@ -106,6 +114,16 @@ int main(int argc, char **argv) {
                (long long)nrec, sum / reps, best, clk);
     };
     timeit("strip", 1);
+    timeit("strip half", 3);
+    if (!(getenv("PGCN_STRIP_PROBE") && atoi(getenv("PGCN_STRIP_PROBE")))) {
+        std::vector<float> ha((size_t)nslots * f), hb((size_t)nslots * f);
+        CHECK(hipMemcpy(ha.data(), dws_n, ha.size() * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(hb.data(), dws_x, hb.size() * 4, hipMemcpyDeviceToHost));
+        size_t nd = 0;
+        for (size_t i = 0; i < ha.size(); ++i)
+            if (memcmp(&ha[i], &hb[i], 4)) { if (nd < 5) printf("  mismatch at slot %zu col %zu: %g vs %g\n", i / f, i % f, ha[i], hb[i]); ++nd; }
+        printf("strip vs strip half: %zu differing values of %zu\n", nd, ha.size());
+    }
 #ifdef WITH_NEXT
     timeit("strip next", 2);
     if (!(getenv("PGCN_STRIP_PROBE") && atoi(getenv("PGCN_STRIP_PROBE")))) {
