@@ -1,0 +1,43 @@
+"""Offline tooling kept honest: the trace-driven L2 model (tools/l2sim) on a case small enough to count by hand, and
+the prepared-but-unmeasured kernel patch (tools/prototypes) still applying to the sources it was written against."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_l2sim_counts_by_hand(tmp_path):
+    so = str(tmp_path / "l2sim.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "l2sim", "l2sim.c")])
+    L = ctypes.CDLL(so)
+    L.l2sim_slice.restype = ctypes.c_int
+    L.l2sim_slice.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 2
+    col = np.array([5, 9, 5, 9, 5, 70], dtype=np.int32)            # two tasks of three entries each
+    tasks = np.array([[0, 3], [3, 3]], dtype=np.int64)
+
+    def run(window, passes, lpp, sets=64, ways=16):
+        h, m = ctypes.c_int64(), ctypes.c_int64()
+        assert L.l2sim_slice(tasks.ctypes.data, 2, col.ctypes.data, window, 8, passes, lpp, sets, ways, ctypes.byref(h), ctypes.byref(m)) == 0
+        return h.value, m.value
+
+    # whole rows = 4 lines each; distinct rows 5, 9, 70 -> 12 compulsory misses, the other 3 x 4 accesses hit
+    assert run(2, 1, 4) == (12, 12)
+    # two passes of 2 lines: the same lines in total, the same compulsory misses
+    assert run(2, 2, 2) == (12, 12)
+    # a cache of ONE line: only back-to-back repeats could hit, and there are none inside a row
+    assert run(1, 1, 4, sets=1, ways=1) == (0, 24)
+
+
+@pytest.mark.skipif(shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")), reason="needs the git checkout")
+def test_prototype_patch_still_applies():
+    patch = os.path.join(ROOT, "tools", "prototypes", "fpass_sequential_grid.patch")
+    target = "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd/csrc/pgcn_spmm.hip"
+    assert target in open(patch).read()
+    p = subprocess.run(["git", "apply", "--check", patch], cwd=ROOT, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
