@@ -35,9 +35,10 @@ def test_l2sim_counts_by_hand(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")), reason="needs the git checkout")
-def test_prototype_patch_still_applies():
-    patch = os.path.join(ROOT, "tools", "prototypes", "fpass_sequential_grid.patch")
-    target = "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd/csrc/pgcn_spmm.hip"
+@pytest.mark.parametrize("name,src", [("fpass_sequential_grid.patch", "pgcn_spmm.hip"), ("dense_b_prefetch.patch", "pgcn_spmm_dense.hip")])
+def test_prototype_patch_still_applies(name, src):
+    patch = os.path.join(ROOT, "tools", "prototypes", name)
+    target = "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd/csrc/" + src
     assert target in open(patch).read()
     p = subprocess.run(["git", "apply", "--check", patch], cwd=ROOT, capture_output=True)
     assert p.returncode == 0, p.stderr.decode()
