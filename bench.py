@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the GCN aggregation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, or self-launched)
 
-Workload (BASELINE.json configs[1]): Reddit-shaped graph (n = 232 965, 114 615 892
-directed edges + self loops, seeded R-MAT stand-in -- the dataset is not in the image),
-3-layer GCN, f = 128, random 1D partition over N GPUs.  One *step* = one training epoch
-of GPU/PGCN.py:212-220 (forward, loss, backward, gradient all-reduce, Adam) = 2.L
-aggregations A.H through the HIP engine.  Metric: edges aggregated per second
-= 2.L.nnz / t_epoch, whole job; ms_per_step = ms/epoch.
+Default workload (BASELINE.json configs[1]): Reddit-shaped graph (n = 232 965, 114 615 892 directed edges + self
+loops, seeded R-MAT stand-in -- the dataset is not in the image), 3-layer GCN, f = 128, random 1D partition over N
+GPUs.  One *step* = one training epoch of GPU/PGCN.py:212-220 (forward, loss, backward, gradient all-reduce, Adam)
+= 2.L aggregations A.H through the HIP engine.  Metric: edges aggregated per second = 2.L.nnz / t_epoch, whole job;
+ms_per_step = ms/epoch.
+
+Inputs (the other BASELINE configs, same JSON contract):
+  --workload products --generator sbm --partvec tests/golden/partvec/products-sbm.A.mtx.8.hp.gz   (config 3)
+  --shards PREFIX [--partvec FILE]      every rank reads ONLY PREFIX.<rank>.pgcsr (tools/make_shards.py): the
+                                        papers100M-scale path (config 4), no global matrix on any rank
+  --workload reddit-gat                 3 x PGAT, 4 heads x 64 (config 5)
+  --mtx A.mtx [--partvec FILE]          a real MatrixMarket file (also picked up automatically from
+                                        $PGCN_DATA_DIR/<workload>.mtx, default ./data/)
+  --emulate-rank r/P                    ONE GPU runs rank r of a P-rank job (exchange = no-op on resident slabs):
+                                        the shard shapes that 2/4/8 GPUs run, with a roofline object per launch group
 
 Extra objects in the JSON line:
-  roofline     dominant kernel = the local-block SpMM A_loc.H, which is one launch GROUP:
-               spmm_tasks_kernel (XCD-sliced gather part) + spmm_core_kernel (LDS-tiled dense
-               core) + the fix-up that adds their partial sums.  achieved = algorithmic bytes
-               (8.nnz + 8.(n_r+1) + 4.f.n_c + 4.f.n_r) / the group's average
-               duration, measured live with HIP events on the launch stream inside the timed
+  roofline     dominant kernel = the local-block SpMM A_loc.H, ONE launch group: spmm_tasks_kernel (XCD-sliced
+               gather part) + spmm_strip_kernel (512 x 128 LDS-staged strip tiles) + spmm_dense_kernel (fp32-MFMA
+               tiles) (+ spmm_core_kernel, the 128 x 128 LDS core, on small blocks) + the fix-up that adds their
+               partial sums.  achieved = algorithmic bytes (8.nnz + 8.(n_r+1) + 4.f.n_c + 4.f.n_r) / the
+               group's average duration, measured live with HIP events on the launch stream inside the timed
                region; peak 8 TB/s.  `traffic` comes from separate rocprofv3 --pmc passes
-               (profiles/pmc_traffic.json, summed over the group) when present, else null.
-  cpu_baseline the CPU oracle (GraphBLAS-free restatement of Parallel-GCN's SpMM, OpenMP)
+               (profiles/pmc_traffic.json, keyed by workload / generator / ranks, stamped with the kernel sources)
+               when present, else null.
+  cpu_baseline the CPU oracle (GraphBLAS-free restatement of Parallel-GCN's SpMM and training loop, OpenMP)
                timed on this host on a bounded sample: rank 0, N = 1 only.
 """
 import argparse
@@ -184,6 +194,153 @@ def cpu_baseline(part, f, budget_s=20.0):
     return out
 
 
+class NoExchange:
+    """--emulate-rank: the exchange of an N-rank job replaced by a no-op on slabs that already hold rows (one GPU
+    measures the COMPUTE side of rank r; nothing is sent)."""
+    name = "none (emulated rank)"
+
+    def alltoallv(self, *a):
+        pass
+
+    def allreduce_sum(self, buf):
+        pass
+
+    def close(self):
+        pass
+
+
+def real_mtx_for(workload):
+    """A real dataset dropped next to the benchmark is used instead of the synthetic stand-in:
+    $PGCN_DATA_DIR/<workload>.mtx (default ./data/), written e.g. by the reference's preprocess/GrB-GNN-IDG.py."""
+    d = os.environ.get("PGCN_DATA_DIR", os.path.join(ROOT, "data"))
+    for name in (workload + ".mtx", workload + ".A.mtx"):
+        path = os.path.join(d, name)
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def read_partvec_arg(args, n, parts, synth, partition):
+    """(part vector tensor, description) for `parts` ranks from --partvec (random | block | FILE)."""
+    if parts == 1:
+        return torch.zeros(n, dtype=torch.int64), "none"
+    if args.partvec == "random":
+        return synth.random_partvec(n, parts, seed=0), "random (seeded, GCN-HP/main.cpp:133-142)"
+    if args.partvec == "block":
+        return synth.block_partvec(n, parts), "contiguous blocks"
+    pv = partition.read_partvec(args.partvec)
+    if len(pv) != n or max(pv) >= parts or min(pv) < 0:
+        sys.exit("part vector %s: %d entries / parts 0..%d, graph has %d vertices on %d ranks"
+                 % (args.partvec, len(pv), max(pv), n, parts))
+    return torch.tensor(pv, dtype=torch.int64), "file:" + os.path.basename(args.partvec)
+
+
+def acquire_partition(args, rank, world, dev, stage, with_transpose=True):
+    """Rank `rank`'s Partition from one of the three input kinds.  Returns (part, info): info = {n, nnz,
+    partition, source, data}.  With --emulate-rank r/P (world == 1) the partition of rank r of P is built."""
+    synth, partition, ingest = pkg("synth"), pkg("partition"), pkg("ingest")
+    prank, parts = rank, world
+    if args.emulate_rank:
+        if world != 1:
+            sys.exit("--emulate-rank runs on one GPU (--gpus 1)")
+        prank, parts = [int(x) for x in args.emulate_rank.split("/")]
+        if not 0 <= prank < parts:
+            sys.exit("--emulate-rank r/P needs 0 <= r < P")
+    mtx = args.mtx or (None if args.shards else real_mtx_for(args.workload.replace("-gat", "")))
+    if args.shards:
+        # ---- binary CSR shards: this rank reads ONLY its own rows (papers100M-scale path) ---------------
+        path = ingest.shard_path(args.shards, prank)
+        sh = ingest.read_shard(path)
+        n = int(sh["n"])
+        if args.partvec in ("random", "block"):
+            cand = "%s.%d.bp" % (args.shards, parts)          # tools/make_shards.py writes the block vector it used
+            if not os.path.exists(cand):
+                sys.exit("--shards needs the part vector the shards were cut with (--partvec FILE or %s)" % cand)
+            args.partvec = cand
+        partvec, pname = read_partvec_arg(args, n, parts, synth, partition)
+        if sh["nparts"] != parts or sh["rank"] != prank:
+            sys.exit("%s was written for rank %d of %d, this is rank %d of %d" % (path, sh["rank"], sh["nparts"], prank, parts))
+        if not np.array_equal(sh["rows"], np.nonzero(partvec.numpy() == prank)[0]):
+            sys.exit("%s does not hold the rows the part vector gives rank %d" % (path, prank))
+        r_, c_, v_ = ingest.shard_coo(sh)
+        row, col, val = torch.from_numpy(r_).to(dev), torch.from_numpy(c_).to(dev), torch.from_numpy(v_).to(dev)
+        del sh, r_, c_, v_
+        stage("shard read")
+        if world > 1:
+            part = partition.build_partition_local(row, col, val, n, partvec, prank, parts, with_transpose=with_transpose)
+        elif parts > 1:
+            sys.exit("--emulate-rank with --shards needs the other ranks' degrees: use a synthetic workload or --mtx")
+        else:
+            part = partition.build_partition(row, col, val, n, partvec, 0, 1, with_transpose=with_transpose)
+        info = {"n": n, "nnz": int(part.nnz_global), "partition": pname, "data": "synthetic (shards)" if not args.real else "real",
+                "source": "binary CSR shards %s.<rank>.pgcsr (rank-local ingest, no global matrix)" % os.path.basename(args.shards)}
+        return part, info
+    if mtx:
+        # ---- a MatrixMarket file (real dataset when present) ---------------------------------------------
+        n = int(ingest.mtx_info(mtx)["nrows"])
+        partvec, pname = read_partvec_arg(args, n, parts, synth, partition)
+        if world > 1:
+            A = ingest.load_partition(mtx, partvec.numpy(), prank)       # this rank's rows only (C++ reader)
+        else:
+            A = ingest.mmread(mtx)
+        row, col = torch.from_numpy(A.row.astype(np.int64)).to(dev), torch.from_numpy(A.col.astype(np.int64)).to(dev)
+        val = torch.from_numpy(A.data.astype(np.float32)).to(dev)
+        del A
+        stage("mtx read")
+        if world > 1:
+            part = partition.build_partition_local(row, col, val, n, partvec, prank, parts, with_transpose=with_transpose)
+        else:
+            part = partition.build_partition(row, col, val, n, partvec, prank, parts, with_transpose=with_transpose)
+        info = {"n": n, "nnz": int(part.nnz_global), "partition": pname, "data": "file",
+                "source": "MatrixMarket file %s" % os.path.basename(mtx)}
+        return part, info
+    # ---- synthetic graph (same seed on every rank) ----------------------------------------------------------
+    base = args.workload.replace("-gat", "")
+    n, row, col, val = synth.make_graph(base, seed=0, device=dev, generator=args.generator)
+    nnz = int(row.numel())
+    partvec, pname = read_partvec_arg(args, n, parts, synth, partition)
+    if world > 1:   # all ranks must hold the same graph
+        chk = torch.stack([row.sum(), col.sum(), (val.double().sum() * 1e6).long()]).double()
+        lo, hi = chk.clone(), chk.clone()
+        P = pkg("PGCN")
+        P._all_reduce(lo, dist.ReduceOp.MIN)
+        P._all_reduce(hi, dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "ranks generated different graphs"
+    stage("graph ready")
+    part = partition.build_partition(row, col, val, n, partvec, prank, parts, with_transpose=with_transpose)
+    info = {"n": n, "nnz": nnz, "partition": pname, "data": "synthetic",
+            "source": "%s-like %s" % (base, "R-MAT" if args.generator == "rmat" else "planted-partition (SBM)")}
+    return part, info
+
+
+def pmc_traffic_for(args, world, f):
+    """(bytes or None, note): L2<->fabric bytes of the dominant launch group from the committed rocprofv3 --pmc
+    passes (profiles/pmc_traffic.json: one record per (workload, generator, ranks, f)), valid only for the kernel
+    sources they were taken on (sha256 stamp)."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(pmc):
+        return None, "no PMC record"
+    try:
+        with open(pmc) as fh:
+            doc = json.load(fh)
+    except Exception:
+        return None, "unreadable PMC record"
+    recs = doc["records"] if isinstance(doc, dict) and "records" in doc else [doc]
+    ranks = args.emulate_rank or str(world)
+    note = "no PMC record for this workload"
+    for rec in recs:
+        same = (rec.get("workload") == args.workload and str(rec.get("ranks", rec.get("n_gpus"))) == ranks
+                and rec.get("f") == f and rec.get("generator", "rmat") == args.generator
+                and rec.get("partvec", "random") == os.path.basename(args.partvec))
+        if not same:
+            continue
+        if rec.get("source_stamp") == kernel_source_stamp():
+            return rec.get("hbm_bytes_per_launch"), ("rocprofv3 --pmc passes of %s (profiles/pmc_traffic.json), same kernel sources"
+                                                     % rec.get("source", "?"))
+        note = "PMC record is stale (kernel sources changed since it was taken): dropped"
+    return None, note
+
+
 class GatKernelTimer:
     """HIP events around every launch of the dominant GAT kernel (the edge gradient: SDDMM + softmax backward)."""
 
@@ -218,17 +375,17 @@ def bench_gat(args, rank, world, dev, backend, stage):
     synth, partition, engine, kernels = pkg("synth"), pkg("partition"), pkg("engine"), pkg("kernels")
     G, gat = pkg("PGAT"), pkg("gat")
     base = args.workload[:-4]
-    n, _, _, _ = synth.SHAPES[base]
     heads, dh, L = args.heads, args.features or 64, args.layers or 3
     F = heads * dh
     t0 = time.time()
-    n, row, col, val = synth.make_graph(base, seed=0, device=dev, generator=args.generator)
-    nnz = int(row.numel())
-    partvec = synth.random_partvec(n, world, seed=0) if world > 1 else torch.zeros(n, dtype=torch.int64)
-    part = partition.build_partition(row, col, val, n, partvec, rank, world, with_transpose=False)
-    del row, col, val
+    part, info = acquire_partition(args, rank, world, dev, stage, with_transpose=False)
+    n, nnz = info["n"], info["nnz"]
     K = kernels.HipKernels(dev)
-    exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
+    emul = bool(args.emulate_rank and part.size > 1)
+    if emul:
+        exch = NoExchange()
+    else:
+        exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
     eng = gat.GatEngine(part, K, dev, exch, mode="standard")
     G.device, G.myrank, G.world_size, G.heads, G._engine_current = dev, rank, world, heads, eng
     torch.cuda.synchronize()
@@ -287,15 +444,25 @@ def bench_gat(args, rank, world, dev, backend, stage):
                     "gather_model_GBs": 4.0 * F * eng.nnz / (avg * 1e-3) / 1e9}
     out = {"metric": "edges aggregated/sec (%s-shaped %d-layer GAT, %d heads x %d, full training epoch)" % (
                base.capitalize(), L, heads, dh),
-           "value": 2 * L * nnz * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+           "value": 2 * L * (eng.nnz if emul else nnz) * args.steps / elapsed, "unit": "edges/s", "n_gpus": world,
+           "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%s-like graph n=%d nnz=%d, %d-layer GAT %d heads x %d (edge softmax + multi-head weighted "
-                                  "SpMM, PGAT.py layer on the stored entries), %d GPU(s)" % (base, n, nnz, L, heads, dh, world),
+           "dtype": "f32", "data": info["data"],
+           "config": {"workload": "%s n=%d nnz=%d, %d-layer GAT %d heads x %d (edge softmax + multi-head weighted "
+                                  "SpMM, PGAT.py layer on the stored entries), 1D partition (%s) over %d GPU(s)%s"
+                                  % (info["source"], n, nnz, L, heads, dh, info["partition"], part.size,
+                                     "; COMPUTE of rank %s alone on one GPU, exchange = no-op" % args.emulate_rank if emul else ""),
                       "n": n, "nnz": nnz, "heads": heads, "head_dim": dh, "layers": L, "generator": args.generator,
+                      "partition": info["partition"], "emulated_rank": args.emulate_rank if emul else None,
+                      "exchange": exch.name if exch else "none",
+                      "rank_shape": {"n_local": part.n_local, "n_halo": part.n_halo, "n_send": part.n_send, "nnz_rank": eng.nnz},
                       "multi_head_spmm": bool(eng.multi_head), "vertex_order": part.order_info},
            "roofline": roofline, "ms_per_epoch": ms, "ms_per_layer_fwd_bwd": ms / L, "loss": float(loss), "setup_s": setup_s,
            "cpu_baseline": None}
+    if world > 1:
+        vol = torch.tensor([eng.stats["send_volume"]], dtype=torch.float64, device=dev)
+        pkg("PGCN")._all_reduce(vol)
+        out["exchange_rows_total"] = float(vol)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -334,6 +501,13 @@ def main():
                          "(GPU/hypergraph/main.cpp:51-63, GPU/graph/main.cpp: one line of n part ids) for N > 1")
     ap.add_argument("--generator", default="rmat", choices=["rmat", "sbm"],
                     help="synthetic graph family: R-MAT (headline) or a planted-partition graph with a power-law tail")
+    ap.add_argument("--shards", default=None, metavar="PREFIX",
+                    help="binary CSR shards PREFIX.<rank>.pgcsr (tools/make_shards.py): every rank reads only its own "
+                         "rows; the part vector is --partvec FILE or PREFIX.<N>.bp")
+    ap.add_argument("--mtx", default=None, help="a MatrixMarket adjacency file (like PGCN.py -a) instead of the synthetic graph")
+    ap.add_argument("--real", action="store_true", help="label the --shards / --mtx input as real data in the JSON line")
+    ap.add_argument("--emulate-rank", default=None, metavar="r/P",
+                    help="one GPU runs rank r of a P-rank job with a no-op exchange (per-rank compute of 2/4/8 GPUs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -373,40 +547,26 @@ def main():
     if args.workload.endswith("-gat"):
         return bench_gat(args, rank, world, dev, backend, stage)
     synth, partition, engine, kernels, P = pkg("synth"), pkg("partition"), pkg("engine"), pkg("kernels"), pkg("PGCN")
-    n, nnz_dir, f, L = synth.SHAPES[args.workload]
-    f = args.features or f
-    L = args.layers or L
+    shape = synth.SHAPES.get(args.workload)
+    if shape is None and not (args.shards or args.mtx):
+        sys.exit("unknown workload %r (known: %s; or give --shards / --mtx)" % (args.workload, ", ".join(synth.SHAPES)))
+    f = args.features or (shape[2] if shape else 128)
+    L = args.layers or (shape[3] if shape else 3)
 
-    # ---- synthetic graph (same seed on every rank) + partition -------------------
+    # ---- inputs: synthetic graph / shards / MatrixMarket file -> this rank's partition ----------------
     t0 = time.time()
-    n, row, col, val = synth.make_graph(args.workload, seed=0, device=dev, generator=args.generator)
-    nnz = int(row.numel())
-    partition_name = "none"
-    if world == 1:
-        partvec = torch.zeros(n, dtype=torch.int64)
-    elif args.partvec == "random":
-        partvec, partition_name = synth.random_partvec(n, world, seed=0), "random (seeded, GCN-HP/main.cpp:133-142)"
-    elif args.partvec == "block":
-        partvec, partition_name = synth.block_partvec(n, world), "contiguous blocks"
-    else:
-        pv = partition.read_partvec(args.partvec)
-        if len(pv) != n or max(pv) >= world:
-            sys.exit("part vector %s: %d entries / %d parts, graph has %d vertices on %d ranks"
-                     % (args.partvec, len(pv), max(pv) + 1, n, world))
-        partvec, partition_name = torch.tensor(pv, dtype=torch.int64), "file:" + os.path.basename(args.partvec)
-    if world > 1:   # all ranks must hold the same graph
-        chk = torch.stack([row.sum(), col.sum(), (val.double().sum() * 1e6).long()]).double()
-        lo, hi = chk.clone(), chk.clone()
-        P._all_reduce(lo, dist.ReduceOp.MIN)
-        P._all_reduce(hi, dist.ReduceOp.MAX)
-        assert torch.equal(lo, hi), "ranks generated different graphs"
-    stage("graph ready")
-    part = partition.build_partition(row, col, val, n, partvec, rank, world)
-    del row, col, val
+    part, info = acquire_partition(args, rank, world, dev, stage)
+    n, nnz, partition_name = info["n"], info["nnz"], info["partition"]
     stage("partition built")
     K = kernels.HipKernels(dev)
-    exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
+    if args.emulate_rank and part.size > 1:
+        exch = NoExchange()
+    else:
+        exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
     eng = engine.AggregationEngine(part, K, dev, exch)
+    if args.emulate_rank and part.size > 1:          # the slabs a real exchange would fill: resident random rows
+        eng._slab("halo", eng.n_halo, f).uniform_()
+        eng._slab("send", eng.n_send, f).uniform_()
     P._engine_current = eng           # gradient all-reduce rides the exchange's communicator and stream
     torch.cuda.synchronize()
     setup_s = time.time() - t0
@@ -458,7 +618,9 @@ def main():
     loss_val = float(loss)
 
     ms_per_step = 1e3 * elapsed / args.steps
-    edges_per_s = 2 * L * nnz * args.steps / elapsed
+    emul = bool(args.emulate_rank and part.size > 1)
+    nnz_job = part.nnz_local if emul else nnz           # an emulated rank aggregates only ITS entries
+    edges_per_s = 2 * L * nnz_job * args.steps / elapsed
 
     # ---- roofline of the dominant kernel (local-block forward SpMM) -----------------
     roofline = None
@@ -466,21 +628,7 @@ def main():
     if avg_ms:
         alg = eng.A_loc.alg_bytes(f)
         achieved = alg / (avg_ms * 1e-3)
-        traffic, traffic_note = None, "no PMC record for this workload"
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                with open(pmc) as fh:
-                    rec = json.load(fh)
-                same = (rec.get("workload") == args.workload and rec.get("n_gpus") == world and rec.get("f") == f
-                        and rec.get("generator", "rmat") == args.generator)
-                if same and rec.get("source_stamp") == kernel_source_stamp():
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_note = "rocprofv3 --pmc passes of %s (profiles/pmc_traffic.json), same kernel sources" % rec.get("source", "?")
-                elif same:
-                    traffic_note = "PMC record is stale (kernel sources changed since it was taken): dropped"
-            except Exception:
-                traffic = None
+        traffic, traffic_note = pmc_traffic_for(args, world, f)
         fpass = os.environ.get("PGCN_FPASS", "auto")
         if fpass == "auto":
             fpass = "64" if (f > 64 and eng.A_loc.ncols * f * 4 >= (96 << 20) and eng.A_loc.col.numel() >= 8_000_000) else "0"
@@ -521,19 +669,35 @@ def main():
             eng.A_loc.launch_cache.clear()
         except Exception as e:
             roofline["split_us"] = {"error": repr(e)}
+    halo_groups = None
+    if part.size > 1:       # the halo launch groups of this rank (A_halo[r] . slab, one per exchange round)
+        halo_groups = []
+        for r, Ah in enumerate(eng.A_halo):
+            havg, hl = timer.summary(id(Ah), f)
+            if havg:
+                halg = 8 * Ah.nnz + 8 * (Ah.nrows + 1) + 4 * f * (part.round_recv_off[r][-1] - part.round_recv_off[r][0]) \
+                    + 2 * 4 * f * part.n_local                   # C is read and written (accumulate)
+                halo_groups.append({"round": r, "nnz": Ah.nnz, "avg_launch_ms": havg, "launches_timed": hl,
+                                    "alg_bytes_per_launch": halg, "achieved": halg / (havg * 1e-3) / 1e9, "unit": "GB/s",
+                                    "frac": halg / (havg * 1e-3) / HBM_PEAK, "ps_per_entry": 1e9 * havg / max(Ah.nnz, 1)})
+        if roofline is not None:
+            roofline["ps_per_entry"] = 1e9 * roofline["avg_launch_ms"] / max(eng.A_loc.nnz, 1)
 
     out = {
-        "metric": "edges aggregated/sec (%s-shaped %d-layer GCN f=%d, full training epoch)" % (
-            args.workload.capitalize(), L, f),
+        "metric": "edges aggregated/sec (%s-shaped %d-layer GCN f=%d, full training epoch%s)" % (
+            args.workload.capitalize(), L, f,
+            "; COMPUTE of rank %s alone on one GPU, exchange = no-op" % args.emulate_rank if emul else ""),
         "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("%s-like " + ("R-MAT" if args.generator == "rmat" else "planted-partition (SBM)")
-                                + " n=%d nnz=%d (incl. self loops), %d-layer GCN f=%d, "
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": info["data"],
+        "config": {"workload": ("%s n=%d nnz=%d (incl. self loops), %d-layer GCN f=%d, "
                                 "1D partition (%s) over %d GPU(s), 1 step = 1 epoch (fwd+loss+bwd+allreduce+Adam)")
-                               % (args.workload, n, nnz, L, f, partition_name, world),
+                               % (info["source"], n, nnz, L, f, partition_name, part.size),
                    "n": n, "nnz": nnz, "f": f, "layers": L, "spmm_per_epoch": 2 * L,
-                   "partition": partition_name, "generator": args.generator,
+                   "partition": partition_name, "generator": args.generator, "source": info["source"],
+                   "emulated_rank": args.emulate_rank if emul else None,
+                   "rank_shape": {"n_local": part.n_local, "n_halo": part.n_halo, "n_send": part.n_send,
+                                  "nnz_local_block": part.A_loc.nnz, "nnz_halo_blocks": sum(a.nnz for a in part.A_halo)},
                    "exchange": exch.name if exch else "none",
                    "xcd_slices": eng.A_loc.nslices, "chunk": K.chunk,
                    "core_tile_fill_min": partition.CORE_TAU,
@@ -543,11 +707,13 @@ def main():
                    if partition.STRIP_ON else None},
         "roofline": roofline, "ms_per_epoch": ms_per_step, "loss": loss_val, "setup_s": setup_s,
     }
+    if halo_groups is not None:
+        out["halo_groups"] = halo_groups
     if world > 1:
         vol = torch.tensor([eng.stats["send_volume"]], dtype=torch.float64, device=dev)
         P._all_reduce(vol)
         out["exchange_rows_total"] = float(vol)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not emul:
         cb = cpu_baseline(part, f, args.cpu_budget)
         out["cpu_baseline"] = cb
     elif rank == 0:

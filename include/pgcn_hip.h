@@ -47,6 +47,7 @@ typedef void *pgcn_stream_t; /* hipStream_t */
 #define PGCN_SPMM_FPASS32 32u   /* gather kernels: 32 features per pass                                     */
 #define PGCN_SPMM_PERSIST 64u   /* gather kernels: a fixed population of 2 workgroups per CU walks the task list (leaves
                                    room on every CU for the strip kernel launched next to it on another stream)  */
+#define PGCN_SPMM_FPASS_SEQ 128u /* gather kernels: feature passes as the slowest-varying part of a 1-D grid (run one after the other) */
 #define PGCN_MAX_SLICES 8        /* = XCDs of an MI355X */
 #define PGCN_MAX_COL_GROUPS 64   /* column groups per slice (time slicing of the column space) */
 #define PGCN_CORE_TR 128         /* rows per tile of the LDS-tiled core kernel    */

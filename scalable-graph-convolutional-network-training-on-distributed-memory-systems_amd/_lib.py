@@ -27,6 +27,7 @@ SPMM_NO_FIXUP = 8
 SPMM_FPASS64 = 16
 SPMM_FPASS32 = 32
 SPMM_PERSIST = 64
+SPMM_FPASS_SEQ = 128
 MAX_SLICES = 8
 
 _vp = ctypes.c_void_p

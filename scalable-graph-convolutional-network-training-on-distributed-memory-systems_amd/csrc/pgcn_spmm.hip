@@ -62,7 +62,14 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
     const int sub = lane % LPR;
 
     __shared__ float2 meta_lds[kWavesPerBlock][64];
-    const int fcol = (blockIdx.y * LPR + sub) * VEC;  // first feature owned by this lane
+    // feature tiles (passes).  Default: grid y.  PGCN_SPMM_FPASS_SEQ: the passes are the SLOWEST-varying part of a
+    // 1-D grid -- pass p = workgroups [p * nblocks, (p + 1) * nblocks) -- so that they are dispatched one after the
+    // other whatever the hardware does with a 2-D grid, and workgroup bx of every pass lands on XCD bx % 8
+    // (nblocks is a multiple of the slice count).
+    const bool seq = (flags & PGCN_SPMM_FPASS_SEQ) != 0;
+    const uint32_t bx = seq ? blockIdx.x % (uint32_t)nblocks : blockIdx.x;
+    const int ytile = seq ? (int)(blockIdx.x / (uint32_t)nblocks) : (int)blockIdx.y;
+    const int fcol = (ytile * LPR + sub) * VEC;  // first feature owned by this lane
     // persist > 0: the grid is nslices x persist workgroups that walk the task list with that stride (a FIXED number
     // of resident gather workgroups per CU: room for the strip kernel's workgroup next to them); 0: one pass
     // (a template parameter: the loop costs the one-pass kernel 9 registers and 3 % of its speed)
@@ -72,13 +79,13 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
         if (nslices > 1) {
             // workgroup b runs on XCD b % 8: it takes tasks of slice b % nslices only, so
             // this XCD's L2 sees just the rows of B with (col % nslices) == slice.
-            const int slice = blockIdx.x % nslices;
-            const int64_t sb = blockIdx.x / nslices + sb0;
+            const int slice = bx % nslices;
+            const int64_t sb = bx / nslices + sb0;
             tid = seg.v[slice] + (sb * kWavesPerBlock + wave) * G + grp;
             nt = seg.v[slice + 1];
             if (seg.v[slice] + sb * kWavesPerBlock * G >= nt) break;
         } else {
-            const int64_t bid = swizzle_block(blockIdx.x + sb0, nblocks, (flags & PGCN_SPMM_XCD_SWIZZLE) != 0 && !PERSIST);
+            const int64_t bid = swizzle_block(bx + sb0, nblocks, (flags & PGCN_SPMM_XCD_SWIZZLE) != 0 && !PERSIST);
             tid = (bid * kWavesPerBlock + wave) * G + grp;
             if (bid * kWavesPerBlock * G >= nt) break;
         }
@@ -166,12 +173,15 @@ int launch_tasks(const int64_t *rowptr, const int32_t *col, const float *val, co
                  int nslices, const SliceSeg &seg, int persist, hipStream_t s) {
     // measurement aid (PGCN_GATHER_LDS_PAD bytes of unused dynamic LDS per workgroup): caps the workgroups per CU
     static const int lds_pad = getenv("PGCN_GATHER_LDS_PAD") ? atoi(getenv("PGCN_GATHER_LDS_PAD")) : 0;
+    const bool seq = (flags & PGCN_SPMM_FPASS_SEQ) != 0 && persist == 0 && grid * ntiles <= 0x7fffffffLL;
+    if (!seq) flags &= ~PGCN_SPMM_FPASS_SEQ;
     if (persist > 0)
         hipLaunchKernelGGL((spmm_tasks_kernel<LPR, VEC, HAS_VAL, OFF32, true>), dim3((unsigned)grid, ntiles),
                            dim3(kThreads), lds_pad, s, rowptr, col, val, tasks, ntasks, row_map, B, ldb, C, ldc,
                            f, partial, grid, flags, nslices, seg, persist);
     else
-        hipLaunchKernelGGL((spmm_tasks_kernel<LPR, VEC, HAS_VAL, OFF32, false>), dim3((unsigned)grid, ntiles),
+        hipLaunchKernelGGL((spmm_tasks_kernel<LPR, VEC, HAS_VAL, OFF32, false>),
+                           seq ? dim3((unsigned)(grid * ntiles)) : dim3((unsigned)grid, ntiles),
                            dim3(kThreads), lds_pad, s, rowptr, col, val, tasks, ntasks, row_map, B, ldb, C, ldc,
                            f, partial, grid, flags, nslices, seg, persist);
     PGCN_HIP_CHECK(hipGetLastError());

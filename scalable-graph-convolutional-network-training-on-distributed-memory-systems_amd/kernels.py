@@ -201,6 +201,8 @@ class HipKernels:
         # entries -- whole graphs; a rank's shard of an 8-way run loses 15 % with them: tools/rank_probe.py, r02)
         self.fpass = os.environ.get("PGCN_FPASS", "auto")
         self.base_flags |= {"64": _lib.SPMM_FPASS64, "32": _lib.SPMM_FPASS32}.get(self.fpass, 0)
+        if os.environ.get("PGCN_FPASS_SEQ", "0") != "0":
+            self.base_flags |= _lib.SPMM_FPASS_SEQ
         self.chunk = chunk
         self.small_row = small_row
         # the LDS-tiled core kernel (LDS-bound) and the gather kernel (L1/L2-bound) use different

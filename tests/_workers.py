@@ -257,3 +257,21 @@ def partition_local_worker(rank, P, port, path_A, path_pv, rounds, q):
     q.put({"rank": rank, "checks": {k: bool(v) for k, v in checks.items()}, "nnz_local": int(mine.nnz)})
     dist.barrier()
     dist.destroy_process_group()
+
+
+def bench_inputs_worker(rank, P, port, kind, path, path_pv, q):
+    """bench.acquire_partition on one of the input kinds of bench.py (shards / mtx) under gloo, device = cpu."""
+    import argparse
+    _init(rank, P, port)
+    import bench
+    args = argparse.Namespace(shards=path if kind == "shards" else None, mtx=path if kind == "mtx" else None,
+                              partvec=path_pv, emulate_rank=None, workload="none", generator="rmat", real=False)
+    part, info = bench.acquire_partition(args, rank, P, torch.device("cpu"), lambda m: None)
+    r, c, v = part.A_loc.to_coo()
+    key = torch.argsort(r * part.n_local + c, stable=True)
+    q.put({"rank": rank, "owned": part.owned.numpy(), "halo_global": part.halo_global.numpy(),
+           "send_global": part.send_global.numpy(), "nnz": info["nnz"], "n": info["n"], "partition": info["partition"],
+           "loc": (r[key].numpy(), c[key].numpy(), v[key].numpy()),
+           "nnz_halo": sum(a.nnz for a in part.A_halo)})
+    dist.barrier()
+    dist.destroy_process_group()

@@ -45,28 +45,46 @@ def main():
     ap.add_argument("--workload", default="mid")
     ap.add_argument("--k", default="2,4,8")
     ap.add_argument("--work", default="/tmp/pgcn_partvec")
+    ap.add_argument("--generator", default="rmat", choices=["rmat", "sbm"],
+                    help="sbm: the planted-partition stand-in (portable stream: the same graph on the GPU box)")
+    ap.add_argument("--tools", default="hp,gp", help="which of the reference's front-ends to run")
+    ap.add_argument("--graph-name", default=None, help="a synth.SHAPES name, or (with --n/--nnz) a free label")
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--nnz", type=int, default=None, help="directed entries without self loops")
     args = ap.parse_args()
     synth = importlib.import_module(PKG + ".synth")
     partition = importlib.import_module(PKG + ".partition")
     io_ = importlib.import_module(PKG + ".pargcn_io")
     os.makedirs(args.work, exist_ok=True)
     hp, gp = build_tools(args.work)
-    n, row, col, val = synth.make_graph(args.workload, seed=0)
-    name = "%s.A.mtx" % args.workload
+    tools = args.tools.split(",")
+    if args.n:
+        n, row, col, val = synth.make_graph(args.n, args.nnz, seed=0, generator=args.generator)
+    else:
+        n, row, col, val = synth.make_graph(args.workload, seed=0, generator=args.generator)
+    label = args.graph_name or (args.workload + ("-sbm" if args.generator == "sbm" else ""))
+    name = "%s.A.mtx" % label
+    print("graph %s: n=%d entries=%d" % (label, n, row.numel()), flush=True)
     mtx = os.path.join(args.work, name)
     A = sp.coo_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n, n))
     mmwrite(mtx, sp.tril(A).tocoo(), symmetry="symmetric", precision=3)        # like preprocess/GrB-GNN-IDG.py:80
+    del A
+    print("wrote", mtx, flush=True)
     outdir = os.path.join(ROOT, "tests", "golden", "partvec")
     os.makedirs(outdir, exist_ok=True)
-    stats = {"workload": args.workload, "n": n, "nnz": int(row.numel()), "parts": {}}
+    stats = {"workload": label, "generator": args.generator, "n": n, "nnz": int(row.numel()), "parts": {}}
     for k in [int(x) for x in args.k.split(",")]:
         o = os.path.join(args.work, "out%d" % k) + "/"
         shutil.rmtree(o, ignore_errors=True)
         os.makedirs(o)
-        subprocess.check_call([hp, "-a", mtx, "-o", o, "-k", str(k)], stdout=subprocess.DEVNULL)
-        subprocess.check_call([gp, "-a", mtx, "-o", o, "-k", str(k)], stdout=subprocess.DEVNULL)
+        if "hp" in tools:
+            subprocess.check_call([hp, "-a", mtx, "-o", o, "-k", str(k)], stdout=subprocess.DEVNULL)
+            print("hp done", k, flush=True)
+        if "gp" in tools:
+            subprocess.check_call([gp, "-a", mtx, "-o", o, "-k", str(k)], stdout=subprocess.DEVNULL)
+            print("gp done", k, flush=True)
         rec = {}
-        for ext in ("hp", "gp", "rp"):
+        for ext in [t for t in ("hp", "gp") if t in tools] + ["rp"]:
             src = os.path.join(o, "%s.%d.%s" % (name, k, ext))
             dst = os.path.join(outdir, "%s.%d.%s" % (name, k, ext))
             if ext == "rp":          # the reference seeds its random vector with the clock: keep OUR seeded one instead
@@ -86,7 +104,7 @@ def main():
                         "max_part_nnz": int(nnz_p.max()), "imbalance_nnz": float(nnz_p.max()) * k / float(row.numel())}
         stats["parts"][str(k)] = rec
         print(k, json.dumps(rec))
-    with open(os.path.join(outdir, "%s.stats.json" % args.workload), "w") as fh:
+    with open(os.path.join(outdir, "%s.stats.json" % label), "w") as fh:
         json.dump(stats, fh, indent=1)
 
 

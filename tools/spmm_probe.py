@@ -91,7 +91,7 @@ def main():
         fpass = 0                        # _p64 / _p32: feature passes of the gather part
         if "_p" in name:
             name, fp = name.split("_p")
-            fpass = {"64": 16, "32": 32}[fp]
+            fpass = {"64": 16, "32": 32, "64s": 16 | 128, "32s": 32 | 128}[fp]   # s: passes as a 1-D grid (sequential)
         fused = name.endswith("F")
         name = name.rstrip("F")
         smode = ""                       # "r:" range slicing (uniform bounds), "d:" dealt order + range slicing
