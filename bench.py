@@ -629,11 +629,11 @@ def main():
         alg = eng.A_loc.alg_bytes(f)
         achieved = alg / (avg_ms * 1e-3)
         traffic, traffic_note = pmc_traffic_for(args, world, f)
-        fpass = os.environ.get("PGCN_FPASS", "auto")
+        fpass = K.fpass
         if fpass == "auto":
             fpass = "64" if (f > 64 and eng.A_loc.ncols * f * 4 >= (96 << 20) and eng.A_loc.col.numel() >= 8_000_000) else "0"
         kname = "A_loc.H forward SpMM = spmm_tasks_kernel<%s,4,1,1> (gather part%s)" % (
-            {"64": "16", "32": "8"}.get(fpass, "32") if f > 64 else "16", {"64": ", 64 features per pass", "32": ", 32 features per pass"}.get(fpass, "") if f > 64 else "")
+            {"64": "16"}.get(fpass, "32") if f > 64 else "16", {"64": ", 64 features per pass"}.get(fpass, "") if f > 64 else "")
         if getattr(eng.A_loc, "strip", None) is not None:
             kname += " + spmm_strip_kernel (512x128 strip tiles, async LDS pipeline, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.strip.nnz / max(eng.A_loc.nnz, 1))

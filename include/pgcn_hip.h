@@ -44,10 +44,7 @@ typedef void *pgcn_stream_t; /* hipStream_t */
 #define PGCN_SPMM_NO_FIXUP 8u    /* plan call: leave partial sums in the work-space; the caller
                                     combines them with pgcn_spmm_fixup_f32                  */
 #define PGCN_SPMM_FPASS64 16u   /* gather kernels: 64 features per pass (grid y = passes, pass-major order) */
-#define PGCN_SPMM_FPASS32 32u   /* gather kernels: 32 features per pass                                     */
-#define PGCN_SPMM_PERSIST 64u   /* gather kernels: a fixed population of 2 workgroups per CU walks the task list (leaves
-                                   room on every CU for the strip kernel launched next to it on another stream)  */
-#define PGCN_SPMM_FPASS_SEQ 128u /* gather kernels: feature passes as the slowest-varying part of a 1-D grid (run one after the other) */
+
 #define PGCN_MAX_SLICES 8        /* = XCDs of an MI355X */
 #define PGCN_MAX_COL_GROUPS 64   /* column groups per slice (time slicing of the column space) */
 #define PGCN_CORE_TR 128         /* rows per tile of the LDS-tiled core kernel    */
@@ -213,14 +210,6 @@ int pgcn_spmm_strip_f32(const int32_t *work, int64_t nwork, const int32_t *recs,
                         const float *B, int64_t ldb, int64_t ncols, int32_t f, float *partial_ws,
                         int64_t partial_ws_elems, int64_t nslots_total, pgcn_stream_t stream);
 
-/* The same product on the same records in half the footprint (512 threads, 64 features per workgroup, 81 KB of
- * LDS, 2 waves per SIMD): one such workgroup and three workgroups of the gather kernel (pgcn_spmm_csr_plan_f32)
- * are resident on a CU together, so the LDS-bound strips and the latency-bound gather part overlap when the two
- * are launched on two streams.  Bit-identical to pgcn_spmm_strip_f32.  Needs f % 4 == 0 and 16-byte aligned
- * B / partial_ws (PGCN_EUNSUPPORTED otherwise: use pgcn_spmm_strip_f32).                                       */
-int pgcn_spmm_strip_half_f32(const int32_t *work, int64_t nwork, const int32_t *recs, const int32_t *pairs,
-                        const float *B, int64_t ldb, int64_t ncols, int32_t f, float *partial_ws,
-                        int64_t partial_ws_elems, int64_t nslots_total, pgcn_stream_t stream);
 
 /* The densest tiles through the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32, k-ordered
  * fmaf chains).  A tile is stored dense, pre-swizzled into the A-operand order:
@@ -236,21 +225,6 @@ int pgcn_spmm_dense_f32(const int32_t *work, int64_t nwork, const int32_t *tile_
                         float *partial_ws, int64_t partial_ws_elems, int64_t nslots_total,
                         pgcn_stream_t stream);
 
-/* Gather tasks and core pieces of one SpMM in ONE launch (512-thread workgroups): the work list
- * interleaves, per XCD, blocks of <= 16 gather tasks with core pieces, so that the L2-bound and the
- * LDS-bound work overlap on every CU.  work: 4 x int32 per workgroup {kind, a, b, 0}: kind 0 = gather
- * tasks [a, a+b) of `tasks` (entry i of the list runs on XCD i % 8: give it tasks of slice i % 8),
- * kind 1 = core piece a of `core_work` (the `work` array of pgcn_spmm_core_f32), kind 2 = nothing.
- * Partial sums are left in partial_ws (combine with pgcn_spmm_fixup_f32); direct tasks write C.
- * Supported: f <= 128, f % 4 == 0, values present, 16-byte aligned panels; else PGCN_EUNSUPPORTED
- * (use the separate entry points).  Results are bit-identical to the three-launch path.        */
-int pgcn_spmm_fused_f32(const int32_t *work, int64_t nwork, const int32_t *col, const float *val,
-                        const int32_t *tasks, const int32_t *row_map, const int32_t *core_work,
-                        const int32_t *tile_panel, const int64_t *tile_base, const int32_t *seg_off,
-                        const int32_t *ccol, const float *cval, const float *B, int64_t ldb,
-                        int64_t ncols, float *C, int64_t ldc, int32_t f, float *partial_ws,
-                        int64_t partial_ws_elems, int64_t nslots_total, uint32_t flags,
-                        pgcn_stream_t stream);
 
 /* C[row] (+)= sum of the partial-sum slots listed for the row, in list order.
  * fix: 4 x int32 per row {row, begin, count, 0}; slot_ids (optional): the row's slots are
@@ -351,6 +325,10 @@ int pgcn_nll_rows_backward_f32(const float *X, int64_t ldx, const int64_t *label
  * repeated index keeps one of the rows (like the reference's assignment, quirk Q3).                 */
 int pgcn_gather_rows_f32(const float *H, int64_t ldh, const int32_t *idx, int64_t nidx,
                          float *out, int64_t ldo, int32_t f, pgcn_stream_t stream);
+/* scatter: accumulate = 0 assigns (duplicate ids: the LAST one wins, like `X[indices] = buf`, PGCN.py:115);
+ * accumulate = 1 ADDS with atomic fp32 adds: correct for duplicate ids, but the order of the additions to one
+ * row -- hence the last bits of the sum -- is NOT reproducible from run to run.  The engine's reverse exchange
+ * therefore does not use it: received partial rows are added by a pattern SpMM in fixed order (engine.py). */
 int pgcn_scatter_rows_f32(float *H, int64_t ldh, const int32_t *idx, int64_t nidx,
                           const float *in, int64_t ldi, int32_t f, int32_t accumulate,
                           pgcn_stream_t stream);

@@ -359,11 +359,15 @@ def run(rank, size, nlayers, nfeatures, path_A, path_partvec, backend):
     partvec = _partition.read_partvec(path_partvec)       # first line: n part ids (PGCN.py:172-173); .gz accepted
     _partition_cache.clear()
     if _ingest.is_shard_prefix(path_A, rank):
-        # binary CSR shards written ahead of time (ingest.write_shards / tools/mtx_to_shards.py): this rank reads
+        # binary CSR shards written ahead of time (ingest.write_shards / tools/make_shards.py): this rank reads
         # ONLY its own rows -- no text, no global matrix anywhere (papers100M-scale path)
         sh = _ingest.read_shard(_ingest.shard_path(path_A, rank))
         if sh["nparts"] != size or sh["rank"] != rank or sh["n"] != len(partvec):
             raise ValueError("shard %s was written for rank %d of %d, n = %d" % (path_A, sh["rank"], sh["nparts"], sh["n"]))
+        import numpy as _np
+        if not _np.array_equal(sh["rows"], _np.nonzero(_np.asarray(partvec) == rank)[0]):
+            raise ValueError("shard %s does not hold the rows the part vector gives rank %d (cut with another part vector?)"
+                             % (path_A, rank))
         r_, c_, v_ = _ingest.shard_coo(sh)
         import scipy.sparse as _sp
         A = _sp.coo_matrix((v_, (r_, c_)), shape=(sh["n"], sh["n"]))

@@ -25,9 +25,6 @@ SPMM_XCD_SWIZZLE = 2
 SPMM_OFFSETS32 = 4
 SPMM_NO_FIXUP = 8
 SPMM_FPASS64 = 16
-SPMM_FPASS32 = 32
-SPMM_PERSIST = 64
-SPMM_FPASS_SEQ = 128
 MAX_SLICES = 8
 
 _vp = ctypes.c_void_p
@@ -54,12 +51,9 @@ SIGNATURES = {
     "pgcn_spmm_core_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp,
                                           _i64, _i64, _vp]),
     "pgcn_spmm_strip_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
-    "pgcn_spmm_strip_half_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
     "pgcn_spmm_heads_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64,
                                            _vp, _i64, _vp, _i64, _i64, _u32, _vp]),
     "pgcn_spmm_dense_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
-    "pgcn_spmm_fused_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                           _i64, _vp, _i64, _i32, _vp, _i64, _i64, _u32, _vp]),
     "pgcn_spmm_fixup_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _u32, _vp]),
     "pgcn_spmm_plan_host": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp,
                                            ctypes.POINTER(_i64), ctypes.POINTER(_i64),

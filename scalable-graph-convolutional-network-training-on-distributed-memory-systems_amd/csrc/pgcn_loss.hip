@@ -52,7 +52,8 @@ __global__ __launch_bounds__(kThreads) void nll_rows_kernel(const float *__restr
     if (lane == 0) {
         const int64_t y = labels[i];
         lse[i] = l;
-        loss[i] = l - x[y];
+        // a label outside [0, f) poisons the row's loss with NaN (F.nll_loss raises; no out-of-bounds read here)
+        loss[i] = (y >= 0 && y < f) ? l - x[y] : __builtin_nanf("");
     }
 }
 

@@ -58,6 +58,9 @@ extern "C" int pgcn_shard_write(const char *path, int64_t n_global, int32_t rank
               put(fh.f, rowptr, (size_t)(nrows + 1) * 8) && put(fh.f, col, (size_t)nnz * 4) &&
               put(fh.f, &zero, (size_t)((nnz & 1) * 4)) && put(fh.f, val, (size_t)nnz * 4);
     if (!ok) return fail_io("pgcn_shard_write: short write to", path);
+    FILE *f = fh.f;
+    fh.f = nullptr;                      // a failed flush at close is a failed write
+    if (fclose(f) != 0) return fail_io("pgcn_shard_write: cannot flush", path);
     return PGCN_OK;
 }
 
@@ -97,5 +100,8 @@ extern "C" int pgcn_shard_read(const char *path, int64_t cap_rows, int64_t cap_n
     for (int64_t i = 0; i < nrows; ++i)
         if (rowptr[i + 1] < rowptr[i] || rows[i] < 0 || rows[i] >= info[0])
             return pgcn_set_error2(PGCN_EINVAL, "pgcn_shard_read: corrupt shard", path);
+    for (int64_t k = 0; k < nnz; ++k)    // column ids become gather indices on the device
+        if (col[k] < 0 || col[k] >= info[0])
+            return pgcn_set_error2(PGCN_EINVAL, "pgcn_shard_read: column id outside the matrix", path);
     return PGCN_OK;
 }

@@ -26,8 +26,6 @@
 //     (which share columns in any locality-preserving ordering) share an L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
-
 #include "pgcn_spmm_bodies.h"
 
 namespace {
@@ -48,13 +46,13 @@ struct SliceSeg { int64_t v[PGCN_MAX_SLICES + 1]; };
 
 // tasks: int4 {kbeg low 32, kbeg high 32, length, dst}; kbeg = absolute offset of the task's
 // first entry in col/val; dst >= 0: partial-sum slot, dst < 0: write row ~dst of C directly.
-template <int LPR, int VEC, bool HAS_VAL, bool OFF32, bool PERSIST>
+template <int LPR, int VEC, bool HAS_VAL, bool OFF32>
 __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const int4 *__restrict__ tasks, int64_t ntasks,
     const int32_t *__restrict__ row_map, const float *__restrict__ B, int64_t ldb,
     float *__restrict__ C, int64_t ldc, int32_t f, float *__restrict__ partial,
-    int64_t nblocks, uint32_t flags, int32_t nslices, SliceSeg seg, int32_t persist) {
+    int64_t nblocks, uint32_t flags, int32_t nslices, SliceSeg seg) {
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -62,53 +60,41 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_tasks_kernel(
     const int sub = lane % LPR;
 
     __shared__ float2 meta_lds[kWavesPerBlock][64];
-    // feature tiles (passes).  Default: grid y.  PGCN_SPMM_FPASS_SEQ: the passes are the SLOWEST-varying part of a
-    // 1-D grid -- pass p = workgroups [p * nblocks, (p + 1) * nblocks) -- so that they are dispatched one after the
-    // other whatever the hardware does with a 2-D grid, and workgroup bx of every pass lands on XCD bx % 8
-    // (nblocks is a multiple of the slice count).
-    const bool seq = (flags & PGCN_SPMM_FPASS_SEQ) != 0;
-    const uint32_t bx = seq ? blockIdx.x % (uint32_t)nblocks : blockIdx.x;
-    const int ytile = seq ? (int)(blockIdx.x / (uint32_t)nblocks) : (int)blockIdx.y;
-    const int fcol = (ytile * LPR + sub) * VEC;  // first feature owned by this lane
-    // persist > 0: the grid is nslices x persist workgroups that walk the task list with that stride (a FIXED number
-    // of resident gather workgroups per CU: room for the strip kernel's workgroup next to them); 0: one pass
-    // (a template parameter: the loop costs the one-pass kernel 9 registers and 3 % of its speed)
-    const int64_t step = PERSIST ? persist : 0;
-    for (int64_t sb0 = 0;; sb0 += step) {
-        int64_t tid, nt = ntasks;
-        if (nslices > 1) {
-            // workgroup b runs on XCD b % 8: it takes tasks of slice b % nslices only, so
-            // this XCD's L2 sees just the rows of B with (col % nslices) == slice.
-            const int slice = bx % nslices;
-            const int64_t sb = bx / nslices + sb0;
-            tid = seg.v[slice] + (sb * kWavesPerBlock + wave) * G + grp;
-            nt = seg.v[slice + 1];
-            if (seg.v[slice] + sb * kWavesPerBlock * G >= nt) break;
-        } else {
-            const int64_t bid = swizzle_block(bx + sb0, nblocks, (flags & PGCN_SPMM_XCD_SWIZZLE) != 0 && !PERSIST);
-            tid = (bid * kWavesPerBlock + wave) * G + grp;
-            if (bid * kWavesPerBlock * G >= nt) break;
-        }
-        const bool tact = tid < nt;
-
-        int32_t len = 0, dst = -1;
-        int64_t kbeg = 0;
-        if (tact) {
-            if (tasks) {
-                const int4 t = tasks[tid];
-                kbeg = (int64_t)(((uint64_t)(uint32_t)t.y << 32) | (uint32_t)t.x);
-                len = t.z;
-                dst = t.w;
-            } else {  // one task per row
-                kbeg = rowptr[tid];
-                len = (int32_t)(rowptr[tid + 1] - kbeg);
-                dst = ~(int32_t)tid;
-            }
-        }
-        pgcn_bodies::gather_task_body<LPR, VEC, HAS_VAL, OFF32>(tact, kbeg, len, dst, rowptr, col, val, row_map, B, ldb,
-                                                              C, ldc, f, partial, flags, fcol, meta_lds[wave]);
-        if (!PERSIST) break;
+    // grid y walks the features LPR * VEC at a time (one tile for whole rows; two 64-feature passes with
+    // PGCN_SPMM_FPASS64: dispatched pass-major, so a pass gathers 256-byte rows from half the working set)
+    const int fcol = (blockIdx.y * LPR + sub) * VEC;  // first feature owned by this lane
+    int64_t tid, nt = ntasks;
+    if (nslices > 1) {
+        // workgroup b runs on XCD b % 8: it takes tasks of slice b % nslices only, so
+        // this XCD's L2 sees just the rows of B with (col % nslices) == slice.
+        const int slice = blockIdx.x % nslices;
+        const int64_t sb = blockIdx.x / nslices;
+        tid = seg.v[slice] + (sb * kWavesPerBlock + wave) * G + grp;
+        nt = seg.v[slice + 1];
+        if (seg.v[slice] + sb * kWavesPerBlock * G >= nt) return;
+    } else {
+        const int64_t bid = swizzle_block(blockIdx.x, nblocks, (flags & PGCN_SPMM_XCD_SWIZZLE) != 0);
+        tid = (bid * kWavesPerBlock + wave) * G + grp;
+        if (bid * kWavesPerBlock * G >= nt) return;
     }
+    const bool tact = tid < nt;
+
+    int32_t len = 0, dst = -1;
+    int64_t kbeg = 0;
+    if (tact) {
+        if (tasks) {
+            const int4 t = tasks[tid];
+            kbeg = (int64_t)(((uint64_t)(uint32_t)t.y << 32) | (uint32_t)t.x);
+            len = t.z;
+            dst = t.w;
+        } else {  // one task per row
+            kbeg = rowptr[tid];
+            len = (int32_t)(rowptr[tid + 1] - kbeg);
+            dst = ~(int32_t)tid;
+        }
+    }
+    pgcn_bodies::gather_task_body<LPR, VEC, HAS_VAL, OFF32>(tact, kbeg, len, dst, rowptr, col, val, row_map, B, ldb,
+                                                          C, ldc, f, partial, flags, fcol, meta_lds[wave]);
 }
 
 // fix: int4 {row, first slot, #segments, unused}; sums the segments of a split
@@ -170,20 +156,10 @@ template <int LPR, int VEC, bool HAS_VAL, bool OFF32>
 int launch_tasks(const int64_t *rowptr, const int32_t *col, const float *val, const int4 *tasks,
                  int64_t ntasks, const int32_t *row_map, const float *B, int64_t ldb, float *C,
                  int64_t ldc, int32_t f, float *partial, int64_t grid, int ntiles, uint32_t flags,
-                 int nslices, const SliceSeg &seg, int persist, hipStream_t s) {
-    // measurement aid (PGCN_GATHER_LDS_PAD bytes of unused dynamic LDS per workgroup): caps the workgroups per CU
-    static const int lds_pad = getenv("PGCN_GATHER_LDS_PAD") ? atoi(getenv("PGCN_GATHER_LDS_PAD")) : 0;
-    const bool seq = (flags & PGCN_SPMM_FPASS_SEQ) != 0 && persist == 0 && grid * ntiles <= 0x7fffffffLL;
-    if (!seq) flags &= ~PGCN_SPMM_FPASS_SEQ;
-    if (persist > 0)
-        hipLaunchKernelGGL((spmm_tasks_kernel<LPR, VEC, HAS_VAL, OFF32, true>), dim3((unsigned)grid, ntiles),
-                           dim3(kThreads), lds_pad, s, rowptr, col, val, tasks, ntasks, row_map, B, ldb, C, ldc,
-                           f, partial, grid, flags, nslices, seg, persist);
-    else
-        hipLaunchKernelGGL((spmm_tasks_kernel<LPR, VEC, HAS_VAL, OFF32, false>),
-                           seq ? dim3((unsigned)(grid * ntiles)) : dim3((unsigned)grid, ntiles),
-                           dim3(kThreads), lds_pad, s, rowptr, col, val, tasks, ntasks, row_map, B, ldb, C, ldc,
-                           f, partial, grid, flags, nslices, seg, persist);
+                 int nslices, const SliceSeg &seg, hipStream_t s) {
+    hipLaunchKernelGGL((spmm_tasks_kernel<LPR, VEC, HAS_VAL, OFF32>), dim3((unsigned)grid, ntiles),
+                       dim3(kThreads), 0, s, rowptr, col, val, tasks, ntasks, row_map, B, ldb, C, ldc,
+                       f, partial, grid, flags, nslices, seg);
     PGCN_HIP_CHECK(hipGetLastError());
     return PGCN_OK;
 }
@@ -212,20 +188,12 @@ int launch(const int64_t *rowptr, const int32_t *col, const float *val, const in
             if (flags & PGCN_SPMM_XCD_SWIZZLE) grid = ((nblocks + 7) / 8) * 8;
         }
         if (grid > 0x7fffffffLL) return pgcn_set_error(PGCN_EINVAL, "spmm: too many tasks for one launch");
-        // PGCN_SPMM_PERSIST: a fixed population of workgroups (2 per CU and feature tile) walks the task list
-        int persist = 0;
-        if ((flags & PGCN_SPMM_PERSIST) && !((flags & PGCN_SPMM_XCD_SWIZZLE) && nslices == 1)) {
-            int dev = 0, ncu = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-            const int64_t want = ((int64_t)2 * ncu / ntiles + nslices - 1) / nslices;   // workgroups per slice
-            if (want >= 1 && want * nslices < grid) { persist = (int)want; grid = want * nslices; }
-        }
         const int4 *t4 = reinterpret_cast<const int4 *>(tasks);
         const bool off32 = (flags & PGCN_SPMM_OFFSETS32) != 0;
         int rc;
 #define PGCN_LT(HV, O32)                                                                        \
     rc = launch_tasks<LPR, VEC, HV, O32>(rowptr, col, val, t4, ntasks, row_map, B, ldb, C, ldc, f, \
-                                         partial, grid, ntiles, flags, nslices, seg, persist, s)
+                                         partial, grid, ntiles, flags, nslices, seg, s)
         if (val) { if (off32) PGCN_LT(true, true); else PGCN_LT(true, false); }
         else     { if (off32) PGCN_LT(false, true); else PGCN_LT(false, false); }
 #undef PGCN_LT
@@ -248,11 +216,10 @@ int dispatch(const int64_t *rowptr, const int32_t *col, const float *val, const 
              const float *B, int64_t ldb, float *C, int64_t ldc, int32_t f, float *partial,
              uint32_t flags, hipStream_t s) {
     Shape sh = pick_shape(f, B, ldb, C, ldc, partial);
-    // feature passes: fewer lanes per task -> the grid's y dimension walks the features 64 / 32 at a time
-    // (pass-major dispatch order), so the rows of B one pass touches are 256 / 128 B each and a pass's
-    // working set is a half / a quarter of the panel
+    // feature passes: fewer lanes per task -> the grid's y dimension walks the features 64 at a time (pass-major
+    // dispatch order), so the rows of B one pass touches are 256 B each and a pass's working set is half the panel
+    // (32-feature passes and a 1-D pass-major grid were measured in r02 / r03: slower / no difference)
     if (sh.vec == 4 && (flags & PGCN_SPMM_FPASS64) && sh.lpr > 16) sh.lpr = 16;
-    if (sh.vec == 4 && (flags & PGCN_SPMM_FPASS32) && sh.lpr > 8) sh.lpr = 8;
 #define PGCN_CASE(L, V)                                                                       \
     if (sh.lpr == L && sh.vec == V)                                                           \
         return launch<L, V>(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, row_map, \

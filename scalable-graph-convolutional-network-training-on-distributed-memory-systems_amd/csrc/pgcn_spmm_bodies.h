@@ -1,6 +1,6 @@
-// pgcn_spmm_bodies.h -- the two SpMM work-item bodies as device functions, shared by the stand-alone
-// kernels (pgcn_spmm.hip: gather tasks; pgcn_spmm_core.hip: LDS-tiled core pieces) and by the fused
-// kernel that co-schedules both kinds of work on one CU (pgcn_spmm_fused.hip).
+// pgcn_spmm_bodies.h -- the two SpMM work-item bodies as device functions: pgcn_spmm.hip runs the gather tasks,
+// pgcn_spmm_core.hip the LDS-tiled core pieces (a third kernel that co-scheduled both kinds on one CU was measured
+// in r01 -- no gain -- and lives in tools/experiments/pgcn_spmm_fused.hip, outside the product build).
 #ifndef PGCN_SPMM_BODIES_H
 #define PGCN_SPMM_BODIES_H
 #include <hip/hip_runtime.h>

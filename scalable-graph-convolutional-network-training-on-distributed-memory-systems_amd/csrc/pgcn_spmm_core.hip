@@ -31,7 +31,7 @@ namespace {
 using namespace pgcn_bodies;
 
 // work: int4 {tile row index, first dense tile, one-past-last dense tile, first slot}; the body lives in
-// pgcn_spmm_bodies.h (core_piece_body) so that the fused kernel can run it too.
+// pgcn_spmm_bodies.h (core_piece_body).
 template <int VEC>
 __global__ __launch_bounds__(kCoreThreads, 4) void spmm_core_kernel(
     const int4 *__restrict__ work, const int32_t *__restrict__ tile_panel,
@@ -129,9 +129,6 @@ extern "C" int pgcn_spmm_core_f32(const int32_t *work, int64_t nwork, const int3
     const bool v4 = aligned16(B, partial_ws, ldb, 4, f);
     if (v4) {
         size_t smem = (size_t)(TC + 1) * 32 * 4 * 4 + (kCoreThreads / 64) * 512;
-        static long pad = -1;   // experiment knob: extra dynamic LDS => one workgroup per CU
-        if (pad < 0) { const char *e = getenv("PGCN_CORE_LDS_PAD"); pad = e ? atol(e) : 0; }
-        smem += (size_t)pad;
         int dev = 0;
         PGCN_HIP_CHECK(hipGetDevice(&dev));
         static bool attr_set[64] = {false};              // the attribute is per device

@@ -83,34 +83,8 @@ template <int NBLK, bool EXACT>
 __device__ __forceinline__ void compute_half(const float4 (&a)[8], const float *__restrict__ tv, int h, int w, int hi,
                                              int lo, const float *smem, f32x16 (&acc)[NBLK]) {
     if (!EXACT) {
-#ifdef PGCN_DENSE_PREFETCH
-        // B operands of step t + 1 are read from LDS BEFORE the MFMAs of step t are issued (sched_barrier pins the
-        // order): otherwise the compiler emits read -> s_waitcnt lgkmcnt(0) -> MFMA for every step and the LDS latency
-        // sits between the matrix instructions of a wave
-        float bc[NBLK], bn[NBLK];
-        {
-            const float *brow = smem + (64 * h + hi) * kT;
-#pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) bc[nb] = brow[(nb * 32 + lo + 32 * hi) & 127];
-        }
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const float4 a4 = a[t >> 2];
-            const float av = (t & 3) == 0 ? a4.x : (t & 3) == 1 ? a4.y : (t & 3) == 2 ? a4.z : a4.w;
-            if (t + 1 < 32) {
-                const float *brow = smem + (64 * h + 2 * (t + 1) + hi) * kT;
-#pragma unroll
-                for (int nb = 0; nb < NBLK; ++nb) bn[nb] = brow[(nb * 32 + lo + 32 * hi) & 127];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bc[nb], acc[nb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) bc[nb] = bn[nb];
-        }
-#else
+        // (reading the B operands of step t + 1 before the MFMAs of step t -- sched_barrier-pinned -- was measured
+        //  in r03: no change, the compiler's order stays)
 #pragma unroll
         for (int s4 = 0; s4 < 8; ++s4) {
             const float av4[4] = {a[s4].x, a[s4].y, a[s4].z, a[s4].w};
@@ -126,7 +100,6 @@ __device__ __forceinline__ void compute_half(const float4 (&a)[8], const float *
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[e], b[nb], acc[nb], 0, 0, 0);
             }
         }
-#endif
     } else {
         // this lane owns D[row = (r & 3) + 8 (r >> 2) + 4 hi][col = lo] of every 32 x 32 block
         for (int k = 64 * h; k < 64 * h + 64; ++k) {

@@ -386,29 +386,30 @@ extern "C" int pgcn_spmm_strip_f32(const int32_t *work, int64_t nwork, const int
     const int4 *w4 = reinterpret_cast<const int4 *>(work);
     const int4 *r4 = reinterpret_cast<const int4 *>(recs);
     const bool vec = f % 4 == 0 && ldb % 4 == 0 && (uintptr_t)B % 16 == 0 && (uintptr_t)partial_ws % 16 == 0;
-    static const int probe = getenv("PGCN_STRIP_PROBE") ? atoi(getenv("PGCN_STRIP_PROBE")) : 0;   // measurement aid, see the kernel
     if (vec) {
         int dev = 0;
         PGCN_HIP_CHECK(hipGetDevice(&dev));
         static bool attr_set[64] = {false};
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {   // the attribute is per device
             PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
+#ifdef PGCN_EXPERIMENTS
             PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
             PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
-            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
             PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
-            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
+#endif
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         const dim3 grid((unsigned)nwork, (unsigned)((f + 127) / 128));
-        switch (probe) {
-            case 1: hipLaunchKernelGGL(spmm_strip_kernel<1>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws); break;
-            case 2: hipLaunchKernelGGL(spmm_strip_kernel<2>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws); break;
-            case 4: hipLaunchKernelGGL(spmm_strip_kernel<4>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws); break;
-            case 6: hipLaunchKernelGGL(spmm_strip_kernel<6>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws); break;
-            case 3: hipLaunchKernelGGL(spmm_strip_kernel<3>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws); break;
-            default: hipLaunchKernelGGL(spmm_strip_kernel<0>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws); break;
-        }
+#ifdef PGCN_EXPERIMENTS
+        // measurement build only (tools/ab_build.sh exp -DPGCN_EXPERIMENTS): PGCN_STRIP_PROBE = 1 no compute phase,
+        // 2 no panel staging, 4 phase timers instead of results
+        static const int probe = getenv("PGCN_STRIP_PROBE") ? atoi(getenv("PGCN_STRIP_PROBE")) : 0;
+        if (probe == 1) hipLaunchKernelGGL(spmm_strip_kernel<1>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws);
+        else if (probe == 2) hipLaunchKernelGGL(spmm_strip_kernel<2>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws);
+        else if (probe == 4) hipLaunchKernelGGL(spmm_strip_kernel<4>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws);
+        else
+#endif
+        hipLaunchKernelGGL(spmm_strip_kernel<0>, grid, dim3(kThreads), kSmem, s, w4, r4, pairs, B, ldb, ncols, f, partial_ws);
     } else {
         hipLaunchKernelGGL(spmm_strip_generic_kernel, dim3((unsigned)nwork, (unsigned)((f + 31) / 32)), dim3(kThreads), 0, s,
                            w4, r4, pairs, B, ldb, ncols, f, partial_ws);

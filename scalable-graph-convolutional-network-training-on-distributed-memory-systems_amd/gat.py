@@ -21,7 +21,6 @@ process computes on the whole graph (owned rows).
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -29,8 +28,9 @@ import torch
 
 from .engine import BoundaryExchange
 from .partition import HostCSR, Partition, csr_from_coo, pick_nslices
+from .tuning import T as _T
 
-LONG_ROW = int(os.environ.get("PGCN_GAT_LONG_ROW", "1024"))   # rows above this get a 256-thread workgroup
+LONG_ROW = _T.gat_long_row   # rows above this get a 256-thread workgroup
 MODES = {"standard": 0, "reference": 1}
 
 
@@ -129,11 +129,11 @@ class GatEngine(BoundaryExchange):
         self.bwd = kernels.prepare_gat(g.bwd, g.bwd_wave, g.bwd_block)
         self.perm = g.perm.to(self.device)
         self._scratch = {}
-        self.sliced_grad = os.environ.get("PGCN_GAT_SLICED", "1") != "0"   # XCD-sliced edge gradient where the shape allows
+        self.sliced_grad = _T.gat_sliced   # XCD-sliced edge gradient where the shape allows
         # the edge gradient over the balanced tasks of the SpMM plan (pgcn_gat_edge_grad_tasks_f32)
-        self.task_grad = os.environ.get("PGCN_GAT_TASK_GRAD", "1") != "0" and hasattr(kernels, "gat_edge_grad_tasks")
+        self.task_grad = _T.gat_task_grad and hasattr(kernels, "gat_edge_grad_tasks")
         # all heads of `attention @ Z` (and of its transpose) in one launch (pgcn_spmm_heads_f32)
-        self.multi_head = os.environ.get("PGCN_GAT_MULTIHEAD", "1") != "0" and hasattr(kernels, "spmm_heads")
+        self.multi_head = _T.gat_multihead and hasattr(kernels, "spmm_heads")
 
     # -- buffers ---------------------------------------------------------
     def _plane_scratch(self, name: str, heads: int) -> torch.Tensor:

@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import ctypes
 import dataclasses
-import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -24,10 +23,11 @@ import torch
 
 from . import _lib
 from .partition import HostCSR
+from .tuning import T as _T
 
-DEFAULT_CHUNK = int(os.environ.get("PGCN_SPMM_CHUNK", "1024"))
-DEFAULT_SMALL_ROW = int(os.environ.get("PGCN_SPMM_SMALL_ROW", "96"))
-GROUP_MIN_ROW = int(os.environ.get("PGCN_GROUP_MIN_ROW", "4096"))
+DEFAULT_CHUNK = _T.spmm_chunk
+DEFAULT_SMALL_ROW = _T.spmm_small_row
+GROUP_MIN_ROW = _T.group_min_row
 
 
 @dataclass
@@ -54,7 +54,6 @@ class DeviceCSR:
     fix_all: Optional[torch.Tensor] = None    # int32 [nfix_all,4] combined fix list (core + gather slots)
     slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
     nslots_total: int = 0
-    fused_work: Optional[torch.Tensor] = None  # int32 [nwork,4] unified work list (pgcn_spmm_fused_f32)
     rows_wave: Optional[torch.Tensor] = None   # GAT kernels: int32 rows handled by one wave each ...
     rows_block: Optional[torch.Tensor] = None  # ... and by one 256-thread workgroup each (hub rows)
     slice_off: Optional[torch.Tensor] = None   # int32 [nrows, 9] offsets of a row's 8 col % 8 slices (XCD-sliced storage)
@@ -140,41 +139,6 @@ def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarr
     return tasks, fix[:nf.value], int(ns.value), seg
 
 
-def fused_work_list(seg, nslices: int, ntasks: int, npieces: int, gb: int = 16, nxcd: int = 8) -> np.ndarray:
-    """Unified work list of pgcn_spmm_fused_f32: entry i runs on XCD i % 8.  Queue x holds the
-    gather blocks (<= gb tasks, never crossing a slice) of slice x -- all slices round-robin when
-    the plan is not 8-sliced -- and core pieces x, x+8, ...; inside a queue the two kinds are
-    spread evenly so that a CU tends to host one workgroup of each.  Both inputs come longest
-    first (LPT), the merge keeps that order within a kind."""
-    queues_g = [[] for _ in range(nxcd)]
-    bounds = [0, ntasks] if seg is None else [int(seg[i]) for i in range(nslices + 1)]
-    k = 0
-    for sl in range(len(bounds) - 1):
-        beg = np.arange(bounds[sl], bounds[sl + 1], gb, dtype=np.int64)
-        cnt = np.minimum(beg + gb, bounds[sl + 1]) - beg
-        blk = np.stack([np.zeros_like(beg), beg, cnt, np.zeros_like(beg)], 1)
-        if len(bounds) - 1 == nxcd:
-            queues_g[sl].append(blk)
-        else:
-            for j in range(blk.shape[0]):
-                queues_g[(k + j) % nxcd].append(blk[j:j + 1])
-            k += blk.shape[0]
-    out = []
-    for x in range(nxcd):
-        g = np.concatenate(queues_g[x]) if queues_g[x] else np.zeros((0, 4), np.int64)
-        pc = np.arange(x, npieces, nxcd, dtype=np.int64)
-        c = np.stack([np.ones_like(pc), pc, np.zeros_like(pc), np.zeros_like(pc)], 1)
-        key = np.concatenate([(np.arange(g.shape[0]) + 0.5) / max(g.shape[0], 1),
-                              (np.arange(c.shape[0]) + 0.25) / max(c.shape[0], 1)])
-        out.append(np.concatenate([g, c])[np.argsort(key, kind="stable")])
-    T = max(q.shape[0] for q in out)
-    work = np.zeros((T, nxcd, 4), dtype=np.int32)
-    work[:, :, 0] = 2
-    for x, q in enumerate(out):
-        work[:q.shape[0], x] = q
-    return work.reshape(T * nxcd, 4)
-
-
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -194,24 +158,16 @@ class HipKernels:
         if self.device.type != "cuda":
             raise _lib.PgcnError("HipKernels needs a cuda (HIP) device, got %s" % device)
         if xcd_swizzle is None:
-            xcd_swizzle = os.environ.get("PGCN_XCD_SWIZZLE", "1") != "0"
+            xcd_swizzle = _T.xcd_swizzle
         self.base_flags = _lib.SPMM_XCD_SWIZZLE if xcd_swizzle else 0
-        # feature passes of the gather kernels (PGCN_FPASS = 64 / 32 features per pass, 0 = whole rows; default "auto":
-        # 64 where the operand panel (>= 96 MB) is several times the aggregate L2 and the gather part holds >= 8 M
-        # entries -- whole graphs; a rank's shard of an 8-way run loses 15 % with them: tools/rank_probe.py, r02)
-        self.fpass = os.environ.get("PGCN_FPASS", "auto")
-        self.base_flags |= {"64": _lib.SPMM_FPASS64, "32": _lib.SPMM_FPASS32}.get(self.fpass, 0)
-        if os.environ.get("PGCN_FPASS_SEQ", "0") != "0":
-            self.base_flags |= _lib.SPMM_FPASS_SEQ
+        # feature passes of the gather kernels (tuning.fpass = "64": 64 features per pass, "0": whole rows; default
+        # "auto": 64 where the operand panel (>= 96 MB) is several times the aggregate L2 and the gather part holds
+        # >= 8 M entries -- whole graphs; a rank's shard of an 8-way run loses 15 % with them: tools/rank_probe.py, r02)
+        self.fpass = _T.fpass
+        if self.fpass == "64":
+            self.base_flags |= _lib.SPMM_FPASS64
         self.chunk = chunk
         self.small_row = small_row
-        # the LDS-tiled core kernel (LDS-bound) and the gather kernel (L1/L2-bound) use different
-        # pipes of a CU: optionally run them on two streams so the hardware can co-schedule them
-        self.core_overlap = os.environ.get("PGCN_CORE_OVERLAP", "0") != "0"
-        self._side = None
-        # one launch for gather tasks + core pieces (pgcn_spmm_fused_f32) instead of two
-        self.fused = os.environ.get("PGCN_SPMM_FUSED", "0") != "0"
-        self.fused_gb = int(os.environ.get("PGCN_FUSED_GB", "16"))
 
     # -- data placement -------------------------------------------------
     def prepare(self, csr: HostCSR, pattern_only: bool = False) -> DeviceCSR:
@@ -298,9 +254,6 @@ class HipKernels:
         d.slot_ids = slots.to(torch.int32).to(dev).contiguous()
         d.nslots_total = ns_rem + ns_strip + ns_core + (hd.nslots if hd is not None else 0)
         d.nnz = csr.nnz
-        if d.ntasks and d.val is not None and hc is not None:
-            fw = fused_work_list(d.seg, d.nslices, d.ntasks, hc.npieces, gb=self.fused_gb)
-            d.fused_work = torch.from_numpy(fw).to(dev).contiguous()
 
     # -- kernels ----------------------------------------------------------
     def _stream(self) -> int:
@@ -323,7 +276,7 @@ class HipKernels:
             raise _lib.PgcnError("B and C must be fp32 CUDA matrices")
         if B.shape[0] < A.ncols or (A.row_map is None and C.shape[0] < A.nrows):
             raise _lib.PgcnError("B or C has too few rows")
-        key = (B.stride(0), C.stride(0), B.shape[1], accumulate, C.shape[1], B.stride(1), C.stride(1), self.fused)
+        key = (B.stride(0), C.stride(0), B.shape[1], accumulate, C.shape[1], B.stride(1), C.stride(1))
         fn = A.launch_cache.get(key)
         if fn is None:
             fn = self._bind_spmm(A, B, C, accumulate)
@@ -389,67 +342,21 @@ class HipKernels:
         ncols, nst = A.ncols, A.nslots_total
         fixp, nfa, slots = A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr()
         gflags, fflags = flags | _lib.SPMM_NO_FIXUP, flags & _lib.SPMM_ACCUMULATE
-        overlap = self.core_overlap and ntasks
-        if (overlap and st is not None) or os.environ.get("PGCN_GATHER_PERSIST", "0") != "0":
-            gflags |= _lib.SPMM_PERSIST        # a fixed 2 gather workgroups per CU: the strip workgroup fits next to them
-        if (self.fused and A.fused_work is not None and co is not None and f <= 128 and f % 4 == 0 and ldb % 4 == 0 and ldc % 4 == 0
-                and B.data_ptr() % 16 == 0 and C.data_ptr() % 16 == 0):
-            fw, nfw = A.fused_work.data_ptr(), A.fused_work.shape[0]
-
-            def fused(B, C):
-                b, c, s = B.data_ptr(), C.data_ptr(), stream()
-                if (b | c) & 15:
-                    return hybrid(B, C)
-                check(lib.pgcn_spmm_fused_f32(fw, nfw, col, val, tasks, rmap, cw, ctp, ctb, cso, ccol, cval, b, ldb,
-                                              ncols, c, ldc, f, ws, ws_n, nst, gflags, s), "pgcn_spmm_fused_f32")
-                if de is not None:
-                    check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s),
-                          "pgcn_spmm_dense_f32")
-                check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, c, ldc, f, fflags, s), "pgcn_spmm_fixup_f32")
-        else:
-            fused = None
-
-        side_first = os.environ.get("PGCN_CORE_OVERLAP", "0") == "2"
-
-        # overlapped with the gather kernel the strips run in their half-footprint shape (one workgroup per CU next
-        # to three gather workgroups); alone, the 1024-thread kernel is faster
-        half_ok = f % 4 == 0 and ldb % 4 == 0 and B.data_ptr() % 16 == 0 and ldb < (1 << 24)
-        strip_fn = lib.pgcn_spmm_strip_half_f32 if ((overlap or os.environ.get("PGCN_STRIP_HALF", "0") != "0") and half_ok) else lib.pgcn_spmm_strip_f32
-
-        def tiled(b, cs):
-            if st is not None:
-                check(strip_fn(sw, sn, srec, spairs, b, ldb, ncols, f, ws, ws_n, nst, cs), "pgcn_spmm_strip_f32")
-            if de is not None:
-                check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, cs),
-                      "pgcn_spmm_dense_f32")
-            if co is not None:
-                check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, cs),
-                      "pgcn_spmm_core_f32")
 
         def hybrid(B, C):
             b, c, s = B.data_ptr(), C.data_ptr(), stream()
-            cs = s
-            if overlap:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device, priority=-1 if os.environ.get("PGCN_SIDE_PRIO", "0") != "0" else 0)
-                main = torch.cuda.current_stream(self.device)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                self._side.wait_event(ev)
-                cs = self._side.cuda_stream
-                if side_first:
-                    tiled(b, cs)
             if ntasks:
                 check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, None, 0, rmap, b, ldb,
                                                  c, ldc, f, ws, ws_n, nslots, gflags, s), "pgcn_spmm_csr_plan_f32")
-            if not (overlap and side_first):
-                tiled(b, cs)
-            if overlap:
-                done = torch.cuda.Event()
-                done.record(self._side)
-                torch.cuda.current_stream(self.device).wait_event(done)
+            if st is not None:
+                check(lib.pgcn_spmm_strip_f32(sw, sn, srec, spairs, b, ldb, ncols, f, ws, ws_n, nst, s), "pgcn_spmm_strip_f32")
+            if de is not None:
+                check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s), "pgcn_spmm_dense_f32")
+            if co is not None:
+                check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, s),
+                      "pgcn_spmm_core_f32")
             check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, c, ldc, f, fflags, s), "pgcn_spmm_fixup_f32")
-        return fused or hybrid
+        return hybrid
 
     # -- GAT path (pgcn_gat.hip) ---------------------------------------------
     def prepare_gat(self, csr: HostCSR, rows_wave: torch.Tensor, rows_block: torch.Tensor) -> DeviceCSR:
@@ -651,6 +558,8 @@ class HipKernels:
         if X.dim() != 2 or X.shape[1] > 1024 or X.stride(1) != 1 or labels.dtype is not torch.int64 or not labels.is_contiguous():
             return None
         self._check_dense(X, labels.numel(), "X")
+        if X.shape[0] != labels.numel():
+            raise _lib.PgcnError("nll_rows: %d rows of logits for %d labels" % (X.shape[0], labels.numel()))
         n, f = labels.numel(), X.shape[1]
         loss = torch.empty(n, dtype=torch.float32, device=self.device)
         lse = torch.empty(n, dtype=torch.float32, device=self.device)
@@ -661,7 +570,9 @@ class HipKernels:
     def nll_rows_backward(self, X: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor, gscale: torch.Tensor,
                           scale: float) -> torch.Tensor:
         n, f = labels.numel(), X.shape[1]
-        dX = torch.empty((X.shape[0], f), dtype=torch.float32, device=self.device)
+        if X.shape[0] != n:
+            raise _lib.PgcnError("nll_rows_backward: %d rows of logits for %d labels" % (X.shape[0], n))
+        dX = torch.empty((n, f), dtype=torch.float32, device=self.device)
         g = gscale.reshape(1).to(torch.float32).contiguous()
         _lib.check(self.lib.pgcn_nll_rows_backward_f32(X.data_ptr(), X.stride(0), labels.data_ptr(), lse.data_ptr(),
                                                        g.data_ptr(), scale, n, f, dX.data_ptr(), dX.stride(0),

@@ -22,11 +22,12 @@ results are bit-exact by construction (checked against the reference's maps).
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch
+
+from .tuning import T as _T       # every tunable below comes from tuning.Tuning (PGCN_TUNING), read once
 
 
 @dataclass
@@ -88,19 +89,16 @@ CORE_TR = 128      # rows per tile   (PGCN_CORE_TR in include/pgcn_hip.h)
 CORE_TC = 128      # columns per panel
 CORE_NG = 16       # 32-lane groups per workgroup
 CORE_RW = CORE_TR // CORE_NG
-CORE_ON = os.environ.get("PGCN_CORE", "1") != "0"
-CORE_TAU = float(os.environ.get("PGCN_CORE_TAU", "0.05"))        # minimum tile fill
-CORE_EMAX = int(os.environ.get("PGCN_CORE_EMAX", "0"))           # entries per work piece; 0 = adaptive:
-                                                                  # ~1024 pieces, between 4096 and 32768 entries
-CORE_PG = int(os.environ.get("PGCN_CORE_PANEL_GROUP", "0"))      # >0: cut pieces at multiples of PG panels
-                                                                  # and run them panel-group-major (L2 locality)
-CORE_MIN_NNZ = int(os.environ.get("PGCN_CORE_MIN_NNZ", "262144"))  # smaller cores are not worth two more launches
-CORE_MIN_FRAC = float(os.environ.get("PGCN_CORE_MIN_FRAC", "0.1"))
-DEGREE_SORT = os.environ.get("PGCN_DEGREE_SORT", "1") != "0"
-DENSE_ON = os.environ.get("PGCN_DENSE", "1") != "0"
-DENSE_TAU = float(os.environ.get("PGCN_DENSE_TAU", "0.30"))       # tiles at least this full go to the matrix cores (0.20 before the r02 strips)
-DENSE_PIECE = int(os.environ.get("PGCN_DENSE_PIECE", "0"))        # tiles per work piece (one 128-row partial block each);
-                                                                  # 0 = adaptive: ~1024 pieces, between 1 and 16 tiles
+CORE_ON = _T.tiles
+CORE_TAU = _T.core_tau            # minimum tile fill of the 128 x 128 LDS core
+CORE_EMAX = _T.core_emax          # entries per work piece; 0 = adaptive: ~1024 pieces, between 4096 and 32768 entries
+CORE_MIN_NNZ = _T.core_min_nnz    # smaller tiled parts are not worth two more launches
+CORE_MIN_FRAC = _T.core_min_frac
+DEGREE_SORT = _T.degree_sort
+DENSE_ON = _T.dense
+DENSE_TAU = _T.dense_tau          # tiles at least this full go to the matrix cores (0.20 before the r02 strips)
+DENSE_PIECE = _T.dense_piece      # tiles per work piece (one 128-row partial block each); 0 = adaptive: ~1024 pieces,
+                                  # between 1 and 16 tiles
 
 
 @dataclass
@@ -198,7 +196,7 @@ def build_dense(r64, c64, v, tkey_local, ntiles, tile_row, tile_panel, nrows, nc
 # out near 18 TB/s even when every row hits in L2 (r02 probe: uniform hot-set SpMM).  Staging a
 # 128-row panel once in LDS and serving every entry of a TALL tile from there costs 64 KB per tile
 # instead of 512 B per entry: a 512 x 128 tile pays off from 128 entries (0.2 % fill) on.
-STRIP_ON = os.environ.get("PGCN_STRIP", "1") != "0"
+STRIP_ON = _T.strip
 STRIP_TR = 512     # rows per strip tile   (PGCN_STRIP_TR in include/pgcn_hip.h)
 STRIP_NG = 64      # 16-lane groups per workgroup (1024 threads)
 STRIP_RW = STRIP_TR // STRIP_NG   # 8 row slots per group, row-in-tile = j * NG + group
@@ -208,12 +206,11 @@ STRIP_PAD_OFF = 128 * 512         # byte offset of the all-zero LDS row: what an
 # Thresholds (measured, r02 sweep on the Reddit- and products-shaped graphs): a record costs 5-6 k clk of LDS
 # time whatever it holds (1 024 slots), the gather kernel ~17-28 clk per entry, so a layer must hold a few
 # hundred stored entries to pay for itself.
-STRIP_MIN = int(os.environ.get("PGCN_STRIP_MIN", "512"))        # entries that make a 512 x 128 tile worth staging
-STRIP_LAYER_MIN = int(os.environ.get("PGCN_STRIP_LAYER_MIN", "384"))   # stored entries that make one more record of a tile worth it
-STRIP_MIN_RECORDS = int(os.environ.get("PGCN_STRIP_MIN_RECORDS", "16384"))   # blocks with fewer strip records use the 128 x 128 LDS core
-STRIP_THEN_CORE = os.environ.get("PGCN_STRIP_CORE", "0") != "0"   # legacy 128 x 128 LDS core on what the strips leave
-STRIP_PIECES = int(os.environ.get("PGCN_STRIP_PIECES", "1024"))  # target number of work pieces
-STRIP_STAGE_COST = float(os.environ.get("PGCN_STRIP_STAGE_COST", "1.0"))  # staging a panel ~ this many records of work
+STRIP_MIN = _T.strip_min                  # entries that make a 512 x 128 tile worth staging
+STRIP_LAYER_MIN = _T.strip_layer_min      # stored entries that make one more record of a tile worth it
+STRIP_MIN_RECORDS = _T.strip_min_records  # blocks with fewer strip records use the 128 x 128 LDS core
+STRIP_PIECES = _T.strip_pieces            # target number of work pieces
+STRIP_STAGE_COST = _T.strip_stage_cost    # staging a panel ~ this many records of work
 
 
 @dataclass
@@ -299,14 +296,17 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     slot = (idx - run_first) % SB
     # tiles worth staging, then their layers worth a record
     ut, tinv, tcnt = torch.unique(tk_s, return_inverse=True, return_counts=True)
-    lkey = tk_s * 64 + torch.clamp(layer, max=63)                # a row holds at most 128 entries per panel = 64 layers
+    # a row holds at most 128 DISTINCT columns per panel = 64 layers; duplicate coordinates (an uncoalesced COO keeps
+    # them as separate entries, PGCN.py:63) can exceed that: whatever lies beyond layer 63 stays in the gather part
+    deep = layer >= 64
+    lkey = tk_s * 64 + torch.clamp(layer, max=63)
     ul, linv, lcnt = torch.unique(lkey, return_inverse=True, return_counts=True)
     lsel = (lcnt >= max(1, layer_min)) & (tcnt[torch.searchsorted(ut, ul // 64)] >= max(1, min_entries))
     # layers of a tile shrink monotonically, so the kept layers of a tile are a prefix 0..L-1
     nrec = int(lsel.sum())
     if nrec == 0:
         return None, None
-    in_s = lsel[linv]
+    in_s = lsel[linv] & ~deep
     rmap = torch.cumsum(lsel.to(torch.int64), 0) - 1
     e_rec = rmap[linv[in_s]]                                     # record of every strip entry (tile major, layer minor)
     rit = rit_s[in_s]
@@ -317,6 +317,8 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     cs, vs = c64[order][in_s], v[order][in_s].to(torch.float32)
     pairs[dst, 0] = ((cs - strip_panel_base(cs // TC, ncols)) * 512).to(torch.int32)
     pairs[dst, 1] = vs.contiguous().view(torch.int32)
+    if int((pairs[:, 0] != STRIP_PAD_OFF).sum()) != int(dst.numel()):
+        raise AssertionError("two stored entries mapped to one strip slot")
     rk = ul[lsel]
     rec_tile, rec_layer = rk // 64, rk % 64
     rec_row, rec_panel = rec_tile // ncp, rec_tile % ncp
@@ -409,18 +411,14 @@ def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, nc
     tt = tile_tot.cpu().numpy()
     import numpy as np
     cum = np.cumsum(tt) - tt
-    tpg = (tile_panel.cpu().numpy() // CORE_PG) if CORE_PG > 0 else np.zeros(ntiles, np.int64)
-    run_start = np.r_[True, (ttr[1:] != ttr[:-1]) | (tpg[1:] != tpg[:-1])]
+    run_start = np.r_[True, ttr[1:] != ttr[:-1]]
     run_base = np.maximum.accumulate(np.where(run_start, cum, 0))
     pid_local = (cum - run_base) // max(emax, 1)
     newp = np.r_[True, run_start[1:] | (pid_local[1:] != pid_local[:-1])]
     kbeg = np.nonzero(newp)[0]
     kend = np.r_[kbeg[1:], ntiles]
     edges = np.add.reduceat(tt, kbeg)
-    if CORE_PG > 0:   # panel-group-major: concurrent workgroups stage the same few panels
-        lpt = np.lexsort((-edges, tpg[kbeg]))
-    else:
-        lpt = np.argsort(-edges, kind="stable")          # longest piece first
+    lpt = np.argsort(-edges, kind="stable")          # longest piece first (panel-group-major order: no gain, r01)
     work = np.stack([ttr[kbeg][lpt], kbeg[lpt], kend[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
     core = HostCore(nrows, ncols, torch.from_numpy(work).to(dev), tile_row, tile_panel, tile_base,
                     seg_off.contiguous(), ccol, cval)
@@ -429,26 +427,16 @@ def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, nc
 
 # XCD-sliced storage: above this many columns the dense panel no longer fits a 4 MiB L2
 # at any realistic width, so rows are stored grouped by (col % 8) -- one slice per XCD.
-SLICE_MIN_COLS = int(os.environ.get("PGCN_SLICE_MIN_COLS", "16384"))
-NSLICES = int(os.environ.get("PGCN_SLICES", "8"))
+SLICE_MIN_COLS = _T.slice_min_cols
+NSLICES = _T.slices
 
 
 def pick_nslices(ncols: int) -> int:
     return NSLICES if (NSLICES > 1 and ncols >= SLICE_MIN_COLS) else 1
 
 
-# column groups: the share of the feature panel one XCD sees during one group should fit its
-# 4 MiB L2 with room for the streams (nominal row width 512 B = 128 fp32 features)
-COL_GROUPS = os.environ.get("PGCN_COL_GROUPS", "1")   # measured: no gain on the benchmark graph (r01)
-GROUP_L2_BYTES = float(os.environ.get("PGCN_GROUP_L2_MB", "2.5")) * (1 << 20)
-
-
-def pick_ngroups(ncols: int, nslices: int) -> int:
-    if nslices <= 1:
-        return 1
-    if COL_GROUPS != "auto":
-        return max(1, min(64, int(COL_GROUPS)))
-    return max(1, min(64, int(-(-(ncols * 512) // int(nslices * GROUP_L2_BYTES)))))
+# Column groups (time slicing of the column space inside an XCD slice) are an explicit argument of csr_from_coo
+# only: measured in r01 / r02 (L2 hits 72 -> 84 %, kernel SLOWER: 2.5x more tasks), never on by default.
 
 
 def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
@@ -474,7 +462,7 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
         if slice_bounds is None:
             return c64 % S
         return torch.bucketize(c64, slice_bounds[1:-1], right=True)
-    G = pick_ngroups(ncols, S) if ngroups is None else (ngroups if S > 1 else 1)
+    G = 1 if ngroups is None else (max(1, min(64, int(ngroups))) if S > 1 else 1)
     gw = max(1, -(-ncols // G))          # columns per group
     hcore, hdense, hstrip, row_flags = None, None, None, None
     if core and not compact_rows and r.numel():
@@ -495,11 +483,6 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
                     r, c, v = r[ckeep], c[ckeep], v[ckeep]
             if skeep is not None:
                 r, c, v = r[skeep], c[skeep], v[skeep]
-            if STRIP_THEN_CORE and r.numel():
-                # what the strips left behind may still hold 128 x 128 tiles dense enough for the LDS core
-                ckeep, hcore, _ = split_core(r, c, v, nrows, ncols, tau, emax, 2.0)
-                if ckeep is not None and hcore is not None:
-                    r, c, v = r[ckeep], c[ckeep], v[ckeep]
         tiled = sum(h.nnz for h in (hcore, hdense, hstrip) if h is not None)
         if tiled and tau is None and strip_min is None and (tiled < CORE_MIN_NNZ or tiled < CORE_MIN_FRAC * r0.numel()):
             hcore = hdense = hstrip = None     # a small tiled part does not pay for the extra kernel + fix-up launches
@@ -628,7 +611,7 @@ class Partition:
                 for q in range(self.size) if q != self.rank}
 
 
-EXCHANGE_ROUNDS = int(os.environ.get("PGCN_EXCHANGE_ROUNDS", "2"))
+EXCHANGE_ROUNDS = _T.exchange_rounds
 
 
 def _round_major(owner: torch.Tensor, size: int, rounds: int):
@@ -774,14 +757,13 @@ def _degree_order(gdeg: Optional[torch.Tensor], n: int, dev):
 # consecutively turn the community's internal edges into dense diagonal blocks that the tiled kernels (MFMA
 # tiles, strips) serve from LDS.  "auto" runs a few rounds of label propagation and keeps the community order
 # only when it found real structure (else: plain degree order, e.g. for R-MAT).
-ORDER_MODE = os.environ.get("PGCN_ORDER", "auto")          # degree | community | auto
-ORDER_LPA_ITERS = int(os.environ.get("PGCN_ORDER_ITERS", "8"))
-ORDER_MIN_INSIDE = float(os.environ.get("PGCN_ORDER_MIN_INSIDE", "0.25"))   # share of entries inside communities
-ORDER_MAX_SHARE = float(os.environ.get("PGCN_ORDER_MAX_SHARE", "0.125"))    # largest community / n
-ORDER_MIN_N = int(os.environ.get("PGCN_ORDER_MIN_N", "4096"))
-ORDER_HUBS = float(os.environ.get("PGCN_ORDER_HUBS", "0.0"))    # share of vertices numbered first as hubs; measured on the
-                                                                 # SBM stand-in (r02): 0 is best, pulling hubs out of their
-                                                                 # communities costs more intra-community density than it buys
+ORDER_MODE = _T.order                      # degree | community | auto
+ORDER_LPA_ITERS = _T.order_iters
+ORDER_MIN_INSIDE = _T.order_min_inside     # share of entries inside communities
+ORDER_MAX_SHARE = _T.order_max_share       # largest community / n
+ORDER_MIN_N = _T.order_min_n
+# (numbering the top-degree vertices of ALL communities first as "hubs" was measured on the SBM stand-in in r02:
+#  worse at every share -- pulling hubs out of their communities costs more intra-community density than it buys)
 
 
 def label_propagation(row: torch.Tensor, col: torch.Tensor, n: int, iters: int = None, seed: int = 12345) -> torch.Tensor:
@@ -825,19 +807,12 @@ def vertex_order(row: torch.Tensor, col: torch.Tensor, n: int, gdeg: Optional[to
     info.update(communities=int(ul.numel()), inside=inside, largest_share=share)
     if mode == "auto" and not (inside >= ORDER_MIN_INSIDE and share <= ORDER_MAX_SHARE):
         return _degree_order(gdeg, n, dev) + (info,)
-    # hubs first (the top ORDER_HUBS share by degree, from all communities: the entries that leave a community
-    # mostly point at them, so they become a few dense column panels every tile row shares), then communities by
-    # decreasing total degree, vertices of a community by decreasing degree
+    # communities by decreasing total degree, vertices of a community by decreasing degree
     cdeg = torch.zeros(ul.numel(), dtype=torch.int64, device=dev).index_add_(0, linv, gdeg)
     crank = torch.empty_like(cdeg)
     crank[torch.argsort(-cdeg, stable=True)] = torch.arange(ul.numel(), dtype=torch.int64, device=dev)
     dmax = int(gdeg.max())
     key = (crank[linv] + 1) * (dmax + 1) + (dmax - gdeg)
-    nh = int(ORDER_HUBS * n)
-    if nh > 0:
-        hubs = torch.argsort(-gdeg, stable=True)[:nh]
-        key[hubs] = dmax - gdeg[hubs]                       # "community 0": all hubs, by degree
-    info["hubs"] = nh
     gorder = torch.argsort(key, stable=True)
     grank = torch.empty(n, dtype=torch.int64, device=dev)
     grank[gorder] = torch.arange(n, dtype=torch.int64, device=dev)

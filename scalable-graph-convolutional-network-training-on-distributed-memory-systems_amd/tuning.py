@@ -1,0 +1,89 @@
+"""Every tunable of the aggregation path in ONE place, read ONCE.
+
+The defaults are the measured choices of rounds 1-3 (DESIGN.md section 4 gives the sweep behind each).  A run can
+override any field through the single environment variable
+
+    PGCN_TUNING="strip_pieces=256,strip_min_records=0,exchange_rounds=1"
+
+(comma separated ``field=value``; booleans as 0/1) -- this is what the probe scripts under ``tools/`` use.  Nothing
+else in the package reads a tuning value from the environment.  The remaining ``PGCN_*`` variables select a
+transport or an ingest path, not a kernel shape: PGCN_EXCHANGE, PGCN_OVERLAP, PGCN_INGEST, PGCN_BACKEND, PGCN_SEED.
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+from dataclasses import dataclass
+
+
+@dataclass
+class Tuning:
+    # ---- gather kernel (spmm_tasks_kernel) plan ---------------------------------------------------------
+    spmm_chunk: int = 1024           # entries per task of a long row
+    spmm_small_row: int = 96         # rows up to this many entries are ONE unsliced task
+    group_min_row: int = 4096        # column groups (explicit `ngroups` only) cut rows at least this long
+    fpass: str = "auto"              # 64-feature passes of the gather part: auto (whole graphs, f > 64) | 64 | 0
+    xcd_swizzle: bool = True         # unsliced plans: one contiguous row range per XCD
+    # ---- XCD-sliced storage ---------------------------------------------------------------------------------
+    slices: int = 8                  # = XCDs of an MI355X
+    slice_min_cols: int = 16384      # narrower operands fit one L2: stored unsliced
+    # ---- tiled parts ----------------------------------------------------------------------------------------
+    tiles: bool = True               # split dense regions off the gather part at all
+    core_tau: float = 0.05           # 128 x 128 LDS core: minimum tile fill
+    core_emax: int = 0               # entries per core piece (0 = adaptive)
+    core_min_nnz: int = 262144       # a smaller tiled part does not pay for its launches
+    core_min_frac: float = 0.1
+    dense: bool = True               # fp32-MFMA tiles
+    dense_tau: float = 0.30          # tiles at least this full go to the matrix cores
+    dense_piece: int = 0             # tiles per MFMA piece (0 = adaptive)
+    strip: bool = True               # 512 x 128 strip tiles
+    strip_min: int = 512             # stored entries that make a strip tile worth staging
+    strip_layer_min: int = 384       # stored entries that make one more layer (record) of a tile worth it
+    strip_min_records: int = 16384   # blocks with fewer records keep the 128 x 128 LDS core instead
+    strip_pieces: int = 1024         # target number of strip work pieces
+    strip_stage_cost: float = 1.0    # staging a panel ~ this many records of work (piece balancing)
+    # ---- vertex order ---------------------------------------------------------------------------------------
+    degree_sort: bool = True
+    order: str = "auto"              # degree | community | auto (label propagation, kept when it finds structure)
+    order_iters: int = 8
+    order_min_inside: float = 0.25
+    order_max_share: float = 0.125
+    order_min_n: int = 4096
+    # ---- exchange -------------------------------------------------------------------------------------------
+    exchange_rounds: int = 2         # boundary lists are cut into this many all-to-all-v rounds
+    # ---- GAT path -------------------------------------------------------------------------------------------
+    gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
+    gat_sliced: bool = True          # XCD-sliced edge gradient
+    gat_task_grad: bool = True       # edge gradient over the SpMM plan's balanced tasks
+    gat_multihead: bool = True       # all heads of attention @ Z in one launch
+
+
+def _parse(spec: str, base: Tuning) -> Tuning:
+    fields = {f.name: f for f in dataclasses.fields(Tuning)}
+    out = dataclasses.replace(base)
+    for item in filter(None, (x.strip() for x in spec.split(","))):
+        if "=" not in item:
+            raise ValueError("PGCN_TUNING: expected field=value, got %r" % item)
+        k, v = (x.strip() for x in item.split("=", 1))
+        if k not in fields:
+            raise ValueError("PGCN_TUNING: unknown field %r (known: %s)" % (k, ", ".join(sorted(fields))))
+        cur = getattr(base, k)
+        if isinstance(cur, bool):
+            val = v.lower() not in ("0", "false", "no", "off", "")
+        elif isinstance(cur, int):
+            val = int(v)
+        elif isinstance(cur, float):
+            val = float(v)
+        else:
+            val = v
+        setattr(out, k, val)
+    return out
+
+
+def load(env=None) -> Tuning:
+    """The defaults overridden by PGCN_TUNING (read from ``env``, default os.environ)."""
+    env = os.environ if env is None else env
+    return _parse(env.get("PGCN_TUNING", ""), Tuning())
+
+
+T = load()

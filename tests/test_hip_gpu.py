@@ -160,21 +160,6 @@ def test_spmm_dense_core_lds_kernel(K, dev, f, nslices):
         C4 = torch.empty((n, f), device=dev)
         K.spmm(d, torch.from_numpy(B2).to(dev), C4)
         assert np.isfinite(C4.cpu().numpy()).all()
-    # the one-launch variant (gather tasks + core pieces co-scheduled) is bit-identical
-    assert d.fused_work is not None
-    kinds = d.fused_work[:, 0].cpu().numpy()
-    assert (kinds == 1).sum() == d.core.npieces
-    assert int(d.fused_work[:, 2].sum()) == d.ntasks
-    was = K.fused
-    try:
-        K.fused = True
-        C5 = torch.full((n, f), float("nan"), device=dev)
-        K.spmm(d, Bd, C5)
-        C6 = torch.from_numpy(base).to(dev)
-        K.spmm(d, Bd, C6, accumulate=True)
-    finally:
-        K.fused = was
-    assert torch.equal(C5, C) and torch.equal(C6, C3)
 
 
 @pytest.mark.parametrize("f", [4, 30, 64, 128, 132, 256])
@@ -298,10 +283,9 @@ def test_spmm_strip_tiles(K, dev, f, nslices):
     assert rel_err(got[:, 1:], ref[:, 1:]) < TOL
 
 
-def test_spmm_variants_bit_identical(K, dev):
-    """The opt-in shapes of the launch group leave the SAME bits as the default one: the gather kernel in 64- / 32-
-    feature passes and as a persistent grid (PGCN_SPMM_FPASS64 / FPASS32 / PERSIST), and the half-footprint strip
-    kernel (pgcn_spmm_strip_half_f32) on a second stream next to it (PGCN_CORE_OVERLAP)."""
+def test_spmm_feature_passes_bit_identical(K, dev):
+    """The one opt-in shape of the launch group leaves the SAME bits as the default one: the gather kernel in 64-
+    feature passes (PGCN_SPMM_FPASS64, automatic on whole graphs) next to strips, MFMA tiles and sliced hub rows."""
     partition, _lib = pkg("partition"), pkg("_lib")
     rng = np.random.default_rng(77)
     n, m, f = 2100, 1500, 128
@@ -316,31 +300,22 @@ def test_spmm_variants_bit_identical(K, dev):
     assert h.strip is not None and h.dense is not None and h.col.numel() > 0
     d = K.prepare(h)
     Bd = torch.from_numpy(rng.random((m, f), dtype=np.float32) * 2 - 1).to(dev)
-    flags0, ov0 = K.base_flags, K.core_overlap
+    flags0 = K.base_flags
     try:
-        K.base_flags = flags0 & ~(_lib.SPMM_FPASS64 | _lib.SPMM_FPASS32 | _lib.SPMM_PERSIST)
+        K.base_flags = flags0 & ~_lib.SPMM_FPASS64
         d.launch_cache.clear()
         ref = torch.full((n, f), float("nan"), device=dev)
         K.spmm(d, Bd, ref)
         assert rel_err(ref.cpu().numpy(), oracle.spmm(A, Bd.cpu().numpy())) < TOL
-        for extra, overlap in ((_lib.SPMM_FPASS64, False), (_lib.SPMM_FPASS32, False), (_lib.SPMM_PERSIST, False),
-                               (_lib.SPMM_FPASS64 | _lib.SPMM_PERSIST, False), (0, True), (_lib.SPMM_FPASS64, True)):
-            K.base_flags = (flags0 & ~(_lib.SPMM_FPASS64 | _lib.SPMM_FPASS32 | _lib.SPMM_PERSIST)) | extra
-            K.core_overlap = overlap
-            d.launch_cache.clear()
-            C = torch.full((n, f), float("nan"), device=dev)
-            K.spmm(d, Bd, C)
-            torch.cuda.synchronize()
-            assert torch.equal(C, ref), (extra, overlap)
-    finally:
-        K.base_flags, K.core_overlap = flags0, ov0
+        K.base_flags = flags0 | _lib.SPMM_FPASS64
         d.launch_cache.clear()
-    # the half-footprint kernel refuses what it cannot stage (the caller then uses pgcn_spmm_strip_f32)
-    st = d.strip
-    ws = torch.empty(d.nslots_total * 6, device=dev)
-    rc = K.lib.pgcn_spmm_strip_half_f32(st.work.data_ptr(), st.npieces, st.rec.data_ptr(), st.pairs.data_ptr(), Bd.data_ptr(), f,
-                                        m, 6, ws.data_ptr(), ws.numel(), d.nslots_total, None)
-    assert rc == _lib.PGCN_EUNSUPPORTED
+        C = torch.full((n, f), float("nan"), device=dev)
+        K.spmm(d, Bd, C)
+        torch.cuda.synchronize()
+        assert torch.equal(C, ref)
+    finally:
+        K.base_flags = flags0
+        d.launch_cache.clear()
 
 
 def test_spmm_strip_pieces_and_panel_reuse(K, dev):

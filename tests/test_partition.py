@@ -219,26 +219,3 @@ def test_mfma_tiles_layout_and_bookkeeping():
     # switched off: everything dense goes to the LDS core
     h2 = partition.csr_from_scipy(A, nslices=1, core=True, tau=0.05, emax=3000, dense_tau=2.0, strip=False)
     assert h2.dense is None and h2.core.nnz == hd.nnz + h.core.nnz
-
-
-def test_fused_work_list_covers_everything_once():
-    """pgcn_spmm_fused_f32's unified work list: entry i runs on XCD i % 8; gather blocks of slice s sit in
-    queue s (8-sliced plan) and never cross a slice; every task and every core piece appears exactly once."""
-    kernels = pkg("kernels")
-    seg = [0, 37, 37, 100, 180, 181, 260, 300, 333]          # 8 slices, one empty
-    work = kernels.fused_work_list(seg, 8, 333, 21, gb=16)
-    assert work.shape[1] == 4 and work.shape[0] % 8 == 0
-    g = work[work[:, 0] == 0]
-    c = work[work[:, 0] == 1]
-    assert sorted(c[:, 1].tolist()) == list(range(21))
-    covered = np.concatenate([np.arange(b, b + n) for _, b, n, _ in g])
-    assert sorted(covered.tolist()) == list(range(333)) and g[:, 2].max() <= 16
-    pos = np.nonzero(work[:, 0] == 0)[0]
-    for p_, (_, b, n, _) in zip(pos, g):
-        s = p_ % 8
-        assert seg[s] <= b and b + n <= seg[s + 1]           # the block stays inside the slice of its XCD
-    assert set(np.unique(work[:, 0])) <= {0, 1, 2}
-    # unsliced plan: blocks are dealt round-robin
-    w1 = kernels.fused_work_list(None, 1, 50, 3, gb=16)
-    g1 = w1[w1[:, 0] == 0]
-    assert sorted(np.concatenate([np.arange(b, b + n) for _, b, n, _ in g1]).tolist()) == list(range(50))

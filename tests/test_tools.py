@@ -1,5 +1,5 @@
 """Offline tooling kept honest: the trace-driven L2 model (tools/l2sim) on a case small enough to count by hand, and
-the prepared-but-unmeasured kernel patch (tools/prototypes) still applying to the sources it was written against."""
+the single tuning object (tuning.Tuning / PGCN_TUNING) that replaced the package's 50 environment switches."""
 import ctypes
 import os
 import shutil
@@ -34,11 +34,31 @@ def test_l2sim_counts_by_hand(tmp_path):
     assert run(1, 1, 4, sets=1, ways=1) == (0, 24)
 
 
-@pytest.mark.skipif(shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")), reason="needs the git checkout")
-@pytest.mark.parametrize("name,src", [("fpass_sequential_grid.patch", "pgcn_spmm.hip"), ("dense_b_prefetch.patch", "pgcn_spmm_dense.hip")])
-def test_prototype_patch_still_applies(name, src):
-    patch = os.path.join(ROOT, "tools", "prototypes", name)
-    target = "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd/csrc/" + src
-    assert target in open(patch).read()
-    p = subprocess.run(["git", "apply", "--check", patch], cwd=ROOT, capture_output=True)
-    assert p.returncode == 0, p.stderr.decode()
+
+def test_tuning_is_read_once_from_one_variable():
+    from conftest import pkg
+    tuning = pkg("tuning")
+    d = tuning.load(env={})
+    assert d == tuning.Tuning() and d.strip_pieces == 1024 and d.exchange_rounds == 2 and d.fpass == "auto"
+    t = tuning.load(env={"PGCN_TUNING": "strip_pieces=256, strip_min_records=0,dense=0,dense_tau=0.2,order=degree"})
+    assert (t.strip_pieces, t.strip_min_records, t.dense, t.dense_tau, t.order) == (256, 0, False, 0.2, "degree")
+    with pytest.raises(ValueError):
+        tuning.load(env={"PGCN_TUNING": "no_such_knob=1"})
+    with pytest.raises(ValueError):
+        tuning.load(env={"PGCN_TUNING": "strip_pieces"})
+
+
+def test_package_reads_no_other_tuning_switch():
+    """at most a dozen environment switches in the package, none of them a kernel shape."""
+    import glob
+    import re
+    names = set()
+    pkgdir = os.path.join(ROOT, "scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd")
+    for fn in glob.glob(os.path.join(pkgdir, "*.py")) + glob.glob(os.path.join(pkgdir, "csrc", "*")):
+        if os.path.isfile(fn) and not fn.endswith((".o", ".so")):
+            with open(fn, errors="replace") as fh:
+                src = fh.read()
+            names |= set(re.findall(r'(?:environ\.get|environ\[|getenv)\(?\s*["\'](PG[A-Z]+_[A-Z0-9_]+)', src))
+    allowed = {"PGCN_TUNING", "PGCN_EXCHANGE", "PGCN_OVERLAP", "PGCN_INGEST", "PGCN_BACKEND", "PGCN_SEED", "PGAT_MODE",
+               "PGCN_STRIP_PROBE"}                 # (the last one only inside #ifdef PGCN_EXPERIMENTS)
+    assert names <= allowed, names - allowed

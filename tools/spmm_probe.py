@@ -91,9 +91,7 @@ def main():
         fpass = 0                        # _p64 / _p32: feature passes of the gather part
         if "_p" in name:
             name, fp = name.split("_p")
-            fpass = {"64": 16, "32": 32, "64s": 16 | 128, "32s": 32 | 128}[fp]   # s: passes as a 1-D grid (sequential)
-        fused = name.endswith("F")
-        name = name.rstrip("F")
+            fpass = {"64": 16}[fp]
         smode = ""                       # "r:" range slicing (uniform bounds), "d:" dealt order + range slicing
         if ":" in name:
             smode, name = name.split(":")
@@ -131,12 +129,12 @@ def main():
         if d is None:
             d = prepared[smode + name] = K.prepare(h)
         for tag, L in libs.items():
-            variants[name0 + ("@" + tag if tag else "")] = (d, sw, L, fused, fpass)
+            variants[name0 + ("@" + tag if tag else "")] = (d, sw, L, fpass)
     alg = 8 * nnz + 8 * (n + 1) + 2 * 4 * f * n
     C = torch.empty(n, f, device=dev)
 
     def run(name):
-        d, sw, L, K.fused, fpass = variants[name]
+        d, sw, L, fpass = variants[name]
         K.base_flags = (2 if sw else 0) | fpass
         if getattr(d, "_fpass", 0) != fpass:
             d.launch_cache.clear()
@@ -168,15 +166,15 @@ def main():
     split = {}
     if args.split:
         for name in variants:
-            d, sw, L, fz, fp = variants[name]
+            d, sw, L, fp = variants[name]
             tl = TimingLib(L)
-            variants[name] = (d, sw, tl, fz, fp)
+            variants[name] = (d, sw, tl, fp)
             d.launch_cache.clear()
             for _ in range(5):
                 run(name)
             torch.cuda.synchronize()
             split[name] = tl.summary()
-            variants[name] = (d, sw, L, fz, fp)
+            variants[name] = (d, sw, L, fp)
             d.launch_cache.clear()
     out = {}
     for name, ts in times.items():
