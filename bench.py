@@ -479,6 +479,9 @@ def self_launch(nproc):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # RCCL shares device buffers between the ranks of a node through HIP IPC handles; this image's host driver
+    # only supports the dmabuf flavour (the legacy mode fails with `hipIpcGetMemHandle: invalid argument`).  The
+    # image exports the variable already -- this only keeps a stripped-down environment from losing it.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // nproc)))
     return subprocess.call(cmd, env=env)

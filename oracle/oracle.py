@@ -346,16 +346,46 @@ class _Adam:
 
 def pgcn_train_np(A: sp.spmatrix, part: Sequence[int], P: int, weights: List[np.ndarray],
                   H0: np.ndarray, labels: np.ndarray, epochs: int = 5, lr: float = 1e-3,
-                  dtype=np.float64):
+                  dtype=np.float64, schedule=None):
     """GPU/PGCN.py:run() 194-226 with exact aggregation (no Q1-Q3 quirks).
 
     ``weights[l]`` is the ``nn.Linear`` weight (out x in) of layer l.  Returns
     (rank-0 loss per epoch, final weights).  Loss semantics follow the
     reference literally (Q4): every rank averages nll over ALL n rows of an
     n x f logits matrix whose non-owned rows are zero (PGCN.py:213-215), the
-    per-rank gradients are summed and divided by P (:150-154)."""
-    A = sp.csr_matrix(A).astype(dtype)
+    per-rank gradients are summed and divided by P (:150-154).
+
+    ``schedule`` (optional): one adjacency matrix per optimiser step instead of ``epochs`` steps on ``A`` -- the
+    mini-batch driver (GPU/PGCN-Mini-batch.py:252-296: every batch is a step on its induced sub-adjacency).  The
+    returned losses are then per STEP, summed over the ranks like :294 (mean nll + (P - 1) log f)."""
     part = np.asarray(part)
+    if schedule is not None:
+        n, f = H0.shape
+        Ws = [np.array(w, dtype=dtype) for w in weights]
+        opt = _Adam(Ws, lr)
+        H0 = H0.astype(dtype)
+        onehot = np.zeros((n, f), dtype=dtype)
+        onehot[np.arange(n), labels] = 1
+        losses = []
+        for At in schedule:
+            At = sp.csr_matrix(At).astype(dtype)
+            acts, pre, agg = [H0], [], []
+            for W in Ws:
+                AH = At @ acts[-1]
+                agg.append(AH)
+                pre.append(AH @ W.T)
+                acts.append(np.maximum(pre[-1], 0))
+            logp = _log_softmax(acts[-1])
+            losses.append(-(logp * onehot).sum() / n + (P - 1) * np.log(f))
+            g = (np.exp(logp) - onehot) / n / P
+            grads = [None] * len(Ws)
+            for l in range(len(Ws) - 1, -1, -1):
+                g = g * (pre[l] > 0)
+                grads[l] = g.T @ agg[l]
+                g = At.T @ (g @ Ws[l])
+            opt.step(grads)
+        return np.array(losses), Ws
+    A = sp.csr_matrix(A).astype(dtype)
     n, f = H0.shape
     Ws = [np.array(w, dtype=dtype) for w in weights]
     opt = _Adam(Ws, lr)

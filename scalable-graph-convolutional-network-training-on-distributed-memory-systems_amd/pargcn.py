@@ -150,7 +150,7 @@ def main(argv, kernels=None, out=None):
     if world > 1:
         # NCCL (= RCCL) process groups only move device tensors, gloo only host tensors here
         wire = dev if (dev.type == "cuda" and dist.get_backend() != "gloo") else torch.device("cpu")
-        tot, mx, el = st.to(wire), st.to(wire), elapsed.to(wire)
+        tot, mx, el = st.to(wire).clone(), st.to(wire).clone(), elapsed.to(wire).clone()   # (.to() on the same device aliases)
         dist.all_reduce(tot)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)

@@ -278,7 +278,6 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     TR, TC, NG, RW, SB = STRIP_TR, CORE_TC, STRIP_NG, STRIP_RW, STRIP_B
     min_entries = STRIP_MIN if min_entries is None else min_entries
     layer_min = min(STRIP_LAYER_MIN, max(1, min_entries)) if layer_min is None else layer_min
-    pieces = STRIP_PIECES if pieces is None else pieces
     dev = r64.device
     if r64.numel() == 0 or ncols < TC:       # (a panel is a window of 128 operand rows)
         return None, None
@@ -306,6 +305,11 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     nrec = int(lsel.sum())
     if nrec == 0:
         return None, None
+    if pieces is None:
+        # one piece writes 512 partial rows (256 KB ~ six records of LDS time): a piece wants >= ~40 records, and the
+        # number of pieces a multiple of the 256 one-workgroup CUs.  Measured r02 (82 k records: 1 024 pieces best of
+        # 512..1 536) and r03 (shards of 8.6 k / 14.9 k records: 256 best of 128 / 256 / 512)
+        pieces = min(STRIP_PIECES, max(256, 256 * int(round(nrec / 64.0 / 256.0))))
     in_s = lsel[linv] & ~deep
     rmap = torch.cumsum(lsel.to(torch.int64), 0) - 1
     e_rec = rmap[linv[in_s]]                                     # record of every strip entry (tile major, layer minor)
@@ -612,18 +616,41 @@ class Partition:
 
 
 EXCHANGE_ROUNDS = _T.exchange_rounds
+ROUND_MASS_PERMILLE = _T.round_mass_permille     # share of a boundary list's degree mass in every round's cut (0: equal rows)
 
 
-def _round_major(owner: torch.Tensor, size: int, rounds: int):
+def _round_major(owner: torch.Tensor, size: int, rounds: int, weight: Optional[torch.Tensor] = None,
+                 mass_permille: Optional[int] = None):
     """``owner`` lists, in slab order, the peer of every row of a (peer, degree-rank)-sorted slab.
     Returns (order, round_off): ``order`` permutes the slab into (round, peer, degree-rank) order
-    and ``round_off[r]`` are the size+1 absolute offsets of round r's per-peer segments."""
+    and ``round_off[r]`` are the size+1 absolute offsets of round r's per-peer segments.
+
+    Where a peer's list is cut.  With ``weight`` (the GLOBAL degree of every row's vertex: an integer both ends of
+    an exchange know) round r of a peer's list ends where the cumulative weight passes 1 - (1 - m)^(r+1) of the
+    list's total, m = ``mass_permille`` / 1000: the FIRST round then carries the few hub rows that hold most of the
+    stored entries (little to transfer, most of the halo product to overlap with the rest of the transfer), the
+    last round the long tail of light rows.  Integer arithmetic only: sender and receiver cut identical lists
+    identically on any device.  Without weights the lists are cut into equal row counts."""
     dev = owner.device
     m = int(owner.numel())
     cnt = torch.bincount(owner, minlength=size) if m else torch.zeros(size, dtype=torch.int64, device=dev)
     start = torch.cumsum(cnt, 0) - cnt
     idx = torch.arange(m, dtype=torch.int64, device=dev) - start[owner]
-    rnd = torch.clamp(idx * rounds // torch.clamp(cnt[owner], min=1), max=rounds - 1)
+    mass_permille = ROUND_MASS_PERMILLE if mass_permille is None else mass_permille
+    if weight is not None and rounds > 1 and 0 < mass_permille < 1000 and m:
+        w = weight.to(torch.int64).clamp(min=1)
+        cw = torch.cumsum(w, 0)
+        tot = torch.zeros(size, dtype=torch.int64, device=dev).index_add_(0, owner, w)
+        # (the slab is sorted by peer: a peer's first row sits at start[peer])
+        first = (cw - w)[torch.clamp(start, max=m - 1)]              # cumulative weight before a peer's first row
+        before = cw - w - first[owner]                               # weight of the peer's rows ahead of this one
+        rnd = torch.zeros(m, dtype=torch.int64, device=dev)
+        rest = 1000
+        for r in range(rounds - 1):                                  # boundary r at 1 - (1 - m)^(r+1), in 1/1000 (floor)
+            rest = rest * (1000 - mass_permille) // 1000
+            rnd += (before * 1000 >= tot[owner] * (1000 - rest)).to(torch.int64)
+    else:
+        rnd = torch.clamp(idx * rounds // torch.clamp(cnt[owner], min=1), max=rounds - 1)
     order = torch.argsort(rnd * size + owner, stable=True)
     seg = torch.bincount(rnd * size + owner, minlength=rounds * size).cpu().tolist() if m else [0] * (rounds * size)
     round_off, pos = [], 0
@@ -674,7 +701,7 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     theirs = (pcol == rank) & (prow != rank)
     suniq = torch.unique(prow[theirs] * n + grank[col[theirs]])
     p = _finish_partition(row[mine], col[mine], val[mine], n, part, rank, size, gorder, grank, suniq,
-                          int(row.numel()), with_transpose, rounds)
+                          int(row.numel()), with_transpose, rounds, gdeg)
     p.order_info = order_info
     return p
 
@@ -730,7 +757,7 @@ def build_partition_local(row: torch.Tensor, col: torch.Tensor, val: torch.Tenso
         src = torch.repeat_interleave(torch.arange(size, dtype=torch.int64), torch.tensor(in_list)).to(dev)
         suniq = torch.unique(src * n + recv_ids.to(dev))                              # (requesting rank, degree rank)
     return _finish_partition(row, col, val, n, part, rank, size, gorder, grank, suniq, int(nnz_global),
-                             with_transpose, rounds)
+                             with_transpose, rounds, gdeg)
 
 
 def _check_partvec(partvec, n: int, size: int, dev) -> torch.Tensor:
@@ -822,7 +849,8 @@ def vertex_order(row: torch.Tensor, col: torch.Tensor, n: int, gdeg: Optional[to
 
 def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Tensor, n: int, part: torch.Tensor,
                       rank: int, size: int, gorder: torch.Tensor, grank: torch.Tensor, suniq: torch.Tensor,
-                      nnz_global: int, with_transpose: bool, rounds: Optional[int]) -> Partition:
+                      nnz_global: int, with_transpose: bool, rounds: Optional[int],
+                      gdeg: Optional[torch.Tensor] = None) -> Partition:
     """Everything after the two global facts (degree ranking, who needs which of my rows):
     ``row_m/col_m/val_m`` are this rank's entries in GLOBAL coordinates."""
     dev = row_m.device
@@ -844,7 +872,8 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
     # (round, owner, degree rank)
     hkey = cp[~loc] * n + grank[c[~loc]]
     huniq, hinv = torch.unique(hkey, return_inverse=True)
-    h_order, h_round, round_recv_off = _round_major(huniq // n, size, R)
+    h_order, h_round, round_recv_off = _round_major(huniq // n, size, R,
+                                                    None if gdeg is None else gdeg[gorder[huniq % n]])
     newpos = torch.empty_like(h_order)
     newpos[h_order] = torch.arange(h_order.numel(), dtype=torch.int64, device=dev)
     hcol = newpos[hinv]                                   # halo-slab position of every halo entry
@@ -868,7 +897,7 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
         A_loc_T = csr_from_coo(g2l[c[loc]], r[loc], v[loc], n_p, n_p, core=CORE_ON)
 
     # rows of mine that other ranks need, in the peers' slab order (round, target rank, degree rank)
-    s_order, _, round_send_off = _round_major(suniq // n, size, R)
+    s_order, _, round_send_off = _round_major(suniq // n, size, R, None if gdeg is None else gdeg[gorder[suniq % n]])
     send_global = gorder[suniq % n][s_order]
     send_owner = (suniq // n)[s_order]
     send_idx = g2l[send_global].to(torch.int32)

@@ -39,8 +39,9 @@ class Tuning:
     strip: bool = True               # 512 x 128 strip tiles
     strip_min: int = 512             # stored entries that make a strip tile worth staging
     strip_layer_min: int = 384       # stored entries that make one more layer (record) of a tile worth it
-    strip_min_records: int = 16384   # blocks with fewer records keep the 128 x 128 LDS core instead
-    strip_pieces: int = 1024         # target number of strip work pieces
+    strip_min_records: int = 4096    # blocks with fewer records keep the 128 x 128 LDS core instead (r03: shards of an
+                                     # 8-way run: 1.1 k records lose, 4.9 k break even, 8.6 k and 14.9 k win 9-15 %)
+    strip_pieces: int = 1024         # upper bound of the strip work pieces (records / 64, in multiples of 256 CUs)
     strip_stage_cost: float = 1.0    # staging a panel ~ this many records of work (piece balancing)
     # ---- vertex order ---------------------------------------------------------------------------------------
     degree_sort: bool = True
@@ -51,6 +52,7 @@ class Tuning:
     order_min_n: int = 4096
     # ---- exchange -------------------------------------------------------------------------------------------
     exchange_rounds: int = 2         # boundary lists are cut into this many all-to-all-v rounds
+    round_mass_permille: int = 700   # ... at 1 - (1 - m)^(r+1) of a list's global-degree mass (0: equal row counts)
     # ---- GAT path -------------------------------------------------------------------------------------------
     gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
     gat_sliced: bool = True          # XCD-sliced edge gradient

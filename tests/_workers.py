@@ -275,3 +275,21 @@ def bench_inputs_worker(rank, P, port, kind, path, path_pv, q):
            "nnz_halo": sum(a.nnz for a in part.A_halo)})
     dist.barrier()
     dist.destroy_process_group()
+
+
+def pargcn_main_worker(rank, P, port, directory, seed, q):
+    """pargcn.main (the `grbgcn -p DIR -c CONFIG` command line of Parallel-GCN/main.c:120-165) with world > 1
+    over gloo, checker-backed kernels."""
+    _init(rank, P, port)
+    from conftest import pkg
+    from oracle_kernels import OracleKernels
+    os.environ["PGCN_SEED"] = str(seed)
+    buf = io.StringIO()
+    errs, Wn, Hout, part = pkg("pargcn").main(["-p", directory, "-c", os.path.join(directory, "config")],
+                                             kernels=OracleKernels(), out=buf)
+    q.put({"rank": rank, "stdout": buf.getvalue(), "errs": [float(e) for e in errs],
+           "W": {l: w.numpy() for l, w in Wn.items()}, "own": part.owned.numpy(), "H": Hout.numpy(),
+           "n_send": part.n_send, "n_halo": part.n_halo,
+           "targets": int(torch.unique(part.send_owner).numel()), "sources": int(torch.unique(part.halo_owner).numel())})
+    dist.barrier()
+    dist.destroy_process_group()

@@ -180,3 +180,44 @@ def test_run_from_binary_csr_shards_is_identical(tmp_path, monkeypatch):
     for a, b in zip(sh, base):
         for wa, wb in zip(a["weights"], b["weights"]):
             np.testing.assert_array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("case,P", [("karate_k2", 2), ("karate_k3", 3)])
+def test_pargcn_main_multi_rank(case, P):
+    """`pargcn.main` (the grbgcn command line, Parallel-GCN/main.c:120-165, :441-454, statistics
+    :506-524) with world > 1 on a directory the reference's own GCN-HP tool wrote: rank 0 prints the reference's
+    lines, every rank ends with the same weights, the numbers are the oracle's P-rank training loop."""
+    import re
+    from conftest import GOLDEN
+    io_, pargcn = pkg("pargcn_io"), pkg("pargcn")
+    directory = os.path.join(GOLDEN, "pargcn", case)
+    seed = 5
+    res = _spawn(_workers.pargcn_main_worker, P, directory, seed)
+    prob = io_.load_directory(directory)
+    d, n = prob["d"], prob["d"][0]
+    A = sp.csr_matrix(prob["A"])
+    err, Wc, Hl, st = oracle.pargcn_train(A, prob["part"], P, d, pargcn.init_weights(d, seed), np.ones((n, d[1]), np.float32),
+                                          prob["Y"], prob["Ymask"])
+    out0 = res[0]["stdout"]
+    assert out0.startswith("nlayers:%d\n" % prob["L"]) and (" ".join(str(x) for x in d) + " ") in out0
+    printed = [float(x) for x in re.findall(r"^err:(\S+)$", out0, re.M)]
+    assert len(printed) == 3
+    np.testing.assert_allclose(printed, err, rtol=1e-4)
+    assert re.search(r"^time : \d+\.\d+ secs$", out0, re.M)
+    for r in range(P):
+        np.testing.assert_allclose(res[r]["errs"], err, rtol=1e-5)
+        for l in Wc:
+            assert rel_err(res[r]["W"][l], Wc[l]) < 1e-5
+            assert np.array_equal(res[r]["W"][l], res[0]["W"][l])          # replicas stay identical
+        assert rel_err(res[r]["H"], Hl[res[r]["own"]]) < 1e-5
+        if r > 0:
+            assert "err:" not in res[r]["stdout"] and "time :" not in res[r]["stdout"]
+    # the statistics line (main.c:506-524): volumes in scalars, three epochs, widths f..f forward and 2, f.. backward
+    L = prob["L"]
+    widths = [d[l] for l in range(1, L)] + [d[l + 1] for l in range(L - 1, 0, -1)]
+    vol = [res[r]["n_send"] * sum(widths) * 3 for r in range(P)]
+    rcv = [res[r]["n_halo"] * sum(widths) * 3 for r in range(P)]
+    msg = [res[r]["targets"] * len(widths) * 3 for r in range(P)]
+    msr = [res[r]["sources"] * len(widths) * 3 for r in range(P)]
+    last = [int(x) for x in out0.strip().splitlines()[-1].split()]
+    assert last == [sum(vol), sum(vol) // P, max(vol), max(rcv), sum(msg), sum(msg) // P, max(msg), max(msr)]

@@ -527,6 +527,14 @@ def test_engine_halo_dense_core(K, dev, P, f, monkeypatch):
     Ac = sp.csr_matrix(A)
     assert rel_err(fwd, oracle.spmm(Ac, Hfull)) < TOL
     assert rel_err(bwd, oracle.spmm(sp.csr_matrix(A.T), Gfull)) < TOL
+    # power-law rows span three orders of magnitude: the PER-ROW bound of tests/test_fullsize_gpu.py against a
+    # float64 shadow, |got_i - ref_i| <= 1e-5 * sum_j |a_ij| |x_j| element-wise (a wrong low-degree row cannot hide
+    # behind a hub row's magnitude)
+    A64, absA = Ac.astype(np.float64), abs(Ac).astype(np.float64)
+    for got, M, Ma, X in ((fwd, A64, absA, Hfull), (bwd, A64.T.tocsr(), absA.T.tocsr(), Gfull)):
+        ref64, bound = M @ X.astype(np.float64), Ma @ np.abs(X).astype(np.float64)
+        worst = float((np.abs(got.astype(np.float64) - ref64) / (1e-5 * bound + 1e-30)).max())
+        assert worst <= 1.0, "a row exceeds 1e-5 * sum|a||x| by a factor %.3g" % worst
 
 
 @pytest.mark.parametrize("name,mtx,pv", TRAIN_CASES)

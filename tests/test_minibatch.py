@@ -67,3 +67,42 @@ def test_minibatch_multi_rank_is_partition_invariant(tmp_path):
     np.testing.assert_allclose(np.diff(got), np.diff(ref), atol=2e-3)
     m = re.search(r"total_vol: (\d+) total_nmsg: (\d+)", res[0]["stdout"])
     assert int(m.group(2)) > 0
+
+
+def test_minibatch_two_ranks_against_the_oracle_on_the_batches(tmp_path):
+    """P = 2 against the numpy restatement of the training loop run on the SAME batches
+    (random.seed(1) + random.sample as GPU/PGCN-Mini-batch.py:201-250; every batch = one Adam step on its induced
+    sub-adjacency): summed epoch losses as printed at :294-296 and the final weights."""
+    import random
+    import scipy.sparse as sp
+    import torch
+    from scipy.io import mmread
+    from conftest import pkg
+    from oracle import oracle
+    arrays, meta = _golden("ref_minibatch_gemat11pA")
+    f, bs, seed, P = meta["f"], meta["batch_size"], meta["seed"], 2
+    A = sp.csr_matrix(mmread(gpath(meta["mtx"]))).astype(np.float64)
+    n = A.shape[0]
+    part = [int(x) for x in np.random.default_rng(3).integers(0, P, n)]
+    pv = str(tmp_path / "pv2.pickle")
+    with open(pv, "wb") as fh:
+        pickle.dump(part, fh)
+    res = _spawn(P, gpath(meta["mtx"]), pv, f, bs, seed, False)
+    # the same batches, the same initial weights (torch.manual_seed(seed) then three PGCN layers)
+    MB = pkg("PGCN_minibatch")
+    random.seed(1)
+    nb = (n // bs + 1) * 3
+    batches = [MB.sample_adjacency_matrix(A.tocoo(), np.array(random.sample(range(0, n), bs))) for _ in range(nb)]
+    torch.manual_seed(seed)
+    model = MB.SequentialGCN(f, f)
+    W0 = [m.linear.weight.detach().numpy().astype(np.float64) for m in (model.gcn1, model.gcn2, model.gcn3)]
+    H0 = np.repeat(np.arange(n, dtype=np.float64)[:, None], f, 1)
+    labels = np.arange(n) % f
+    losses, Ws = oracle.pgcn_train_np(None, part, P, W0, H0, labels, schedule=batches * 5)      # 1 untimed + 4 printed epochs
+    per_epoch = float(P) + losses.reshape(5, nb).sum(1)[1:]      # every rank starts its sum at 1 (:273), then all-reduce
+    got = np.array(_losses(res[0]["stdout"]))
+    np.testing.assert_allclose(got, per_epoch, rtol=2e-4)
+    for r in range(P):
+        for i, w in enumerate(res[r]["weights"]):
+            assert rel_err(w, Ws[i]) < 5e-4
+            assert np.array_equal(w, res[0]["weights"][i])
