@@ -324,12 +324,17 @@ int oracle_pargcn_train(int64_t n, const int64_t *rowptr, const int32_t *col,
             memset(dW, 0, (size_t)fi * fo * sizeof(float));
             for (int32_t p = 0; p < P; p++) {
                 memset(dWp, 0, (size_t)fi * fo * sizeof(float));
-                for (int64_t i = 0; i < n; i++) {
-                    if (part[i] != p) continue;
-                    const float *h = H[layer - 1] + i * fi;
-                    const float *g = AH + i * fo;
-                    for (int32_t a = 0; a < fi; a++)
-                        for (int32_t b = 0; b < fo; b++) dWp[a * fo + b] += h[a] * g[b];
+                /* every thread owns rows `a` of dW and walks the vertices in ascending order: the additions into one
+                 * element happen in the order of the serial loop (bit-identical to it), all host cores busy */
+#pragma omp parallel for schedule(static)
+                for (int32_t a = 0; a < fi; a++) {
+                    float *dst = dWp + (int64_t)a * fo;
+                    for (int64_t i = 0; i < n; i++) {
+                        if (part[i] != p) continue;
+                        const float ha = H[layer - 1][i * fi + a];
+                        const float *g = AH + i * fo;
+                        for (int32_t b = 0; b < fo; b++) dst[b] += ha * g[b];
+                    }
                 }
                 for (int32_t e = 0; e < fi * fo; e++) dW[e] += dWp[e];
             }

@@ -168,6 +168,7 @@ class HipKernels:
             self.base_flags |= _lib.SPMM_FPASS64
         self.chunk = chunk
         self.small_row = small_row
+        self.adaptive_chunk = _T.spmm_adaptive_chunk
 
     # -- data placement -------------------------------------------------
     def prepare(self, csr: HostCSR, pattern_only: bool = False) -> DeviceCSR:
@@ -175,7 +176,14 @@ class HipKernels:
         rowptr_host = csr.rowptr.detach().cpu().numpy()
         sc = None if csr.slice_cnt is None else csr.slice_cnt.detach().cpu().numpy()
         rf = None if csr.row_flags is None else csr.row_flags.detach().cpu().numpy()
-        tasks, fix, nslots, seg = build_plan(rowptr_host, self.chunk, sc, self.small_row,
+        # a task is a latency chain of chunk / 8 gather batches (~0.7 us each): on a small block (a rank's shard of an
+        # 8-way run) a 1 024-entry task outlasts the rest of the kernel, so the chunk shrinks with the block --
+        # entries / 8 192, between 64 and the configured chunk (r03: tools/probes_r03, emulated ranks)
+        chunk = self.chunk
+        if self.adaptive_chunk:
+            e = max(int(csr.col.numel()), 1) // 8192
+            chunk = min(self.chunk, max(64, 1 << max(e.bit_length() - 1, 0)))
+        tasks, fix, nslots, seg = build_plan(rowptr_host, chunk, sc, self.small_row,
                                              force=csr.row_map is not None, row_flags=rf,
                                              ngroups=csr.ngroups)
         d = DeviceCSR(

@@ -616,41 +616,23 @@ class Partition:
 
 
 EXCHANGE_ROUNDS = _T.exchange_rounds
-ROUND_MASS_PERMILLE = _T.round_mass_permille     # share of a boundary list's degree mass in every round's cut (0: equal rows)
 
 
-def _round_major(owner: torch.Tensor, size: int, rounds: int, weight: Optional[torch.Tensor] = None,
-                 mass_permille: Optional[int] = None):
+def _round_major(owner: torch.Tensor, size: int, rounds: int):
     """``owner`` lists, in slab order, the peer of every row of a (peer, degree-rank)-sorted slab.
     Returns (order, round_off): ``order`` permutes the slab into (round, peer, degree-rank) order
     and ``round_off[r]`` are the size+1 absolute offsets of round r's per-peer segments.
 
-    Where a peer's list is cut.  With ``weight`` (the GLOBAL degree of every row's vertex: an integer both ends of
-    an exchange know) round r of a peer's list ends where the cumulative weight passes 1 - (1 - m)^(r+1) of the
-    list's total, m = ``mass_permille`` / 1000: the FIRST round then carries the few hub rows that hold most of the
-    stored entries (little to transfer, most of the halo product to overlap with the rest of the transfer), the
-    last round the long tail of light rows.  Integer arithmetic only: sender and receiver cut identical lists
-    identically on any device.  Without weights the lists are cut into equal row counts."""
+    A peer's list is cut into equal ROW counts.  (r03 also measured cutting at a share of the list's global-degree
+    mass, so that a small first round carries the hub rows: on every shard shape the two medium halo products
+    then cost more than one large + one small, and with one peer per xGMI link the larger second transfer is
+    exposed -- worse at P = 2, 4 and 8 under every link speed assumed: DESIGN.md section 5.)"""
     dev = owner.device
     m = int(owner.numel())
     cnt = torch.bincount(owner, minlength=size) if m else torch.zeros(size, dtype=torch.int64, device=dev)
     start = torch.cumsum(cnt, 0) - cnt
     idx = torch.arange(m, dtype=torch.int64, device=dev) - start[owner]
-    mass_permille = ROUND_MASS_PERMILLE if mass_permille is None else mass_permille
-    if weight is not None and rounds > 1 and 0 < mass_permille < 1000 and m:
-        w = weight.to(torch.int64).clamp(min=1)
-        cw = torch.cumsum(w, 0)
-        tot = torch.zeros(size, dtype=torch.int64, device=dev).index_add_(0, owner, w)
-        # (the slab is sorted by peer: a peer's first row sits at start[peer])
-        first = (cw - w)[torch.clamp(start, max=m - 1)]              # cumulative weight before a peer's first row
-        before = cw - w - first[owner]                               # weight of the peer's rows ahead of this one
-        rnd = torch.zeros(m, dtype=torch.int64, device=dev)
-        rest = 1000
-        for r in range(rounds - 1):                                  # boundary r at 1 - (1 - m)^(r+1), in 1/1000 (floor)
-            rest = rest * (1000 - mass_permille) // 1000
-            rnd += (before * 1000 >= tot[owner] * (1000 - rest)).to(torch.int64)
-    else:
-        rnd = torch.clamp(idx * rounds // torch.clamp(cnt[owner], min=1), max=rounds - 1)
+    rnd = torch.clamp(idx * rounds // torch.clamp(cnt[owner], min=1), max=rounds - 1)
     order = torch.argsort(rnd * size + owner, stable=True)
     seg = torch.bincount(rnd * size + owner, minlength=rounds * size).cpu().tolist() if m else [0] * (rounds * size)
     round_off, pos = [], 0
@@ -701,7 +683,7 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     theirs = (pcol == rank) & (prow != rank)
     suniq = torch.unique(prow[theirs] * n + grank[col[theirs]])
     p = _finish_partition(row[mine], col[mine], val[mine], n, part, rank, size, gorder, grank, suniq,
-                          int(row.numel()), with_transpose, rounds, gdeg)
+                          int(row.numel()), with_transpose, rounds)
     p.order_info = order_info
     return p
 
@@ -757,7 +739,7 @@ def build_partition_local(row: torch.Tensor, col: torch.Tensor, val: torch.Tenso
         src = torch.repeat_interleave(torch.arange(size, dtype=torch.int64), torch.tensor(in_list)).to(dev)
         suniq = torch.unique(src * n + recv_ids.to(dev))                              # (requesting rank, degree rank)
     return _finish_partition(row, col, val, n, part, rank, size, gorder, grank, suniq, int(nnz_global),
-                             with_transpose, rounds, gdeg)
+                             with_transpose, rounds)
 
 
 def _check_partvec(partvec, n: int, size: int, dev) -> torch.Tensor:
@@ -849,8 +831,7 @@ def vertex_order(row: torch.Tensor, col: torch.Tensor, n: int, gdeg: Optional[to
 
 def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Tensor, n: int, part: torch.Tensor,
                       rank: int, size: int, gorder: torch.Tensor, grank: torch.Tensor, suniq: torch.Tensor,
-                      nnz_global: int, with_transpose: bool, rounds: Optional[int],
-                      gdeg: Optional[torch.Tensor] = None) -> Partition:
+                      nnz_global: int, with_transpose: bool, rounds: Optional[int]) -> Partition:
     """Everything after the two global facts (degree ranking, who needs which of my rows):
     ``row_m/col_m/val_m`` are this rank's entries in GLOBAL coordinates."""
     dev = row_m.device
@@ -872,8 +853,7 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
     # (round, owner, degree rank)
     hkey = cp[~loc] * n + grank[c[~loc]]
     huniq, hinv = torch.unique(hkey, return_inverse=True)
-    h_order, h_round, round_recv_off = _round_major(huniq // n, size, R,
-                                                    None if gdeg is None else gdeg[gorder[huniq % n]])
+    h_order, h_round, round_recv_off = _round_major(huniq // n, size, R)
     newpos = torch.empty_like(h_order)
     newpos[h_order] = torch.arange(h_order.numel(), dtype=torch.int64, device=dev)
     hcol = newpos[hinv]                                   # halo-slab position of every halo entry
@@ -897,7 +877,7 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
         A_loc_T = csr_from_coo(g2l[c[loc]], r[loc], v[loc], n_p, n_p, core=CORE_ON)
 
     # rows of mine that other ranks need, in the peers' slab order (round, target rank, degree rank)
-    s_order, _, round_send_off = _round_major(suniq // n, size, R, None if gdeg is None else gdeg[gorder[suniq % n]])
+    s_order, _, round_send_off = _round_major(suniq // n, size, R)
     send_global = gorder[suniq % n][s_order]
     send_owner = (suniq // n)[s_order]
     send_idx = g2l[send_global].to(torch.int32)

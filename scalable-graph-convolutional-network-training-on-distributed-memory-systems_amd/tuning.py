@@ -19,7 +19,8 @@ from dataclasses import dataclass
 @dataclass
 class Tuning:
     # ---- gather kernel (spmm_tasks_kernel) plan ---------------------------------------------------------
-    spmm_chunk: int = 1024           # entries per task of a long row
+    spmm_chunk: int = 1024           # entries per task of a long row ...
+    spmm_adaptive_chunk: bool = True # ... shrunk on small blocks (entries / 8192, >= 64): a task is a latency chain
     spmm_small_row: int = 96         # rows up to this many entries are ONE unsliced task
     group_min_row: int = 4096        # column groups (explicit `ngroups` only) cut rows at least this long
     fpass: str = "auto"              # 64-feature passes of the gather part: auto (whole graphs, f > 64) | 64 | 0
@@ -31,7 +32,8 @@ class Tuning:
     tiles: bool = True               # split dense regions off the gather part at all
     core_tau: float = 0.05           # 128 x 128 LDS core: minimum tile fill
     core_emax: int = 0               # entries per core piece (0 = adaptive)
-    core_min_nnz: int = 262144       # a smaller tiled part does not pay for its launches
+    core_min_nnz: int = 2000000      # a smaller tiled part does not pay for its three extra launches (r03: the 1.7 M-entry
+                                     # local block of an 8-way shard runs 0.067 ms gather-only, 0.099 ms tiled)
     core_min_frac: float = 0.1
     dense: bool = True               # fp32-MFMA tiles
     dense_tau: float = 0.30          # tiles at least this full go to the matrix cores
@@ -52,7 +54,6 @@ class Tuning:
     order_min_n: int = 4096
     # ---- exchange -------------------------------------------------------------------------------------------
     exchange_rounds: int = 2         # boundary lists are cut into this many all-to-all-v rounds
-    round_mass_permille: int = 700   # ... at 1 - (1 - m)^(r+1) of a list's global-degree mass (0: equal row counts)
     # ---- GAT path -------------------------------------------------------------------------------------------
     gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
     gat_sliced: bool = True          # XCD-sliced edge gradient

@@ -422,3 +422,85 @@ def test_edge_gradient_over_plan_tasks(K, dev, mode, heads, d, nslices, chunk):
     de2, ds2 = torch.empty_like(de1), torch.empty_like(ds1)
     K.gat_edge_grad_tasks(dA, s1, s2, alpha, beta, Zd, dOut, t, heads, d, 0.2, mode_id, de2, ds2)
     assert torch.equal(de1, de2) and torch.equal(ds1, ds2)            # deterministic
+
+
+def test_full_size_gat_shard_rank_of_four(K, dev):
+    """BASELINE config 5 names FOUR GPUs: rank 2 of a 4-way random partition of the Reddit-sized graph (4 heads x
+    64) with the exchange emulated on the one GPU (the halo rows of [Z | s2] come from global data the test holds;
+    peers return nothing in backward, so dZ holds exactly this rank's own contributions).  Sampled owned rows of the
+    forward, sampled owned AND halo rows of the backward against a float64 recomputation of the reference's layer on
+    the stored entries (GPU/PGAT.py:138-151, standard mode), incl. the packed slab being exactly the send rows."""
+    from test_fullsize_gpu import _Exchanger
+    synth, partition, gat = pkg("synth"), pkg("partition"), pkg("gat")
+    n, row, col, val = synth.make_graph("reddit", seed=0, device=dev)
+    P, r, heads, d = 4, 2, 4, 64
+    F = heads * d
+    pv = synth.random_partvec(n, P, seed=0)
+    part = partition.build_partition(row, col, val, n, pv, r, P, with_transpose=False)
+    ex = _Exchanger()
+    eng = gat.GatEngine(part, K, dev, ex, mode="standard")
+    n_p, n_h = part.n_local, part.n_halo
+    assert eng.size == 4 and n_h > 0.5 * n * (P - 1) / P and abs(n_p - n / P) < 0.05 * n / P
+    Fp = eng.padded_width(F, heads)
+    gen = torch.Generator(device=dev); gen.manual_seed(11)
+    Zg = torch.randn(n, F, device=dev, generator=gen)
+    s1g = torch.randn(n, heads, device=dev, generator=gen)
+    s2g = torch.randn(n, heads, device=dev, generator=gen)
+    Gg = torch.randn(n, F, device=dev, generator=gen)
+    own, halo = part.owned.to(dev), part.halo_global.to(dev)
+    panel = torch.zeros(n, Fp, device=dev)
+    panel[:, :F], panel[:, F:F + heads] = Zg, s2g
+    st = eng.new_layer_state(heads, d)
+    ex.begin(panel[halo])
+    out = eng.forward(st, Zg[own], s1g[own], s2g[own])
+    torch.cuda.synchronize()
+    assert torch.equal(ex.sent, panel[part.send_global.to(dev)])           # the packed slab: exactly the rows peers need
+    # ---- forward rows against float64 (global graph: a row's neighbours are its stored entries) ----------
+    deg = torch.bincount(row, minlength=n)
+    order = own[torch.argsort(-deg[own])]
+    sample = torch.cat([order[:3], order[n_p // 2:n_p // 2 + 3], order[-3:]])
+    pos = torch.full((n,), -1, dtype=torch.int64, device=dev); pos[own] = torch.arange(n_p, device=dev)
+
+    rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rp[1:] = torch.cumsum(deg, 0)                                           # (make_graph returns (row, col)-sorted entries)
+
+    def alpha_of_row(i):
+        cols = col[int(rp[i]):int(rp[i + 1])]
+        raw = s1g[i].double()[None, :] + s2g[cols].double()
+        e = torch.where(raw > 0, raw, 0.2 * raw)
+        w = torch.exp(e - e.max(0).values)
+        return cols, w / w.sum(0)                                            # [deg, heads]
+    for i in sample.tolist():
+        cols, w = alpha_of_row(i)
+        exp = torch.einsum("jk,jkd->kd", w, Zg[cols].double().view(-1, heads, d)).reshape(F)
+        assert rel_err(out[pos[i]].cpu().numpy(), exp.cpu().numpy()) < 2e-5
+    # ---- backward: peers return nothing -> dZ_j, ds2_j hold the contributions of MY rows only ------------------
+    ex.begin(torch.zeros(part.n_send, Fp, device=dev))
+    dZ, ds1, ds2 = eng.backward(st, Gg[own])
+    torch.cuda.synchronize()
+    sent = ex.sent                                                          # [dZ | ds2] partial rows of the halo vertices
+    mine = pv.to(dev)[row] == r
+    rr, cc = row[mine], col[mine]
+    # float64 edge quantities of my rows that touch a sampled column j:  dZ_j = sum_i alpha_ij dOut_i ;  ds2_j = sum_i de_ij
+    hsel = torch.randperm(n_h, device=dev, generator=gen)[:4]
+    osel = order[torch.tensor([40, n_p // 2, n_p - 1], device=dev)]          # a hub, a middle and a light owned vertex
+    targets = [(int(halo[h]), sent[h]) for h in hsel.tolist()] + \
+              [(int(j), torch.cat([dZ[pos[j]], ds2[pos[j]], torch.zeros(Fp - F - heads, device=dev)])) for j in osel.tolist()]
+    for j, got in targets:
+        rows_j = rr[cc == j]
+        accZ = torch.zeros(heads, d, dtype=torch.float64, device=dev)
+        accS = torch.zeros(heads, dtype=torch.float64, device=dev)
+        for i in rows_j.tolist():
+            cols, w = alpha_of_row(i)
+            k = int(torch.nonzero(cols == j)[0])
+            go = Gg[i].double().view(heads, d)
+            accZ += w[k][:, None] * go
+            # softmax backward: dp_ij = <dOut_i, Z_j> ; de_ij = alpha_ij (dp_ij - sum_l alpha_il dp_il) ; LeakyReLU'
+            dp = torch.einsum("kd,jkd->jk", go, Zg[cols].double().view(-1, heads, d))
+            de = w * (dp - (w * dp).sum(0, keepdim=True))
+            raw = s1g[i].double()[None, :] + s2g[cols].double()
+            de = de * torch.where(raw > 0, torch.ones_like(raw), torch.full_like(raw, 0.2))
+            accS += de[k]
+        scale = max(float(accZ.abs().max()), 1e-12)
+        assert float((got[:F].double().view(heads, d) - accZ).abs().max()) < 2e-5 * scale + 1e-7, j
+        assert float((got[F:F + heads].double() - accS).abs().max()) < 5e-5 * max(float(accS.abs().max()), 1e-6) + 1e-7, j

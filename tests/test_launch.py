@@ -174,3 +174,65 @@ def test_bench_sbm_generator_line():
     assert rec["config"]["generator"] == "sbm" and "planted-partition" in rec["config"]["workload"]
     assert rec["config"]["vertex_order"]["order"] == "community"
     assert rec["roofline"]["split_us"] and "error" not in rec["roofline"]["split_us"]
+
+
+@pytest.mark.gpu
+def test_bench_from_binary_shards_papers_shape_two_ranks(tmp_path):
+    """BASELINE config 4 (papers100M, GCN-GP part vector, f = 64, L = 2) rehearsed at 1/64 scale: rank-local generator
+    -> binary CSR shards -> `bench.py --shards PREFIX` with two ranks over gloo.  No process ever holds the global
+    matrix (the reference parses all of it on every rank, GPU/PGCN.py:171); the part vector is the one the reference's
+    own METIS front-end (GPU/graph/main.cpp) wrote for the union of the shards (tools/make_partvecs.py
+    --generator shardstream), so the exchanged volume is that tool's cut."""
+    from conftest import GOLDEN
+    pv = os.path.join(GOLDEN, "partvec", "papers64.A.mtx.2.gp.gz")
+    with open(os.path.join(GOLDEN, "partvec", "papers64.stats.json")) as fh:
+        stats = json.load(fh)
+    prefix = str(tmp_path / "papers64")
+    mk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_shards.py"), "--workload", "papers", "--scale", "0.015625",
+                         "--ranks", "2", "--partvec", pv, "--out", prefix, "--device", "cuda"], env=_env(),
+                        capture_output=True, text=True, timeout=1200)
+    assert mk.returncode == 0, mk.stderr[-3000:]
+    assert os.path.exists(prefix + ".0.pgcsr") and os.path.exists(prefix + ".1.pgcsr")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shards", prefix, "--partvec", pv,
+                          "--features", "64", "--layers", "2", "--steps", "2", "--warmup", "1"],
+                         env=_env(PGCN_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and cfg["n"] == stats["n"] == 1735311 and cfg["nnz"] == stats["nnz"]
+    assert cfg["f"] == 64 and cfg["layers"] == 2 and "binary CSR shards" in cfg["source"]
+    assert cfg["partition"] == "file:papers64.A.mtx.2.gp.gz"
+    rows = stats["parts"]["2"]["gp"]["boundary_rows_per_aggregation"]
+    assert rec["exchange_rows_total"] == rows * 2 * 2 * 3           # (warm-up + steps) epochs x 2L aggregations
+    assert rows < stats["parts"]["2"]["rp"]["boundary_rows_per_aggregation"]
+    assert np.isfinite(rec["loss"]) and rec["value"] > 0 and rec["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gat_two_ranks_share_the_gpu():
+    """BASELINE config 5 is a multi-GPU GAT: `bench.py --workload reddit-gat --gpus 2` (ranks share the GPU over gloo,
+    real attention kernels, Reddit-sized shards) prints the same kind of line as the GCN bench."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "reddit-gat",
+                          "--steps", "2", "--warmup", "1"], env=_env(PGCN_BENCH_BACKEND="gloo"),
+                         capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["n_gpus"] == 2 and rec["config"]["heads"] == 4 and rec["config"]["head_dim"] == 64
+    assert rec["config"]["partition"].startswith("random") and rec["exchange_rows_total"] > 0
+    assert np.isfinite(rec["loss"]) and rec["value"] > 0
+    assert rec["roofline"] and rec["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_emulated_rank_line():
+    """`--emulate-rank r/P`: one GPU runs the compute of rank r of a P-rank job (the shard shapes 2/4/8 GPUs run),
+    with a roofline object for the local block and one per halo launch group."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mid", "--emulate-rank", "1/4",
+                          "--steps", "3", "--warmup", "1"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    assert rec["n_gpus"] == 1 and rec["config"]["emulated_rank"] == "1/4" and rec["cpu_baseline"] is None
+    shape = rec["config"]["rank_shape"]
+    assert shape["n_halo"] > 0 and shape["nnz_halo_blocks"] > 0 and abs(shape["n_local"] - 131072 / 4) < 2000
+    assert len(rec["halo_groups"]) == rec["config"]["exchange_rounds"] and all(h["frac"] > 0 for h in rec["halo_groups"])
+    assert rec["roofline"]["frac"] > 0 and "COMPUTE of rank 1/4" in rec["metric"]

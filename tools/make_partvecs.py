@@ -45,8 +45,11 @@ def main():
     ap.add_argument("--workload", default="mid")
     ap.add_argument("--k", default="2,4,8")
     ap.add_argument("--work", default="/tmp/pgcn_partvec")
-    ap.add_argument("--generator", default="rmat", choices=["rmat", "sbm"],
-                    help="sbm: the planted-partition stand-in (portable stream: the same graph on the GPU box)")
+    ap.add_argument("--generator", default="rmat", choices=["rmat", "sbm", "shardstream"],
+                    help="sbm: the planted-partition stand-in (portable stream: the same graph on the GPU box); "
+                         "shardstream: the union of the rank-local shards tools/make_shards.py generates "
+                         "(synth.rmat_shard_keys: papers-scale workloads, with --scale)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shardstream: shrink n and nnz of the workload by this factor")
     ap.add_argument("--tools", default="hp,gp", help="which of the reference's front-ends to run")
     ap.add_argument("--graph-name", default=None, help="a synth.SHAPES name, or (with --n/--nnz) a free label")
     ap.add_argument("--n", type=int, default=None)
@@ -58,7 +61,12 @@ def main():
     os.makedirs(args.work, exist_ok=True)
     hp, gp = build_tools(args.work)
     tools = args.tools.split(",")
-    if args.n:
+    if args.generator == "shardstream":
+        n0, nnz0, _, _ = synth.SHAPES[args.workload]
+        n, pairs = max(64, int(n0 * args.scale)), max(64, int(nnz0 * args.scale) // 2)       # as tools/make_shards.py
+        keys = synth.rmat_shard_keys(n, pairs, 0, torch.zeros(n, dtype=torch.int64), seed=0)
+        row, col, val = synth.shard_normalize(n, keys, torch.bincount(keys // n, minlength=n))
+    elif args.n:
         n, row, col, val = synth.make_graph(args.n, args.nnz, seed=0, generator=args.generator)
     else:
         n, row, col, val = synth.make_graph(args.workload, seed=0, generator=args.generator)
