@@ -313,7 +313,7 @@ def acquire_partition(args, rank, world, dev, stage, with_transpose=True):
     return part, info
 
 
-def pmc_traffic_for(args, world, f):
+def pmc_traffic_for(args, world, f, block="loc"):
     """(bytes or None, note): L2<->fabric bytes of the dominant launch group from the committed rocprofv3 --pmc
     passes (profiles/pmc_traffic.json: one record per (workload, generator, ranks, f)), valid only for the kernel
     sources they were taken on (sha256 stamp)."""
@@ -331,7 +331,7 @@ def pmc_traffic_for(args, world, f):
     for rec in recs:
         same = (rec.get("workload") == args.workload and str(rec.get("ranks", rec.get("n_gpus"))) == ranks
                 and rec.get("f") == f and rec.get("generator", "rmat") == args.generator
-                and rec.get("partvec", "random") == os.path.basename(args.partvec))
+                and rec.get("partvec", "random") == os.path.basename(args.partvec) and rec.get("block", "loc") == block)
         if not same:
             continue
         if rec.get("source_stamp") == kernel_source_stamp():
@@ -680,7 +680,8 @@ def main():
             if havg:
                 halg = 8 * Ah.nnz + 8 * (Ah.nrows + 1) + 4 * f * (part.round_recv_off[r][-1] - part.round_recv_off[r][0]) \
                     + 2 * 4 * f * part.n_local                   # C is read and written (accumulate)
-                halo_groups.append({"round": r, "nnz": Ah.nnz, "avg_launch_ms": havg, "launches_timed": hl,
+                htraffic, _ = pmc_traffic_for(args, world, f, "halo%d" % r)
+                halo_groups.append({"round": r, "nnz": Ah.nnz, "avg_launch_ms": havg, "launches_timed": hl, "traffic": htraffic,
                                     "alg_bytes_per_launch": halg, "achieved": halg / (havg * 1e-3) / 1e9, "unit": "GB/s",
                                     "frac": halg / (havg * 1e-3) / HBM_PEAK, "ps_per_entry": 1e9 * havg / max(Ah.nnz, 1)})
         if roofline is not None:

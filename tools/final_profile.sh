@@ -1,22 +1,52 @@
 #!/bin/bash
-# Round evidence: GPU tests, smoke, default bench, rocprofv3 kernel stats of the bench command, PMC traffic passes,
-# second shapes (products, SBM, GAT).  usage: bash tools/final_profile.sh r02   (under gpurun)
+# Round evidence in one gpurun call: GPU tests, smoke, default bench, rocprofv3 kernel stats of the bench command, PMC
+# traffic passes per launch group (tools/group_probe.py: the block exactly as bench.py builds it), the other workloads
+# (products, SBM, mid, GAT) and the shard shapes (--emulate-rank).  usage: bash tools/final_profile.sh r03 [hp-partvec]
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-tag=${1:-r02}
+tag=${1:-r03}
+HP=${2:-tests/golden/partvec/products-sbm.A.mtx.8.hp.gz}
 out=gpurun_out/final_$tag; rm -rf $out; mkdir -p $out
-timeout 2400 python -m pytest tests -m gpu -x -q > $out/pytest_gpu_full.txt 2>&1; grep -E "passed|failed|error" $out/pytest_gpu_full.txt | tail -3 | tee $out/pytest_gpu.txt
+timeout 2400 python -m pytest tests -m gpu -q > $out/pytest_gpu_full.txt 2>&1; grep -E "passed|failed|error" $out/pytest_gpu_full.txt | tail -3 | tee $out/pytest_gpu.txt
 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $out/smoke.txt
-python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1500 $out/bench.json; echo
+python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1200 $out/bench.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/prof_stdout.log 2> $out/prof_stderr.log
 rm -f $out/prof/*kernel_trace.csv $out/prof/*/*kernel_trace.csv
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
-  t=$(echo "$set" | tr ' ' '+')
-  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm" --output-format csv -d $out/pmc/$t -- python tools/spmm_probe.py --once s8c1024k_p64 > $out/pmc_$t.log 2>&1
-done
-python tools/pmc_summary.py $out/pmc spmm > $out/pmc_summary.txt; grep -v kernel_trace $out/pmc_summary.txt | head -40
-python tools/make_pmc_traffic.py $out/pmc_summary.txt $out/pmc_traffic.json profiles/${tag}_pmc_final.txt
+pmc() {  # name, then the record key: workload generator ranks f partvec block, then group_probe arguments
+  name=$1; key="$2 $3 $4 $5 $6 $7"; shift 7
+  for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    t=$(echo "$set" | tr ' ' '+')
+    rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm" --output-format csv -d $out/pmc_$name/$t -- python tools/group_probe.py "$@" > $out/pmc_${name}_$t.log 2>&1
+  done
+  python tools/pmc_summary.py $out/pmc_$name spmm > $out/pmc_summary_$name.txt
+  python tools/make_pmc_traffic.py $out/pmc_summary_$name.txt $out/pmc_traffic.json profiles/${tag}_pmc_$name.txt $key
+  rm -rf $out/pmc_$name
+}
+pmc reddit      reddit rmat 1 128 random loc
+pmc reddit_r8h0 reddit rmat 0/8 128 random halo0 --emulate-rank 0/8 --block halo0
+pmc reddit_r8l  reddit rmat 0/8 128 random loc --emulate-rank 0/8 --block loc
+pmc products    products rmat 1 128 random loc --workload products
+pmc reddit_sbm  reddit sbm 1 128 random loc --generator sbm
+cp $out/pmc_traffic.json profiles/pmc_traffic.json      # (bench.py reads it from there for the lines below)
+python bench.py --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_with_traffic.json 2>/dev/null
 python bench.py --workload products --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_products.json 2>/dev/null
 python bench.py --generator sbm --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_sbm.json 2>/dev/null
+python bench.py --workload mid --steps 10 --warmup 2 > $out/bench_mid.json 2>/dev/null
 python bench.py --workload reddit-gat --steps 5 --warmup 2 > $out/bench_gat.json 2>/dev/null
-for f in products sbm gat; do python -c "
-import json;r=json.load(open('$out/bench_$f.json'));print('$f', round(r['ms_per_step'],3), r['roofline']['avg_launch_ms'], r['roofline'].get('split_us'))"; done
+for rp in 0/8 3/8 7/8 0/4 0/2; do t=$(echo $rp | tr '/' '_')
+  python bench.py --emulate-rank $rp --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rank_$t.json 2>/dev/null
+done
+python bench.py --workload reddit-gat --emulate-rank 0/4 --steps 5 --warmup 2 > $out/bench_gat_rank_0_4.json 2>/dev/null
+if [ -f "$HP" ]; then
+  for r in 0 3; do
+    python bench.py --workload products --generator sbm --partvec $HP --emulate-rank $r/8 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_products_sbm_hp_rank_${r}_8.json 2>/dev/null
+    python bench.py --workload products --generator sbm --emulate-rank $r/8 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_products_sbm_rp_rank_${r}_8.json 2>/dev/null
+  done
+fi
+for f in $out/bench*.json; do python - <<PY
+import json
+try:
+    r=json.load(open("$f")); ro=r.get("roofline") or {}
+    print("%-48s ms/step %8.3f  group %.3f ms frac %.4f traffic %s  halo %s" % ("$(basename $f)", r["ms_per_step"], ro.get("avg_launch_ms", 0), ro.get("frac", 0), ro.get("traffic"), [round(h["avg_launch_ms"], 3) for h in (r.get("halo_groups") or [])]))
+except Exception as e: print("$(basename $f)", "FAILED", e)
+PY
+done
