@@ -209,3 +209,45 @@ def test_portable_generators_same_graph_on_cpu_and_gpu(dev):
         assert a[0] == b[0]
         for x, y in zip(a[1:], b[1:]):
             assert torch.equal(x, y.cpu())
+
+
+_HP8 = None
+
+
+def _hp8_path():
+    import os
+    from conftest import GOLDEN
+    return os.path.join(GOLDEN, "partvec", "products-sbm.A.mtx.8.hp.gz")
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(_hp8_path()), reason="the PaToH part vector of the products-shaped graph is not committed")
+def test_products_sbm_hypergraph_partition_shards(K, dev):
+    """BASELINE config 3 as written: products-shaped graph (n = 2 449 029, 126 M stored entries; the planted-partition
+    stand-in, since R-MAT has no structure for a partitioner to find), EIGHT ranks, the HYPERGRAPH part vector of the
+    reference's own front-end (GPU/hypergraph/main.cpp:51-63,340-356: PaToH column-net, tools/make_partvecs.py).
+    Ranks 0, 3 and 7 on the one GPU with the emulated exchange: forward, backward and the halo partial sums against
+    the float64 shadow with the per-row bound; the part vector cuts far fewer boundary rows than a random one."""
+    import json
+    import os
+    from conftest import GOLDEN
+    synth, partition = pkg("synth"), pkg("partition")
+    n, row, col, val = synth.make_graph("products", seed=0, device=dev, generator="sbm")
+    assert n == 2449029
+    pv = torch.tensor(partition.read_partvec(_hp8_path()), dtype=torch.int64)
+    assert pv.numel() == n and int(pv.max()) == 7
+    with open(os.path.join(GOLDEN, "partvec", "products-sbm.stats.json")) as fh:
+        stats = json.load(fh)["parts"]["8"]
+    pvd = pv.to(dev)
+    cut = pvd[row] != pvd[col]
+    rows_hp = int(torch.unique(pvd[row[cut]] * n + col[cut]).numel())
+    assert rows_hp == stats["hp"]["boundary_rows_per_aggregation"] < 0.6 * stats["rp"]["boundary_rows_per_aggregation"]
+    f = 128
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(21)
+    X = torch.rand(n, f, device=dev, generator=gen) * 2 - 1
+    G = torch.rand(n, f, device=dev, generator=gen) * 2 - 1
+    for r in (0, 3, 7):
+        p = _check_rank(K, dev, n, row, col, val, pv, r, 8, X, G, sample=300, oracle_rows=40)
+        assert 0 < p.n_halo < 0.5 * n                      # a structured partition: most of the graph is NOT in the halo
+        del p
+        torch.cuda.empty_cache()
