@@ -34,7 +34,7 @@ from . import partition as _partition
 
 def sample_adjacency_matrix(A, indices):
     """PGCN-Mini-batch.py:58-69: entries whose row AND column are in the batch."""
-    keep = np.in1d(A.row, indices) & np.in1d(A.col, indices)
+    keep = np.isin(A.row, indices) & np.isin(A.col, indices)
     return sparse.coo_matrix((A.data[keep], (A.row[keep], A.col[keep])), shape=A.shape)
 
 
