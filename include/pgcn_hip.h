@@ -241,15 +241,18 @@ int pgcn_spmm_fixup_f32(const int32_t *fix, int64_t nfix, const int32_t *slot_id
  *     m = max(0, max e), D = sum_edges exp(e-m) + (n_global-deg) exp(-m),
  *     alpha_ij = (exp(e_ij-m) - exp(-m))/D, beta[i,k] = exp(-m)/D, so that
  *     out_i = sum_edges alpha_ij Z_j + beta_i sum_all Z_j  (:149).  beta: [nrows x heads].
- * alpha / de are head-major [heads][nnz] in the storage order of `col`: plane k is the `val`
- * array of pgcn_spmm_csr(_plan)_f32, which does the aggregation out[:,k] = A_alpha_k . Z[:,k].
+ * alpha is head-major [heads][nnz] in the storage order of `col`: plane k is the `val` array of
+ * pgcn_spmm_csr(_plan)_f32, which does the aggregation out[:,k] = A_alpha_k . Z[:,k].  de (the edge gradient)
+ * is ENTRY-major [nnz][heads] in the same order: its only consumer reads it through a permutation (ds2 below),
+ * and the heads of an entry are then ONE gather of 4 * heads bytes instead of `heads` random 4-byte gathers.
  * Row lists: rows_wave (NULL = rows 0..nrows_wave-1) get one 64-lane wave each, rows_block one
  * 256-thread workgroup each (hub rows); a row must be in exactly one list to be processed.
  *
  * pgcn_gat_edge_grad_f32: de_ij = (alpha_ij + beta_i)(<dOut[i,k,:], Z[col,k,:]> - t[i,k]) [x LeakyReLU'(raw)],
  * ds1[i,k] = sum_j de_ij; t[i,k] = <dOut[i,k,:], out[i,k,:]> is supplied by the caller.  d = head width.
- * pgcn_csr_row_sums_f32: out[i*ldo + k] = sum of plane k of src over row i's entries, read through
- * perm (NULL = identity): with the transposed structure and its permutation this is ds2_j = sum_i de_ij.
+ * pgcn_csr_row_sums_f32: out[i*ldo + k] = sum over row i's entries p of src[idx(p) * planes + k], idx(p) =
+ * perm[p] (NULL = identity), src ENTRY-major [nnz][planes] (the layout of de): with the transposed structure
+ * and its permutation this is ds2_j = sum_i de_ij.
  * pgcn_csr_permute_f32: dst[k][p] = src[k][perm[p]] (values of A^T from values of A).
  * rowstat (optional output of the softmax, [nrows x heads x 4] fp32, 16-byte aligned) = (s1, m, 1/D,
  * exp(-m) or 0) per row and head; pgcn_gat_edge_weights_t_f32 recomputes from it the alpha planes

@@ -91,6 +91,34 @@ __global__ __launch_bounds__(kThreads) void gat_weights_t_kernel(
     }
 }
 
+// The same with ALL KH = heads heads of an entry per pass (KH = 1, 2, 4): one column load and ONE contiguous
+// 16 KH-byte gather of the row statistics per entry instead of one of each per head (r03: 3.1 -> see DESIGN 7).
+template <int TPR, int MODE, int KH>
+__global__ __launch_bounds__(kThreads) void gat_weights_t_heads_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ rows,
+    int64_t nlist, const float *__restrict__ s2, int64_t lds2, const float4 *__restrict__ rowstat, float slope,
+    float *__restrict__ alpha_t, int64_t nnz) {
+    int64_t j;
+    int lane;
+    if (!pick_row<TPR>(rows, nlist, j, lane)) return;
+    const int64_t b = rowptr[j], e = rowptr[j + 1];
+    float a2[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) a2[k] = s2[j * lds2 + k];
+    for (int64_t p = b + lane; p < e; p += TPR) {
+        const float4 *st = rowstat + (int64_t)col[p] * KH;
+        float4 q[KH];
+#pragma unroll
+        for (int k = 0; k < KH; ++k) q[k] = st[k];
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            float r = q[k].x + a2[k];
+            if (MODE == 0) r = r > 0.f ? r : r * slope;
+            alpha_t[(int64_t)k * nnz + p] = (expf(r - q[k].y) - q[k].w) * q[k].z;
+        }
+    }
+}
+
 // KH heads of a row per pass (KH = 1, 2, 4; s2 compact, lds2 % KH == 0): one col load and one
 // 4*KH-byte s2 gather per entry serve KH heads, two entries per lane and iteration are in flight.
 template <int KH> struct HeadVec;
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_kernel(
     const float ti = t[i * heads + k];
     const float bi = MODE == 1 ? beta[i * heads + k] : 0.f;
     const float *ak = alpha + (int64_t)k * nnz;
-    float *dk = de + (int64_t)k * nnz;
+    float *dk = de + k;                    // de is ENTRY-major: de[p * heads + k]
     const bool one = nvec <= lpe;          // the team covers the head in one vector per lane
     V g0 = {};
     if (one && sub < nvec) g0 = go[sub];
@@ -248,12 +276,12 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_kernel(
             if (va) {
                 ga = (ak[pa] + bi) * (da - ti);
                 if (MODE == 0) ga *= (a + s2[ca * lds2 + k]) > 0.f ? 1.f : slope;
-                dk[pa] = ga;
+                dk[pa * heads] = ga;
             }
             if (vb) {
                 gb = (ak[pb] + bi) * (db - ti);
                 if (MODE == 0) gb *= (a + s2[cb * lds2 + k]) > 0.f ? 1.f : slope;
-                dk[pb] = gb;
+                dk[pb * heads] = gb;
             }
             acc += ga + gb;
         }
@@ -319,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_heads_kernel(
         if (MODE == 1) bi = beta[i * heads + hk];
     }
     const float *ak = alpha + (int64_t)hk * nnz;
-    float *dk = de + (int64_t)hk * nnz;
+    float *dk = de + hk;                   // de is ENTRY-major: de[p * heads + k] (the heads of an entry are 4*heads bytes)
     float acc = 0.f;
     for (int64_t p0 = b + (int64_t)team * U; p0 < e; p0 += (int64_t)nteam * U) {
         int64_t c[U];
@@ -346,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_heads_kernel(
         if (fin && p < e) {
             float g = (ak[p] + bi) * (dm - ti);
             if (MODE == 0) g *= (a + s2[cm * lds2 + hk]) > 0.f ? 1.f : slope;
-            dk[p] = g;
+            dk[p * heads] = g;
             acc += g;
         }
     }
@@ -424,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_tasks_kernel(
         if (MODE == 1) bi = beta[i * heads + hk];
     }
     const float *ak = alpha + (int64_t)hk * nnz;
-    float *dk = de + (int64_t)hk * nnz;
+    float *dk = de + hk;                   // de is ENTRY-major: de[p * heads + k] (the heads of an entry are 4*heads bytes)
     float acc = 0.f;
     for (int64_t p0 = b + (int64_t)team * U; p0 < e; p0 += (int64_t)nteam * U) {
         int64_t c[U];
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_tasks_kernel(
         if (fin && p < e) {
             float g = (ak[p] + bi) * (dm - ti);
             if (MODE == 0) g *= (a + s2[cm * lds2 + hk]) > 0.f ? 1.f : slope;
-            dk[p] = g;
+            dk[p * heads] = g;
             acc += g;
         }
     }
@@ -462,24 +490,44 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_tasks_kernel(
     }
 }
 
-template <int TPR>
+// out[i, k] = sum over the entries p of row i of src[idx(p) * planes + k], idx(p) = perm[p] or p: `src` is ENTRY-major
+// ([nnz][planes]: the planes of an entry are adjacent, so a permuted entry costs ONE gather of 4 * planes bytes -- with
+// plane-major storage the gather of ds2 = column sums of de was `planes` random 4-byte gathers per entry, 3.9 of the
+// 25 ms of a GAT layer's backward, r02).  KH = planes in {1, 2, 4}: vector loads, all planes per pass; KH = 0: any
+// number of planes, one per blockIdx.y.
+template <int TPR, int KH>
 __global__ __launch_bounds__(kThreads) void csr_row_sums_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ perm, const int32_t *__restrict__ rows,
-    int64_t nlist, const float *__restrict__ src, int64_t nnz, float *__restrict__ out, int64_t ldo) {
+    int64_t nlist, const float *__restrict__ src, int32_t planes, float *__restrict__ out, int64_t ldo) {
     __shared__ float red[4];
     int64_t i;
     int lane;
     if (!pick_row<TPR>(rows, nlist, i, lane)) return;
-    const int k = blockIdx.y;
     const int64_t b = rowptr[i], e = rowptr[i + 1];
-    const float *sk = src + (int64_t)k * nnz;
-    float acc = 0.f;
-    if (perm)
-        for (int64_t p = b + lane; p < e; p += TPR) acc += sk[perm[p]];
-    else
-        for (int64_t p = b + lane; p < e; p += TPR) acc += sk[p];
-    acc = group_reduce<TPR, false>(acc, red);
-    if (lane == 0) out[i * ldo + k] = acc;
+    if constexpr (KH > 0) {
+        using HV = typename HeadVec<KH>::T;
+        const HV *sv = reinterpret_cast<const HV *>(src);
+        float acc[KH];
+#pragma unroll
+        for (int k = 0; k < KH; ++k) acc[k] = 0.f;
+        for (int64_t p = b + lane; p < e; p += TPR) {
+            const HV v = sv[perm ? perm[p] : p];
+            const float *vf = reinterpret_cast<const float *>(&v);
+#pragma unroll
+            for (int k = 0; k < KH; ++k) acc[k] += vf[k];
+        }
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            const float r = group_reduce<TPR, false>(acc[k], red);
+            if (lane == 0) out[i * ldo + k] = r;
+        }
+    } else {
+        const int k = blockIdx.y;
+        float acc = 0.f;
+        for (int64_t p = b + lane; p < e; p += TPR) acc += src[(perm ? perm[p] : p) * planes + k];
+        acc = group_reduce<TPR, false>(acc, red);
+        if (lane == 0) out[i * ldo + k] = acc;
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void csr_permute_kernel(const float *__restrict__ src,
@@ -742,14 +790,28 @@ extern "C" int pgcn_gat_edge_weights_t_f32(const int64_t *rowptr_t, const int32_
 #define PGCN_WT(TPR, MODE, GRID, ROWS, N)                                                                         \
     hipLaunchKernelGGL((gat_weights_t_kernel<TPR, MODE>), GRID, dim3(kThreads), 0, s, rowptr_t, col_t, ROWS, N, s2, \
                        lds2, rs, heads, slope, alpha_t, nnz)
+#define PGCN_WTH(TPR, MODE, KH, GRID, ROWS, N)                                                                       \
+    hipLaunchKernelGGL((gat_weights_t_heads_kernel<TPR, MODE, KH>), GRID, dim3(kThreads), 0, s, rowptr_t, col_t, ROWS, \
+                       N, s2, lds2, rs, slope, alpha_t, nnz)
+#define PGCN_WTK(TPR, GRID1, ROWS, N)                                                                  \
+    do {                                                                                               \
+        if (heads == 4) { if (mode == 0) PGCN_WTH(TPR, 0, 4, GRID1, ROWS, N); else PGCN_WTH(TPR, 1, 4, GRID1, ROWS, N); } \
+        else if (heads == 2) { if (mode == 0) PGCN_WTH(TPR, 0, 2, GRID1, ROWS, N); else PGCN_WTH(TPR, 1, 2, GRID1, ROWS, N); } \
+        else { if (mode == 0) PGCN_WTH(TPR, 0, 1, GRID1, ROWS, N); else PGCN_WTH(TPR, 1, 1, GRID1, ROWS, N); } \
+    } while (0)
+    const bool allheads = heads == 1 || heads == 2 || heads == 4;      // all heads of an entry per pass
     if (l.nwave) {
-        if (mode == 0) PGCN_WT(64, 0, wave_grid(l.nwave, heads), l.wave, l.nwave);
+        if (allheads) PGCN_WTK(64, wave_grid(l.nwave, 1), l.wave, l.nwave);
+        else if (mode == 0) PGCN_WT(64, 0, wave_grid(l.nwave, heads), l.wave, l.nwave);
         else PGCN_WT(64, 1, wave_grid(l.nwave, heads), l.wave, l.nwave);
     }
     if (l.nblock) {
-        if (mode == 0) PGCN_WT(256, 0, block_grid(l.nblock, heads), l.block, l.nblock);
+        if (allheads) PGCN_WTK(256, block_grid(l.nblock, 1), l.block, l.nblock);
+        else if (mode == 0) PGCN_WT(256, 0, block_grid(l.nblock, heads), l.block, l.nblock);
         else PGCN_WT(256, 1, block_grid(l.nblock, heads), l.block, l.nblock);
     }
+#undef PGCN_WTK
+#undef PGCN_WTH
 #undef PGCN_WT
     PGCN_HIP_CHECK(hipGetLastError());
     return PGCN_OK;
@@ -768,12 +830,23 @@ extern "C" int pgcn_csr_row_sums_f32(const int64_t *rowptr, const int64_t *perm,
     if (nrows == 0 || l.nwave + l.nblock == 0) return PGCN_OK;
     if (!rowptr || !out || (nnz && !src)) return pgcn_set_error2(PGCN_EINVAL, who, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (l.nwave)
-        hipLaunchKernelGGL((csr_row_sums_kernel<64>), wave_grid(l.nwave, planes), dim3(kThreads), 0, s, rowptr, perm,
-                           l.wave, l.nwave, src, nnz, out, ldo);
-    if (l.nblock)
-        hipLaunchKernelGGL((csr_row_sums_kernel<256>), block_grid(l.nblock, planes), dim3(kThreads), 0, s, rowptr, perm,
-                           l.block, l.nblock, src, nnz, out, ldo);
+    const bool v4 = planes == 4 && (uintptr_t)src % 16 == 0, v2 = planes == 2 && (uintptr_t)src % 8 == 0, v1 = planes == 1;
+#define PGCN_RS(TPR, KH, GRID, ROWS, N)                                                                        \
+    hipLaunchKernelGGL((csr_row_sums_kernel<TPR, KH>), GRID, dim3(kThreads), 0, s, rowptr, perm, ROWS, N, src, planes, \
+                       out, ldo)
+    if (l.nwave) {
+        if (v4) PGCN_RS(64, 4, wave_grid(l.nwave, 1), l.wave, l.nwave);
+        else if (v2) PGCN_RS(64, 2, wave_grid(l.nwave, 1), l.wave, l.nwave);
+        else if (v1) PGCN_RS(64, 1, wave_grid(l.nwave, 1), l.wave, l.nwave);
+        else PGCN_RS(64, 0, wave_grid(l.nwave, planes), l.wave, l.nwave);
+    }
+    if (l.nblock) {
+        if (v4) PGCN_RS(256, 4, block_grid(l.nblock, 1), l.block, l.nblock);
+        else if (v2) PGCN_RS(256, 2, block_grid(l.nblock, 1), l.block, l.nblock);
+        else if (v1) PGCN_RS(256, 1, block_grid(l.nblock, 1), l.block, l.nblock);
+        else PGCN_RS(256, 0, block_grid(l.nblock, planes), l.block, l.nblock);
+    }
+#undef PGCN_RS
     PGCN_HIP_CHECK(hipGetLastError());
     return PGCN_OK;
 }

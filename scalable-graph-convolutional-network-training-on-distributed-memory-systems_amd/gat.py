@@ -202,7 +202,9 @@ class GatEngine(BoundaryExchange):
         Fp = st.Zc.shape[1]
         dOut = dOut.contiguous()
         t = (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
-        de = self._plane_scratch("de", K)
+        de = self._scratch.get(("de", K))          # the edge gradient, ENTRY-major [nnz, K] (read once, through perm)
+        if de is None:
+            de = self._scratch[("de", K)] = torch.empty((max(self.nnz, 1), K), dtype=torch.float32, device=self.device)
         ds1 = None
         if self.task_grad:
             ds1t = torch.empty((n_p, K), dtype=torch.float32, device=self.device)

@@ -460,6 +460,13 @@ class HipKernels:
             AT.rowptr.data_ptr(), AT.col.data_ptr(), AT.nrows, nnz, *self._lists(AT), s2.data_ptr(), s2.stride(0),
             rowstat.data_ptr(), heads, slope, mode, alpha_t.data_ptr(), self._stream()), "pgcn_gat_edge_weights_t_f32")
 
+    @staticmethod
+    def _bad_de(de, alpha, heads: int, nnz: int) -> bool:
+        """alpha: [heads, nnz] head-major planes; de: [nnz, heads] ENTRY-major (include/pgcn_hip.h)."""
+        return (alpha.dim() != 2 or de.dim() != 2 or alpha.shape[0] != heads or de.shape[1] != heads
+                or de.shape[0] != alpha.shape[1] or not de.is_contiguous() or not alpha.is_contiguous()
+                or bool(nnz and alpha.shape[1] != nnz))
+
     def gat_edge_grad(self, A: DeviceCSR, s1, s2, alpha, beta, Z, dOut, t, heads: int, d: int, slope: float,
                       mode: int, de: torch.Tensor, ds1: torch.Tensor) -> None:
         self._check_rows(s1, A.nrows, heads, "s1")
@@ -471,10 +478,9 @@ class HipKernels:
                 and Z.shape[1] >= heads * d):
             raise _lib.PgcnError("Z must hold ncols rows of at least heads*d fp32 columns")
         nnz = A.col.numel()
-        if de.shape != alpha.shape or not de.is_contiguous() or not alpha.is_contiguous() \
-                or (nnz and alpha.shape[1] != nnz) \
+        if self._bad_de(de, alpha, heads, nnz) \
                 or t.stride(0) != heads or ds1.stride(0) != heads or beta.stride(0) != heads:
-            raise _lib.PgcnError("alpha/de must be [heads, nnz] contiguous; t, ds1, beta [nrows, heads] contiguous")
+            raise _lib.PgcnError("alpha must be [heads, nnz], de [nnz, heads], both contiguous; t, ds1, beta [nrows, heads] contiguous")
         _lib.check(self.lib.pgcn_gat_edge_grad_f32(
             A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, *self._lists(A), s1.data_ptr(),
             s1.stride(0), s2.data_ptr(), s2.stride(0), alpha.data_ptr(), beta.data_ptr(), Z.data_ptr(), Z.stride(0),
@@ -494,7 +500,7 @@ class HipKernels:
         self._check_rows(t, A.nrows, heads, "t")
         self._check_rows(dOut, A.nrows, F, "dOut")
         nnz = A.col.numel()
-        if de.shape != alpha.shape or not de.is_contiguous() or not alpha.is_contiguous() or (nnz and alpha.shape[1] != nnz) \
+        if self._bad_de(de, alpha, heads, nnz) \
                 or t.stride(0) != heads or beta.stride(0) != heads or not ds1_slices.is_contiguous() \
                 or tuple(ds1_slices.shape) != (A.nrows, 8, heads) or Z.shape[0] < A.ncols or Z.shape[1] < F:
             raise _lib.PgcnError("bad operand shapes for the sliced edge gradient")
@@ -519,7 +525,7 @@ class HipKernels:
         self._check_rows(ds1, A.nrows, heads, "ds1")
         self._check_rows(dOut, A.nrows, F, "dOut")
         nnz = A.col.numel()
-        if de.shape != alpha.shape or not de.is_contiguous() or not alpha.is_contiguous() or (nnz and alpha.shape[1] != nnz) \
+        if self._bad_de(de, alpha, heads, nnz) \
                 or t.stride(0) != heads or ds1.stride(0) != heads or beta.stride(0) != heads or Z.shape[0] < A.ncols \
                 or Z.shape[1] < F:
             raise _lib.PgcnError("bad operand shapes for the task-based edge gradient")
@@ -541,8 +547,8 @@ class HipKernels:
                      out: torch.Tensor) -> None:
         self._check_rows(out, A.nrows, planes, "out")
         nnz = A.col.numel()
-        if src.dim() != 2 or src.shape[0] != planes or not src.is_contiguous() or (nnz and src.shape[1] != nnz):
-            raise _lib.PgcnError("src must be [planes, nnz] contiguous")
+        if src.dim() != 2 or src.shape[1] != planes or not src.is_contiguous() or (nnz and src.shape[0] != nnz):
+            raise _lib.PgcnError("src must be [nnz, planes] contiguous (entry-major, like de)")
         if perm is not None and (perm.dtype is not torch.int64 or perm.numel() < A.col.numel()):
             raise _lib.PgcnError("perm must be int64 [nnz]")
         _lib.check(self.lib.pgcn_csr_row_sums_f32(

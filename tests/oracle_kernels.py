@@ -134,7 +134,7 @@ def _gat_edge_grad(self, A, s1, s2, alpha, beta, Z, dOut, t, heads, d, slope, mo
         g = p * (dp - t.numpy()[A.seg, k])
         if mode == 0:
             g = g * np.where(_raw(A, s1, s2, k) > 0, 1.0, slope)
-        de[k, :nz] = torch.from_numpy(g.astype(np.float32))
+        de[:nz, k] = torch.from_numpy(g.astype(np.float32))          # de is entry-major [nnz, heads]
         acc = np.zeros(A.nrows, np.float32)
         np.add.at(acc, A.seg, g.astype(np.float32))
         ds1[:, k] = torch.from_numpy(acc)
@@ -143,7 +143,7 @@ def _gat_edge_grad(self, A, s1, s2, alpha, beta, Z, dOut, t, heads, d, slope, mo
 def _csr_row_sums(self, A, perm, src, planes, out):
     nz = A.col.shape[0]
     for k in range(planes):
-        v = src.numpy()[k, :nz]
+        v = src.numpy()[:nz, k]                                        # entry-major source
         if perm is not None:
             v = v[perm.numpy()]
         acc = np.zeros(A.nrows, np.float32)

@@ -82,13 +82,14 @@ def _assert_rows(got, ref, bnd, what):
     assert worst <= 1.0, "%s: a row exceeds 1e-5 * sum|a||x| by a factor %.3g" % (what, worst)
 
 
-def _check_rank(K, dev, n, row, col, val, partvec, r, P, X, G, sample=400, oracle_rows=60):
+def _check_rank(K, dev, n, row, col, val, partvec, r, P, X, G, sample=400, oracle_rows=60, need_tiles=True):
     partition, engine = pkg("partition"), pkg("engine")
     p = partition.build_partition(row, col, val, n, partvec, r, P)
     assert p.rounds == (2 if P > 1 else 1)
     ex = _Exchanger() if P > 1 else None
     eng = engine.AggregationEngine(p, K, dev, ex)
-    assert eng.A_loc.strip is not None or eng.A_loc.dense is not None      # the tiled kernels take part at this size
+    if need_tiles:
+        assert eng.A_loc.strip is not None or eng.A_loc.dense is not None  # the tiled kernels take part at this size
     own = p.owned.to(dev)
     pv = partvec.to(dev)
     gen = torch.Generator(device=dev)
@@ -249,5 +250,33 @@ def test_products_sbm_hypergraph_partition_shards(K, dev):
     for r in (0, 3, 7):
         p = _check_rank(K, dev, n, row, col, val, pv, r, 8, X, G, sample=300, oracle_rows=40)
         assert 0 < p.n_halo < 0.5 * n                      # a structured partition: most of the graph is NOT in the halo
+        del p
+        torch.cuda.empty_cache()
+
+
+def test_papers_shape_graph_partition_shards_f64(K, dev):
+    """BASELINE config 4's shape at 1/64 scale (the union of the rank-local shards of tools/make_shards.py
+    --workload papers --scale 1/64: n = 1 735 311, 26.3 M stored entries), f = 64, EIGHT ranks, the GRAPH part vector of
+    the reference's METIS front-end (GPU/graph/main.cpp:53-65, committed by tools/make_partvecs.py --generator
+    shardstream).  Ranks 0 and 5 with the emulated exchange: forward, backward and halo partial sums inside the
+    per-row bound -- the 64-wide panels of the tiled kernels at full problem size, on an unbalanced partition
+    (METIS balances vertices: nnz imbalance 3.4)."""
+    import os
+    from conftest import GOLDEN
+    synth, partition = pkg("synth"), pkg("partition")
+    n0, nnz0, f, _ = synth.SHAPES["papers"]
+    n, pairs = int(n0 * 0.015625), int(nnz0 * 0.015625) // 2
+    keys = synth.rmat_shard_keys(n, pairs, 0, torch.zeros(n, dtype=torch.int64), seed=0, device=dev)
+    row, col, val = synth.shard_normalize(n, keys, torch.bincount(keys // n, minlength=n))
+    assert n == 1735311 and row.numel() == 26274311 and f == 64
+    pv = torch.tensor(partition.read_partvec(os.path.join(GOLDEN, "partvec", "papers64.A.mtx.8.gp.gz")), dtype=torch.int64)
+    assert pv.numel() == n and int(pv.max()) == 7
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(31)
+    X = torch.rand(n, f, device=dev, generator=gen) * 2 - 1
+    G = torch.rand(n, f, device=dev, generator=gen) * 2 - 1
+    for r in (0, 5):
+        p = _check_rank(K, dev, n, row, col, val, pv, r, 8, X, G, sample=300, oracle_rows=40, need_tiles=False)
+        assert p.n_halo > 0
         del p
         torch.cuda.empty_cache()

@@ -110,7 +110,7 @@ def test_attention_kernels_vs_oracle(K, dev, mode, heads, d, nslices, long_row):
     dOut = (rng.standard_normal((n, F))).astype(np.float32)
     dOd = torch.from_numpy(dOut).to(dev)
     t = (dOd.view(n, heads, d) * out.view(n, heads, d)).sum(-1).contiguous()
-    de = torch.full((heads, nnz), float("nan"), device=dev)
+    de = torch.full((nnz, heads), float("nan"), device=dev)                # ENTRY-major: [nnz, heads]
     ds1 = torch.full((n, heads), float("nan"), device=dev)
     K.gat_edge_grad(dA, s1d, Zd[:, F:F + heads], alpha, beta, Zd, dOd, t, heads, d, 0.2, mode_id, de, ds1)
     ds2 = torch.full((m, heads + 2), float("nan"), device=dev)
@@ -159,7 +159,7 @@ def test_attention_kernels_edge_cases_and_errors(K, dev):
     torch.cuda.synchronize()
     np.testing.assert_allclose(beta.cpu().numpy(), 0.25)                 # softmax over 4 zero logits
     out = torch.full((4, 2), float("nan"), device=dev)
-    K.csr_row_sums(dT, perm, alpha, 2, out)
+    K.csr_row_sums(dT, perm, torch.zeros((1, 2), device=dev), 2, out)    # entry-major source [nnz (padded), planes]
     assert (out == 0).all()
     # a row missing from the lists is left alone; wrong shapes are refused loudly
     A, _ = _graph(40, 30, 1, hub=False)
@@ -411,9 +411,9 @@ def test_edge_gradient_over_plan_tasks(K, dev, mode, heads, d, nslices, chunk):
         beta.zero_()
     dOut = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(dev)
     t = torch.from_numpy(rng.standard_normal((n, heads)).astype(np.float32)).to(dev)
-    de0, ds0 = torch.full((heads, nnz), float("nan"), device=dev), torch.full((n, heads), float("nan"), device=dev)
+    de0, ds0 = torch.full((nnz, heads), float("nan"), device=dev), torch.full((n, heads), float("nan"), device=dev)
     K.gat_edge_grad(dA, s1, s2, alpha, beta, Zd, dOut, t, heads, d, 0.2, mode_id, de0, ds0)
-    de1, ds1 = torch.full((heads, nnz), float("nan"), device=dev), torch.full((n, heads), float("nan"), device=dev)
+    de1, ds1 = torch.full((nnz, heads), float("nan"), device=dev), torch.full((n, heads), float("nan"), device=dev)
     assert K.gat_edge_grad_tasks(dA, s1, s2, alpha, beta, Zd, dOut, t, heads, d, 0.2, mode_id, de1, ds1)
     torch.cuda.synchronize()
     assert torch.isfinite(de1).all() and torch.isfinite(ds1).all()

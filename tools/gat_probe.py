@@ -49,7 +49,7 @@ def main():
     o = torch.empty(n, F, device=dev)
     out["spmm_heads_ms"] = timed(lambda: [K.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], o[:, k * d:(k + 1) * d]) for k in range(heads)])
     t = (G.view(n, heads, d) * st.out.view(n, heads, d)).sum(-1).contiguous()
-    de = eng._plane_scratch("de", heads); ds1 = torch.empty(n, heads, device=dev)
+    de = torch.empty(max(nnz, 1), heads, device=dev); ds1 = torch.empty(n, heads, device=dev)   # de: entry-major
     out["edge_grad_ms"] = timed(lambda: K.gat_edge_grad(eng.fwd, st.s1, st.s2c, st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1))
     ds1p = torch.empty(n, 8, heads, device=dev)
     out["edge_grad_sliced_ms"] = timed(lambda: K.gat_edge_grad_sliced(eng.fwd, st.s1, st.s2c, st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1p))
