@@ -233,6 +233,20 @@ int pgcn_spmm_fixup_f32(const int32_t *fix, int64_t nfix, const int32_t *slot_id
                         const int32_t *row_map, const float *partial_ws, float *C, int64_t ldc,
                         int32_t f, uint32_t flags, pgcn_stream_t stream);
 
+/* The same product with the weights RECOMPUTED per entry instead of read from planes -- the transposed product of
+ * the GAT backward pass, dZ = A_alpha^T . dOut on the transposed structure (rows = columns of A): entry (row j,
+ * col i) weighs alpha_ij = (exp(e - m_i) - em_i) / D_i, e = [LeakyReLU](s1_i + s2_j), from rowstat[i] = (s1, m, 1/D, em)
+ * (the softmax's per-row statistics, [ncols x heads x 4], 16-byte aligned) and s2[j] ([nrows x lds2]).  The
+ * arithmetic of pgcn_gat_edge_weights_t_f32 inside the gather kernel, bit for bit: the alpha^T planes and the
+ * walk that wrote them disappear (GPU/PGAT.py:148 backward).  mode / slope as in the attention kernels below.   */
+int pgcn_spmm_heads_recompute_f32(const int64_t *rowptr, const int32_t *col, const float *rowstat,
+                                  const float *s2, int64_t lds2, float slope, int32_t mode, int32_t heads,
+                                  int32_t d, int64_t nrows, const int32_t *tasks, int64_t ntasks,
+                                  const int64_t *seg, int32_t nslices, const int32_t *fix, int64_t nfix,
+                                  const float *B, int64_t ldb, float *C, int64_t ldc, float *partial_ws,
+                                  int64_t partial_ws_elems, int64_t nslots, uint32_t flags,
+                                  pgcn_stream_t stream);
+
 /* ---- GAT path: attention over the stored entries ----------------------
  * Replaces the dense n x n arithmetic of PGAT.forward, GPU/PGAT.py:138-151.  Per head k with
  * s1 = Z a1, s2 = Z a2 (:141-142):  raw_ij = s1[i,k] + s2[col,k]  (:144).

@@ -221,16 +221,20 @@ class GatEngine(BoundaryExchange):
             ds1 = torch.empty((n_p, K), dtype=torch.float32, device=self.device)
             self.k.gat_edge_grad(self.fwd, st.s1, st.s2c, st.alpha, st.beta, st.Zc, dOut, t, K, d,
                                  self.slope, self.mode_id, de, ds1)
-        alpha_t = self._plane_scratch("alpha_t", K)
-        self.k.gat_edge_weights_t(self.bwd, st.s2c, st.rowstat, K, self.slope, self.mode_id, alpha_t)
-        bwd_heads = self._scratch.get(("bwd_heads", K))
-        if bwd_heads is None:
-            bwd_heads = [self.k.with_values(self.bwd, alpha_t[k]) for k in range(K)]
-            self._scratch[("bwd_heads", K)] = bwd_heads
         dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
-        if not (self.multi_head and self.k.spmm_heads(self.bwd, alpha_t, dOut, dZc, K, d)):
-            for k in range(K):
-                self.k.spmm(bwd_heads[k], dOut[:, k * d:(k + 1) * d], dZc[:, k * d:(k + 1) * d])
+        # dZc = A_alpha^T . dOut: the weights of the transposed structure are recomputed inside the gather kernel from
+        # the row statistics (r03) -- or, for shapes / providers without that kernel, written as planes first
+        if not (self.multi_head and hasattr(self.k, "spmm_heads_recompute")
+                and self.k.spmm_heads_recompute(self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, dZc, K, d)):
+            alpha_t = self._plane_scratch("alpha_t", K)
+            self.k.gat_edge_weights_t(self.bwd, st.s2c, st.rowstat, K, self.slope, self.mode_id, alpha_t)
+            bwd_heads = self._scratch.get(("bwd_heads", K))
+            if bwd_heads is None:
+                bwd_heads = [self.k.with_values(self.bwd, alpha_t[k]) for k in range(K)]
+                self._scratch[("bwd_heads", K)] = bwd_heads
+            if not (self.multi_head and self.k.spmm_heads(self.bwd, alpha_t, dOut, dZc, K, d)):
+                for k in range(K):
+                    self.k.spmm(bwd_heads[k], dOut[:, k * d:(k + 1) * d], dZc[:, k * d:(k + 1) * d])
         self.k.csr_row_sums(self.bwd, self.perm, de, K, dZc[:, F:F + K])
         if Fp > F + K:
             dZc[:, F + K:].zero_()

@@ -428,6 +428,34 @@ class HipKernels:
         _lib.check(rc, "pgcn_spmm_heads_f32")
         return True
 
+    def spmm_heads_recompute(self, AT: DeviceCSR, rowstat: torch.Tensor, s2: torch.Tensor, slope: float, mode: int,
+                             B: torch.Tensor, C: torch.Tensor, heads: int, d: int, accumulate: bool = False) -> bool:
+        """C[:, k*d:(k+1)*d] (+)= A_alpha_k^T . B[:, k*d:(k+1)*d] on the TRANSPOSED structure ``AT`` with the weights
+        recomputed per entry from the softmax's row statistics (pgcn_spmm_heads_recompute_f32): no alpha^T planes.
+        rowstat: [AT.ncols, heads, 4]; s2: [>= AT.nrows, heads] (s2 of the rows of AT).  False = shape not covered."""
+        F = heads * d
+        self._check_rows(s2, AT.nrows, heads, "s2")
+        if not (rowstat.is_cuda and rowstat.dtype is torch.float32 and rowstat.is_contiguous()
+                and rowstat.numel() == AT.ncols * heads * 4):
+            raise _lib.PgcnError("rowstat must be a contiguous fp32 [ncols, heads, 4] CUDA tensor")
+        self._check_dense(B, AT.ncols, "B")
+        self._check_dense(C, AT.nrows, "C")
+        if B.shape[1] < F or C.shape[1] < F or AT.row_map is not None:
+            raise _lib.PgcnError("B / C narrower than heads * d, or a compact-row structure")
+        need = AT.nslots * F
+        if need and (AT.ws is None or AT.ws.numel() < need):
+            AT.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            AT.launch_cache.clear()
+        flags = _lib.SPMM_ACCUMULATE if accumulate else 0
+        rc = self.lib.pgcn_spmm_heads_recompute_f32(
+            AT.rowptr.data_ptr(), AT.col.data_ptr(), rowstat.data_ptr(), s2.data_ptr(), s2.stride(0), slope, mode, heads, d,
+            AT.nrows, _ptr(AT.tasks), AT.ntasks, AT.seg, AT.nslices, _ptr(AT.fix), AT.nfix, B.data_ptr(), B.stride(0),
+            C.data_ptr(), C.stride(0), _ptr(AT.ws), 0 if AT.ws is None else AT.ws.numel(), AT.nslots, flags, self._stream())
+        if rc == _lib.PGCN_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "pgcn_spmm_heads_recompute_f32")
+        return True
+
     def gat_edge_softmax(self, A: DeviceCSR, s1, s2, heads: int, slope: float, mode: int, n_global: int,
                          alpha: torch.Tensor, beta: torch.Tensor, rowstat: Optional[torch.Tensor] = None) -> None:
         self._check_rows(s1, A.nrows, heads, "s1")

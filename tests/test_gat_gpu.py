@@ -371,6 +371,53 @@ def test_multi_head_spmm_one_launch(K, dev, heads, d, nslices, chunk):
         assert torch.isfinite(o3).all()
 
 
+@pytest.mark.parametrize("mode", ["standard", "reference"])
+@pytest.mark.parametrize("heads,d", [(4, 64), (2, 32), (1, 128), (3, 20)])
+@pytest.mark.parametrize("nslices,chunk", [(1, 1024), (8, 1024), (8, 32)])
+def test_transposed_product_with_recomputed_weights(K, dev, mode, heads, d, nslices, chunk):
+    """pgcn_spmm_heads_recompute_f32 (r03): dZ = A_alpha^T . dOut with alpha recomputed per entry from the softmax's row
+    statistics inside the gather kernel == pgcn_gat_edge_weights_t_f32 (planes) followed by pgcn_spmm_heads_f32, BIT FOR
+    BIT (same expf arguments, same fmaf chains): direct rows, rows split into slots (their row found by binary search),
+    XCD-sliced structures, accumulate."""
+    n, m = 500, 420
+    A, rng = _graph(n, m, 11 * heads + d)
+    A.sort_indices()
+    mode_id = {"standard": 0, "reference": 1}[mode]
+    old, K.chunk = K.chunk, chunk
+    try:
+        dA, dT, perm, er, ec = _structure(K, A, nslices, 1 << 30)
+    finally:
+        K.chunk = old
+    nnz, F = A.nnz, heads * d
+    s1 = torch.from_numpy((rng.standard_normal((n, heads)) * 1.5).astype(np.float32)).to(dev)
+    s2 = torch.from_numpy((rng.standard_normal((m, heads)) * 1.5).astype(np.float32)).to(dev)
+    alpha = torch.empty((heads, nnz), device=dev)
+    beta = torch.zeros((n, heads), device=dev)
+    rowstat = torch.empty((n, heads, 4), device=dev)
+    K.gat_edge_softmax(dA, s1, s2, heads, 0.2, mode_id, 1000, alpha, beta, rowstat)
+    G = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(dev)
+    at = torch.full((heads, nnz), float("nan"), device=dev)
+    K.gat_edge_weights_t(dT, s2, rowstat, heads, 0.2, mode_id, at)
+    ref = torch.full((m, F + 4), float("nan"), device=dev)
+    assert K.spmm_heads(dT, at, G, ref, heads, d)
+    got = torch.full((m, F + 4), float("nan"), device=dev)
+    assert K.spmm_heads_recompute(dT, rowstat, s2, 0.2, mode_id, G, got, heads, d)
+    torch.cuda.synchronize()
+    assert torch.equal(got[:, :F], ref[:, :F]) and torch.isnan(got[:, F:]).all()
+    base = torch.from_numpy(rng.random((m, F + 4), dtype=np.float32)).to(dev)
+    acc, acc_ref = base.clone(), base.clone()
+    K.spmm_heads_recompute(dT, rowstat, s2, 0.2, mode_id, G, acc, heads, d, accumulate=True)
+    K.spmm_heads(dT, at, G, acc_ref, heads, d, accumulate=True)
+    assert torch.equal(acc, acc_ref)
+    # and against float64 through the forward planes (alpha^T = alpha permuted)
+    a = alpha.cpu().numpy().astype(np.float64)
+    Gn = G.cpu().numpy().astype(np.float64)
+    exp = np.zeros((m, F))
+    for k in range(heads):
+        exp[:, k * d:(k + 1) * d] = sp.csr_matrix((a[k], (er, ec)), shape=A.shape).T @ Gn[:, k * d:(k + 1) * d]
+    assert rel_err(got[:, :F].cpu().numpy(), exp) < 5 * TOL
+
+
 def test_multi_head_spmm_unsupported_shapes_fall_back(K, dev):
     A, rng = _graph(100, 90, 3, hub=False)
     A.sort_indices()
