@@ -349,34 +349,51 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_heads_kernel(
     const float *ak = alpha + (int64_t)hk * nnz;
     float *dk = de + hk;                   // de is ENTRY-major: de[p * heads + k] (the heads of an entry are 4*heads bytes)
     float acc = 0.f;
-    for (int64_t p0 = b + (int64_t)team * U; p0 < e; p0 += (int64_t)nteam * U) {
-        int64_t c[U];
-        float dot[U];
+    // The column ids of the NEXT batch are requested before the row gathers of this one go out, and a lane's alpha /
+    // s2 words together with them: the kernel is a latency chain per batch (col -> 1 KB rows -> alpha, s2), r03 took
+    // the first and the last link out of it.
+    int32_t c[U];
+    {
+        const int64_t p0 = b + (int64_t)team * U;
 #pragma unroll
-        for (int u = 0; u < U; ++u) c[u] = col[p0 + u < e ? p0 + u : e - 1];
+        for (int u = 0; u < U; ++u) c[u] = (e > b) ? col[p0 + u < e ? p0 + u : e - 1] : 0;
+    }
+    for (int64_t p0 = b + (int64_t)team * U; p0 < e; p0 += (int64_t)nteam * U) {
+        const int64_t pn = p0 + (int64_t)nteam * U;
+        int32_t cn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cn[u] = col[pn + u < e ? pn + u : e - 1];
+        int32_t cm = c[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u) cm = u_mine == u ? c[u] : cm;
+        const int64_t p = p0 + u_mine;
+        const bool mine = fin && p < e;
+        float al = 0.f, s2v = 0.f;
+        if (mine) {
+            al = ak[p];
+            if (MODE == 0) s2v = s2[(int64_t)cm * lds2 + hk];
+        }
+        float dot[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             dot[u] = 0.f;
-            if (live) dot[u] = Vec<4>::dot(g0, reinterpret_cast<const float4 *>(Z + c[u] * ldz)[sub]);
+            if (live) dot[u] = Vec<4>::dot(g0, reinterpret_cast<const float4 *>(Z + (int64_t)c[u] * ldz)[sub]);
         }
         for (int o = hl >> 1; o > 0; o >>= 1) {
 #pragma unroll
             for (int u = 0; u < U; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
         }
         float dm = dot[0];
-        int64_t cm = c[0];
 #pragma unroll
-        for (int u = 1; u < U; ++u) {
-            dm = u_mine == u ? dot[u] : dm;
-            cm = u_mine == u ? c[u] : cm;
-        }
-        const int64_t p = p0 + u_mine;
-        if (fin && p < e) {
-            float g = (ak[p] + bi) * (dm - ti);
-            if (MODE == 0) g *= (a + s2[cm * lds2 + hk]) > 0.f ? 1.f : slope;
+        for (int u = 1; u < U; ++u) dm = u_mine == u ? dot[u] : dm;
+        if (mine) {
+            float g = (al + bi) * (dm - ti);
+            if (MODE == 0) g *= (a + s2v) > 0.f ? 1.f : slope;
             dk[p * heads] = g;
             acc += g;
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = cn[u];
     }
     for (int k = 0; k < heads; ++k) {
         const float v = group_reduce<TPR, false>((fin && hk == k) ? acc : 0.f, red);
@@ -454,34 +471,51 @@ __global__ __launch_bounds__(kThreads) void gat_edge_grad_tasks_kernel(
     const float *ak = alpha + (int64_t)hk * nnz;
     float *dk = de + hk;                   // de is ENTRY-major: de[p * heads + k] (the heads of an entry are 4*heads bytes)
     float acc = 0.f;
-    for (int64_t p0 = b + (int64_t)team * U; p0 < e; p0 += (int64_t)nteam * U) {
-        int64_t c[U];
-        float dot[U];
+    // The column ids of the NEXT batch are requested before the row gathers of this one go out, and a lane's alpha /
+    // s2 words together with them: the kernel is a latency chain per batch (col -> 1 KB rows -> alpha, s2), r03 took
+    // the first and the last link out of it.
+    int32_t c[U];
+    {
+        const int64_t p0 = b + (int64_t)team * U;
 #pragma unroll
-        for (int u = 0; u < U; ++u) c[u] = col[p0 + u < e ? p0 + u : e - 1];
+        for (int u = 0; u < U; ++u) c[u] = (e > b) ? col[p0 + u < e ? p0 + u : e - 1] : 0;
+    }
+    for (int64_t p0 = b + (int64_t)team * U; p0 < e; p0 += (int64_t)nteam * U) {
+        const int64_t pn = p0 + (int64_t)nteam * U;
+        int32_t cn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cn[u] = col[pn + u < e ? pn + u : e - 1];
+        int32_t cm = c[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u) cm = u_mine == u ? c[u] : cm;
+        const int64_t p = p0 + u_mine;
+        const bool mine = fin && p < e;
+        float al = 0.f, s2v = 0.f;
+        if (mine) {
+            al = ak[p];
+            if (MODE == 0) s2v = s2[(int64_t)cm * lds2 + hk];
+        }
+        float dot[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             dot[u] = 0.f;
-            if (live) dot[u] = Vec<4>::dot(g0, reinterpret_cast<const float4 *>(Z + c[u] * ldz)[sub]);
+            if (live) dot[u] = Vec<4>::dot(g0, reinterpret_cast<const float4 *>(Z + (int64_t)c[u] * ldz)[sub]);
         }
         for (int o = hl >> 1; o > 0; o >>= 1) {
 #pragma unroll
             for (int u = 0; u < U; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
         }
         float dm = dot[0];
-        int64_t cm = c[0];
 #pragma unroll
-        for (int u = 1; u < U; ++u) {
-            dm = u_mine == u ? dot[u] : dm;
-            cm = u_mine == u ? c[u] : cm;
-        }
-        const int64_t p = p0 + u_mine;
-        if (fin && p < e) {
-            float g = (ak[p] + bi) * (dm - ti);
-            if (MODE == 0) g *= (a + s2[cm * lds2 + hk]) > 0.f ? 1.f : slope;
+        for (int u = 1; u < U; ++u) dm = u_mine == u ? dot[u] : dm;
+        if (mine) {
+            float g = (al + bi) * (dm - ti);
+            if (MODE == 0) g *= (a + s2v) > 0.f ? 1.f : slope;
             dk[p * heads] = g;
             acc += g;
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = cn[u];
     }
     float *outp = dst >= 0 ? partial + (int64_t)dst * heads : ds1 + i * heads;
     for (int k = 0; k < heads; ++k) {
