@@ -278,6 +278,7 @@ def run(rank, size, nlayers, nfeatures, path_A, path_partvec, backend, epochs=50
     X = None
     labels = owned % nfeatures                                                                         # :202
 
+    _pgcn.tune_dense_gemms(A.part.n_local, nfeatures, device)     # library GEMM choice for H.W^T made in set-up
     model = nn.Sequential(*[PGAT(A, nfeatures, nfeatures) for _ in range(nlayers)])
     model = model.to(device)
     initiliaze_parameters(model)
