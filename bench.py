@@ -341,6 +341,50 @@ def pmc_traffic_for(args, world, f, block="loc"):
     return None, note
 
 
+def graph_replay(model, make_model, H, labels, n, P, steps, dev, eager_ms):
+    """Capture ONE training step (forward, loss, backward, Adam) in a HIP graph and time `steps` replays.  The C-ABI
+    library never allocates or synchronises and the engine orders its streams with events only, so the whole step --
+    ~80 launches on a whole graph, ~150 on a shard with its halo groups -- is capturable; a replay has no host-side
+    enqueue cost.  Eager timing stays the headline `value` (it carries the live per-kernel events)."""
+    try:
+        # fresh leaves: the AccumulateGrad nodes of the eager run's parameters are bound to the default stream, which
+        # must not be touched during a capture
+        fresh = make_model()
+        fresh.load_state_dict(model.state_dict())
+        model = fresh
+        H = H.detach().clone().requires_grad_(True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # warm-up of the capturable optimizer off the default stream
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                P.local_loss(model(H), labels, n).backward()
+                opt.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            loss = P.local_loss(model(H), labels, n)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize(dev)
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        t_all = time.perf_counter() - t0
+        return {"captured": True, "ms_per_step": 1e3 * t_all / steps, "host_enqueue_ms_per_step": 1e3 * t_host / steps,
+                "eager_ms_per_step": eager_ms, "loss": float(loss)}
+    except Exception as e:                                 # a capture problem must not cost the eager line
+        return {"captured": False, "error": repr(e)[:300]}
+
+
 class GatKernelTimer:
     """HIP events around every launch of the dominant GAT kernel (the edge gradient: SDDMM + softmax backward)."""
 
@@ -510,6 +554,9 @@ def main():
                          "rows; the part vector is --partvec FILE or PREFIX.<N>.bp")
     ap.add_argument("--mtx", default=None, help="a MatrixMarket adjacency file (like PGCN.py -a) instead of the synthetic graph")
     ap.add_argument("--real", action="store_true", help="label the --shards / --mtx input as real data in the JSON line")
+    ap.add_argument("--graph", action="store_true",
+                    help="after the timed (eager) region: capture ONE training step in a HIP graph and time its replays "
+                         "(reported as `graph_replay`; one process only -- an RCCL capture cannot be exercised on one GPU)")
     ap.add_argument("--emulate-rank", default=None, metavar="r/P",
                     help="one GPU runs rank r of a P-rank job with a no-op exchange (per-rank compute of 2/4/8 GPUs)")
     args = ap.parse_args()
@@ -717,6 +764,9 @@ def main():
     }
     if halo_groups is not None:
         out["halo_groups"] = halo_groups
+    if args.graph and world == 1:
+        out["graph_replay"] = graph_replay(model, lambda: nn.Sequential(*[P.PGCN(eng, f, f) for _ in range(L)]).to(dev),
+                                           H, labels, n, P, args.steps, dev, ms_per_step)
     if world > 1:
         vol = torch.tensor([eng.stats["send_volume"]], dtype=torch.float64, device=dev)
         P._all_reduce(vol)

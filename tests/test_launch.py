@@ -236,3 +236,19 @@ def test_bench_emulated_rank_line():
     assert shape["n_halo"] > 0 and shape["nnz_halo_blocks"] > 0 and abs(shape["n_local"] - 131072 / 4) < 2000
     assert len(rec["halo_groups"]) == rec["config"]["exchange_rounds"] and all(h["frac"] > 0 for h in rec["halo_groups"])
     assert rec["roofline"]["frac"] > 0 and "COMPUTE of rank 1/4" in rec["metric"]
+
+
+@pytest.mark.gpu
+def test_bench_graph_replay_of_one_training_step():
+    """`--graph`: one whole training step of an emulated rank (local block + two halo launch groups ordered with
+    events on two streams, loss kernels, Adam) is captured in a HIP graph and replayed: the C-ABI library never
+    allocates or synchronises (include/pgcn_hip.h), so nothing in the step breaks a capture, and a replay costs the
+    host next to nothing (compute side)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mid", "--emulate-rank", "0/4", "--graph",
+                          "--steps", "5", "--warmup", "2"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _json_line(out.stdout)
+    g = rec["graph_replay"]
+    assert g["captured"], g
+    assert g["host_enqueue_ms_per_step"] < 0.5 and 0 < g["ms_per_step"] < 1.5 * rec["ms_per_step"]
+    assert np.isfinite(g["loss"])
