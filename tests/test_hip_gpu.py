@@ -747,7 +747,8 @@ def test_minibatch_driver_real_kernels(dev, name, P, tmp_path):
             np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("n,f,ld", [(1, 1, 1), (513, 16, 16), (4000, 128, 128), (777, 100, 104), (300, 1024, 1024), (50, 65, 65)])
+@pytest.mark.parametrize("n,f,ld", [(1, 1, 1), (513, 16, 16), (4000, 128, 128), (777, 100, 104), (300, 1024, 1024), (50, 65, 65), (1001, 256, 260),
+                                     (35, 64, 64), (18, 4, 4)])
 def test_row_nll_kernels_vs_torch(K, dev, n, f, ld):
     """pgcn_nll_rows_f32 / _backward_f32 == F.nll_loss(F.log_softmax(x), y, reduction='sum') and its gradient
     (GPU/PGCN.py:214-215), incl. rows with -inf entries and large magnitudes."""
