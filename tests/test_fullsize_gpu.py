@@ -88,8 +88,9 @@ def _check_rank(K, dev, n, row, col, val, partvec, r, P, X, G, sample=400, oracl
     assert p.rounds == (2 if P > 1 else 1)
     ex = _Exchanger() if P > 1 else None
     eng = engine.AggregationEngine(p, K, dev, ex)
-    if need_tiles:
-        assert eng.A_loc.strip is not None or eng.A_loc.dense is not None  # the tiled kernels take part at this size
+    if need_tiles:                          # the tiled kernels take part at this size (a small LOCAL block of an 8-way
+        blocks = [eng.A_loc] + list(eng.A_halo)   # shard runs gather-only since r03; its halo block is tiled)
+        assert any(a.strip is not None or a.dense is not None for a in blocks)
     own = p.owned.to(dev)
     pv = partvec.to(dev)
     gen = torch.Generator(device=dev)
