@@ -8,9 +8,6 @@ HP=${2:-tests/golden/partvec/products-sbm.A.mtx.8.hp.gz}
 out=gpurun_out/final_$tag; rm -rf $out; mkdir -p $out
 timeout 2400 python -m pytest tests -m gpu -q > $out/pytest_gpu_full.txt 2>&1; grep -E "passed|failed|error" $out/pytest_gpu_full.txt | tail -3 | tee $out/pytest_gpu.txt
 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $out/smoke.txt
-python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1200 $out/bench.json; echo
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/prof_stdout.log 2> $out/prof_stderr.log
-rm -f $out/prof/*kernel_trace.csv $out/prof/*/*kernel_trace.csv
 pmc() {  # name, then the record key: workload generator ranks f partvec block, then group_probe arguments
   name=$1; key="$2 $3 $4 $5 $6 $7"; shift 7
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
@@ -27,13 +24,15 @@ pmc reddit_r8l  reddit rmat 0/8 128 random loc --emulate-rank 0/8 --block loc
 pmc products    products rmat 1 128 random loc --workload products
 pmc reddit_sbm  reddit sbm 1 128 random loc --generator sbm
 cp $out/pmc_traffic.json profiles/pmc_traffic.json      # (bench.py reads it from there for the lines below)
-python bench.py --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_with_traffic.json 2>/dev/null
+python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1200 $out/bench.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/prof_stdout.log 2> $out/prof_stderr.log
+rm -f $out/prof/*kernel_trace.csv $out/prof/*/*kernel_trace.csv
 python bench.py --workload products --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_products.json 2>/dev/null
 python bench.py --generator sbm --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_sbm.json 2>/dev/null
 python bench.py --workload mid --steps 10 --warmup 2 > $out/bench_mid.json 2>/dev/null
 python bench.py --workload reddit-gat --steps 5 --warmup 2 > $out/bench_gat.json 2>/dev/null
 for rp in 0/8 3/8 7/8 0/4 0/2; do t=$(echo $rp | tr '/' '_')
-  python bench.py --emulate-rank $rp --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rank_$t.json 2>/dev/null
+  python bench.py --emulate-rank $rp --graph --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rank_$t.json 2>/dev/null
 done
 python bench.py --workload reddit-gat --emulate-rank 0/4 --steps 5 --warmup 2 > $out/bench_gat_rank_0_4.json 2>/dev/null
 if [ -f "$HP" ]; then
