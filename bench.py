@@ -386,14 +386,17 @@ def graph_replay(model, make_model, H, labels, n, P, steps, dev, eager_ms):
 
 
 class GatKernelTimer:
-    """HIP events around every launch of the dominant GAT kernel (the edge gradient: SDDMM + softmax backward)."""
+    """HIP events around every launch of the dominant GAT kernel: the fused transposed product + edge gradient
+    (pgcn_spmm_heads_grad_f32), or -- shapes it does not cover -- the stand-alone edge gradient."""
+    NAMES = ("spmm_heads_grad", "gat_edge_grad_tasks", "gat_edge_grad_sliced")
 
     def __init__(self, kernels, device):
-        self.k, self.device, self.records, self.on = kernels, device, [], False
-        for name in ("gat_edge_grad_tasks", "gat_edge_grad_sliced"):      # whichever variant the engine uses
-            setattr(kernels, name, self._wrap(getattr(kernels, name)))
+        self.k, self.device, self.records, self.on = kernels, device, {}, False
+        for name in self.NAMES:                                             # whichever variant the engine uses
+            if hasattr(kernels, name):
+                setattr(kernels, name, self._wrap(name, getattr(kernels, name)))
 
-    def _wrap(self, fn):
+    def _wrap(self, name, fn):
         def call(*a, **kw):
             if not self.on:
                 return fn(*a, **kw)
@@ -403,13 +406,17 @@ class GatKernelTimer:
             out = fn(*a, **kw)
             e1.record(s)
             if out:
-                self.records.append((e0, e1))
+                self.records.setdefault(name, []).append((e0, e1))
             return out
         return call
 
     def mean_ms(self):
-        ts = [a.elapsed_time(b) for a, b in self.records]
-        return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
+        """(kernel name, mean launch ms, launches) of the variant that ran."""
+        for name in self.NAMES:
+            ts = [a.elapsed_time(b) for a, b in self.records.get(name, [])]
+            if ts:
+                return name, sum(ts) / len(ts), len(ts)
+        return None, None, 0
 
 
 def bench_gat(args, rank, world, dev, backend, stage):
@@ -477,13 +484,20 @@ def bench_gat(args, rank, world, dev, backend, stage):
         elapsed = float(t)
     ms = 1e3 * elapsed / args.steps
     roofline = None
-    avg, launches = timer.mean_ms()
+    kname, avg, launches = timer.mean_ms()
     if avg:
         n_r, n_c = part.n_local, part.n_local + part.n_halo
-        alg = (4 + 8 * heads) * eng.nnz + 4 * F * (n_c + n_r)      # col + alpha + de per entry and head; Z and dOut panels
+        if kname == "spmm_heads_grad":
+            # col + de per entry and head; dOut panel gathered, Z panel and dZ rows streamed once; statistics are L2-sized
+            alg = (4 + 4 * heads) * eng.nnz + 4 * F * (n_r + 2 * n_c)
+            label = ("spmm_heads_kernel<%d, recompute, grad> (pgcn_spmm_heads_grad_f32: ONE gather pass over the transposed "
+                     "structure = A_alpha^T . dOut + SDDMM <dOut_i, Z_j> + softmax / LeakyReLU backward + ds2)" % heads)
+        else:
+            alg = (4 + 8 * heads) * eng.nnz + 4 * F * (n_c + n_r)  # col + alpha + de per entry and head; Z and dOut panels
+            label = ("%s_kernel (XCD-sliced SDDMM <dOut_i, Z_j> + softmax / LeakyReLU backward, one pass over the "
+                     "stored entries)" % kname)
         ach = alg / (avg * 1e-3)
-        roofline = {"bound": "hbm", "kernel": "gat_edge_grad_%s_kernel (XCD-sliced SDDMM <dOut_i, Z_j> + softmax / LeakyReLU "
-                                              "backward, one pass over the stored entries)" % ("tasks" if eng.task_grad else "heads"),
+        roofline = {"bound": "hbm", "kernel": label,
                     "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
                     "alg_bytes_per_launch": alg, "avg_launch_ms": avg, "launches_timed": launches,
                     "gather_model_GBs": 4.0 * F * eng.nnz / (avg * 1e-3) / 1e9}
@@ -501,7 +515,8 @@ def bench_gat(args, rank, world, dev, backend, stage):
                       "partition": info["partition"], "emulated_rank": args.emulate_rank if emul else None,
                       "exchange": exch.name if exch else "none",
                       "rank_shape": {"n_local": part.n_local, "n_halo": part.n_halo, "n_send": part.n_send, "nnz_rank": eng.nnz},
-                      "multi_head_spmm": bool(eng.multi_head), "vertex_order": part.order_info},
+                      "multi_head_spmm": bool(eng.multi_head), "fused_edge_gradient": bool(eng.fused_grad),
+                      "vertex_order": part.order_info},
            "roofline": roofline, "ms_per_epoch": ms, "ms_per_layer_fwd_bwd": ms / L, "loss": float(loss), "setup_s": setup_s,
            "cpu_baseline": None}
     if world > 1:

@@ -247,6 +247,24 @@ int pgcn_spmm_heads_recompute_f32(const int64_t *rowptr, const int32_t *col, con
                                   int64_t partial_ws_elems, int64_t nslots, uint32_t flags,
                                   pgcn_stream_t stream);
 
+/* ... and with the EDGE GRADIENT of the same pass (r03).  The backward of GPU/PGAT.py:144-149 needs, per stored (i, j),
+ * dp_ij = <dOut_i, Z_j> and alpha_ij dOut_i summed into dZ_j: the same pairs of rows.  On the transposed structure Z_j is
+ * the task's own row (Z, [nrows x ldz]) and dOut_i (B) is gathered anyway, so one pass yields
+ *   C[j, 0 .. F)            (+)= sum_i alpha_ij dOut_i                       (as pgcn_spmm_heads_recompute_f32)
+ *   de[q, k]                 = (alpha_ij + beta_i)(dp_ij - t_i)[x LeakyReLU'(s1_i + s2_j)]   entry-major [nnz x heads],
+ *                              q = the entry's position in THIS (transposed) structure; t = [ncols x heads]
+ *   C[j, F .. F + heads)    (+)= sum_i de_ij  (= ds2_j; columns up to the next multiple of 4 are written as zero)
+ * so ldc >= F + heads rounded up to 4, and a partial row is that wide.  ds1 = the column sums of de:
+ * pgcn_csr_row_sums_f32 over the forward structure with the inverse permutation.  PGCN_EUNSUPPORTED unless
+ * d is 32, 64, 128 or 256 (and the limits of pgcn_spmm_heads_f32): callers then run pgcn_gat_edge_grad_*_f32 and
+ * pgcn_spmm_heads_recompute_f32.                                                                              */
+int pgcn_spmm_heads_grad_f32(const int64_t *rowptr, const int32_t *col, const float *rowstat, const float *s2,
+                             int64_t lds2, float slope, int32_t mode, int32_t heads, int32_t d, int64_t nrows,
+                             const int32_t *tasks, int64_t ntasks, const int64_t *seg, int32_t nslices,
+                             const int32_t *fix, int64_t nfix, const float *B, int64_t ldb, const float *Z,
+                             int64_t ldz, const float *t, float *C, int64_t ldc, float *de, float *partial_ws,
+                             int64_t partial_ws_elems, int64_t nslots, uint32_t flags, pgcn_stream_t stream);
+
 /* ---- GAT path: attention over the stored entries ----------------------
  * Replaces the dense n x n arithmetic of PGAT.forward, GPU/PGAT.py:138-151.  Per head k with
  * s1 = Z a1, s2 = Z a2 (:141-142):  raw_ij = s1[i,k] + s2[col,k]  (:144).

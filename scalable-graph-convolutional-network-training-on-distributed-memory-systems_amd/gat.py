@@ -7,10 +7,13 @@ matrix ``z1 + z2^T`` masked with ``A > 0``, a row softmax over all n columns and
     forward   [Z | s2] boundary rows -> all-to-all-v -> panel Zc = [local rows ; halo rows]
               alpha = edge softmax(s1_i + s2_j)              (pgcn_gat_edge_softmax_f32)
               out[:, head k] = A_alpha_k . Zc[:, head k]     (the CSR SpMM kernels, val = alpha plane k)
-    backward  de, ds1 = edge gradient                        (pgcn_gat_edge_grad_f32)
-              alpha^T planes recomputed from the row statistics   (pgcn_gat_edge_weights_t_f32)
-              dZc[:, head k] = A_alpha_k^T . dOut[:, head k] (SpMM on the transposed structure)
-              ds2 = row sums of de over the transposed structure (pgcn_csr_row_sums_f32)
+    backward  ONE gather pass over the transposed structure    (pgcn_spmm_heads_grad_f32, r03):
+                  dZc[:, head k] = A_alpha_k^T . dOut[:, head k]  (weights recomputed from the row statistics)
+                  de_ij = edge gradient from <dOut_i, Z_j> -- Z_j is the task's own row, dOut_i is gathered anyway
+                  ds2 = row sums of de (leave with the row)
+              ds1 = column sums of de: row sums over the forward structure (pgcn_csr_row_sums_f32, inverse permutation)
+              [shapes the fused kernel does not cover: pgcn_gat_edge_grad_*_f32 (row i gathers Z_j), then the
+               transposed product, then ds2 = row sums of de over the transposed structure]
               halo rows of [dZ | ds2] travel back to their owners and are ADDED (reverse all-to-all-v)
 
 Two semantics (``mode``): "standard" = LeakyReLU + softmax over the neighbours, K heads
@@ -128,12 +131,23 @@ class GatEngine(BoundaryExchange):
         self.fwd = kernels.prepare_gat(g.fwd, g.fwd_wave, g.fwd_block)
         self.bwd = kernels.prepare_gat(g.bwd, g.bwd_wave, g.bwd_block)
         self.perm = g.perm.to(self.device)
+        self._inv_perm = None              # forward entry -> its position in the transposed structure (built on demand)
         self._scratch = {}
         self.sliced_grad = _T.gat_sliced   # XCD-sliced edge gradient where the shape allows
         # the edge gradient over the balanced tasks of the SpMM plan (pgcn_gat_edge_grad_tasks_f32)
         self.task_grad = _T.gat_task_grad and hasattr(kernels, "gat_edge_grad_tasks")
         # all heads of `attention @ Z` (and of its transpose) in one launch (pgcn_spmm_heads_f32)
         self.multi_head = _T.gat_multihead and hasattr(kernels, "spmm_heads")
+        # the edge gradient inside the transposed product's gather pass (pgcn_spmm_heads_grad_f32)
+        self.fused_grad = _T.gat_fused_grad and self.multi_head and hasattr(kernels, "spmm_heads_grad")
+
+    @property
+    def inv_perm(self) -> torch.Tensor:
+        if self._inv_perm is None:
+            inv = torch.empty_like(self.perm)
+            inv[self.perm] = torch.arange(self.perm.numel(), dtype=torch.int64, device=self.perm.device)
+            self._inv_perm = inv
+        return self._inv_perm
 
     # -- buffers ---------------------------------------------------------
     def _plane_scratch(self, name: str, heads: int) -> torch.Tensor:
@@ -202,6 +216,16 @@ class GatEngine(BoundaryExchange):
         Fp = st.Zc.shape[1]
         dOut = dOut.contiguous()
         t = (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
+        dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
+        if self.fused_grad:
+            # one gather pass: dZc = A_alpha^T . dOut, de (entry-major, TRANSPOSED storage order) and ds2 = its row sums
+            de_t = self._scratch.get(("de_t", K))
+            if de_t is None:
+                de_t = self._scratch[("de_t", K)] = torch.empty((max(self.nnz, 1), K), dtype=torch.float32, device=self.device)
+            if self.k.spmm_heads_grad(self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, st.Zc, t, dZc, de_t, K, d):
+                ds1 = torch.empty((n_p, K), dtype=torch.float32, device=self.device)
+                self.k.csr_row_sums(self.fwd, self.inv_perm, de_t, K, ds1)
+                return self._finish_backward(st, dOut, dZc, ds1)
         de = self._scratch.get(("de", K))          # the edge gradient, ENTRY-major [nnz, K] (read once, through perm)
         if de is None:
             de = self._scratch[("de", K)] = torch.empty((max(self.nnz, 1), K), dtype=torch.float32, device=self.device)
@@ -221,7 +245,6 @@ class GatEngine(BoundaryExchange):
             ds1 = torch.empty((n_p, K), dtype=torch.float32, device=self.device)
             self.k.gat_edge_grad(self.fwd, st.s1, st.s2c, st.alpha, st.beta, st.Zc, dOut, t, K, d,
                                  self.slope, self.mode_id, de, ds1)
-        dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
         # dZc = A_alpha^T . dOut: the weights of the transposed structure are recomputed inside the gather kernel from
         # the row statistics (r03) -- or, for shapes / providers without that kernel, written as planes first
         if not (self.multi_head and hasattr(self.k, "spmm_heads_recompute")
@@ -236,6 +259,14 @@ class GatEngine(BoundaryExchange):
                 for k in range(K):
                     self.k.spmm(bwd_heads[k], dOut[:, k * d:(k + 1) * d], dZc[:, k * d:(k + 1) * d])
         self.k.csr_row_sums(self.bwd, self.perm, de, K, dZc[:, F:F + K])
+        return self._finish_backward(st, dOut, dZc, ds1)
+
+    def _finish_backward(self, st: GatLayerState, dOut: torch.Tensor, dZc: torch.Tensor, ds1: torch.Tensor):
+        """Halo rows of [dZ | ds2] back to their owners (added), then the owned rows."""
+        K, d = st.heads, st.d
+        F = K * d
+        n_p, n_h = self.n_local, self.n_halo
+        Fp = st.Zc.shape[1]
         if Fp > F + K:
             dZc[:, F + K:].zero_()
         if self.size > 1:                                   # partial rows of [dZ | ds2] back to their owners, ADDED

@@ -456,6 +456,47 @@ class HipKernels:
         _lib.check(rc, "pgcn_spmm_heads_recompute_f32")
         return True
 
+    def spmm_heads_grad(self, AT: DeviceCSR, rowstat: torch.Tensor, s2: torch.Tensor, slope: float, mode: int,
+                        B: torch.Tensor, Z: torch.Tensor, t: torch.Tensor, C: torch.Tensor, de: torch.Tensor, heads: int,
+                        d: int, accumulate: bool = False) -> bool:
+        """The transposed product of ``spmm_heads_recompute`` AND the edge gradient of the same (i, j) pairs in one
+        gather pass (pgcn_spmm_heads_grad_f32): C[:, :F] (+)= A_alpha^T . B, de[q] = the edge gradient of entry q of
+        ``AT`` (entry-major [nnz, heads]), C[:, F:F+heads] (+)= its row sums (ds2).  Z: rows of AT ([>= AT.nrows, >= F]),
+        t: [AT.ncols, heads].  False = shape not covered (d must be 32, 64, 128 or 256)."""
+        F = heads * d
+        hl = d // 4
+        if d % 4 or hl < 8 or hl & (hl - 1) or F > 256 or heads > 8:
+            return False                   # (the C entry point answers PGCN_EUNSUPPORTED for these too)
+        pw = F + (heads + 3) // 4 * 4
+        nnz = AT.col.numel()
+        self._check_rows(s2, AT.nrows, heads, "s2")
+        self._check_rows(t, AT.ncols, heads, "t")
+        if not (rowstat.is_cuda and rowstat.dtype is torch.float32 and rowstat.is_contiguous()
+                and rowstat.numel() == AT.ncols * heads * 4):
+            raise _lib.PgcnError("rowstat must be a contiguous fp32 [ncols, heads, 4] CUDA tensor")
+        self._check_dense(B, AT.ncols, "B")
+        self._check_dense(Z, AT.nrows, "Z")
+        self._check_dense(C, AT.nrows, "C")
+        if B.shape[1] < F or Z.shape[1] < F or C.shape[1] < pw or AT.row_map is not None or t.stride(0) != heads:
+            raise _lib.PgcnError("B / Z narrower than heads * d, C narrower than heads * d + heads (rounded up to 4), "
+                                 "t not contiguous, or a compact-row structure")
+        if not (de.is_cuda and de.dtype is torch.float32 and de.is_contiguous() and de.numel() >= nnz * heads):
+            raise _lib.PgcnError("de must be a contiguous fp32 CUDA tensor of nnz * heads elements")
+        need = AT.nslots * pw
+        if need and (AT.ws is None or AT.ws.numel() < need):
+            AT.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            AT.launch_cache.clear()
+        flags = _lib.SPMM_ACCUMULATE if accumulate else 0
+        rc = self.lib.pgcn_spmm_heads_grad_f32(
+            AT.rowptr.data_ptr(), AT.col.data_ptr(), rowstat.data_ptr(), s2.data_ptr(), s2.stride(0), slope, mode, heads, d,
+            AT.nrows, _ptr(AT.tasks), AT.ntasks, AT.seg, AT.nslices, _ptr(AT.fix), AT.nfix, B.data_ptr(), B.stride(0),
+            Z.data_ptr(), Z.stride(0), t.data_ptr(), C.data_ptr(), C.stride(0), de.data_ptr(), _ptr(AT.ws),
+            0 if AT.ws is None else AT.ws.numel(), AT.nslots, flags, self._stream())
+        if rc == _lib.PGCN_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "pgcn_spmm_heads_grad_f32")
+        return True
+
     def gat_edge_softmax(self, A: DeviceCSR, s1, s2, heads: int, slope: float, mode: int, n_global: int,
                          alpha: torch.Tensor, beta: torch.Tensor, rowstat: Optional[torch.Tensor] = None) -> None:
         self._check_rows(s1, A.nrows, heads, "s1")

@@ -61,6 +61,7 @@ class Tuning:
     gat_sliced: bool = True          # XCD-sliced edge gradient
     gat_task_grad: bool = True       # edge gradient over the SpMM plan's balanced tasks
     gat_multihead: bool = True       # all heads of attention @ Z in one launch
+    gat_fused_grad: bool = True      # edge gradient inside the transposed product's gather pass (one pass fewer)
 
 
 def _parse(spec: str, base: Tuning) -> Tuning:

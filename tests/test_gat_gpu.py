@@ -471,6 +471,94 @@ def test_edge_gradient_over_plan_tasks(K, dev, mode, heads, d, nslices, chunk):
     assert torch.equal(de1, de2) and torch.equal(ds1, ds2)            # deterministic
 
 
+@pytest.mark.parametrize("mode", ["standard", "reference"])
+@pytest.mark.parametrize("heads,d", [(4, 64), (2, 32), (1, 256), (3, 64), (1, 128)])
+@pytest.mark.parametrize("nslices,chunk", [(1, 1024), (8, 1024), (8, 32)])
+def test_edge_gradient_fused_into_the_transposed_product(K, dev, mode, heads, d, nslices, chunk):
+    """pgcn_spmm_heads_grad_f32 (r03): ONE gather pass over the transposed structure gives dZ = A_alpha^T . dOut (bit for
+    bit the recompute kernel's), the edge gradient de (entry-major in the TRANSPOSED storage order; == the per-row
+    kernel's de through the permutation, up to the order of the 16-lane dot-product reduction) and ds2 = its row sums
+    in columns [F, F + heads) of the output (pad columns zero).  Direct rows, split rows (slots, binary search),
+    XCD-sliced structures, empty rows, accumulate; ds1 = column sums through the inverse permutation."""
+    n, m = 400, 360
+    A, rng = _graph(n, m, 13 * heads + d)
+    A.sort_indices()
+    mode_id = {"standard": 0, "reference": 1}[mode]
+    old, K.chunk = K.chunk, chunk
+    try:
+        dA, dT, perm, er, ec = _structure(K, A, nslices, 1 << 30)
+    finally:
+        K.chunk = old
+    nnz, F = A.nnz, heads * d
+    pw = F + (heads + 3) // 4 * 4
+    Zd = torch.from_numpy((rng.standard_normal((m, pw)) * 0.7).astype(np.float32)).to(dev)
+    s1 = torch.from_numpy((rng.standard_normal((n, heads)) * 1.5).astype(np.float32)).to(dev)
+    s2 = Zd[:, F:F + heads].contiguous()
+    alpha = torch.empty((heads, nnz), device=dev)
+    beta = torch.zeros((n, heads), device=dev)
+    rowstat = torch.empty((n, heads, 4), device=dev)
+    K.gat_edge_softmax(dA, s1, s2, heads, 0.2, mode_id, 1000, alpha, beta, rowstat)
+    if mode == "standard":
+        beta.zero_()
+    dOut = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(dev)
+    t = torch.from_numpy(rng.standard_normal((n, heads)).astype(np.float32)).to(dev)
+    # the three-kernel route
+    de0, ds1_0 = torch.full((nnz, heads), float("nan"), device=dev), torch.full((n, heads), float("nan"), device=dev)
+    K.gat_edge_grad(dA, s1, s2, alpha, beta, Zd, dOut, t, heads, d, 0.2, mode_id, de0, ds1_0)
+    ref = torch.full((m, pw), float("nan"), device=dev)
+    assert K.spmm_heads_recompute(dT, rowstat, s2, 0.2, mode_id, dOut, ref, heads, d)
+    K.csr_row_sums(dT, perm, de0, heads, ref[:, F:F + heads])
+    # the fused pass
+    got = torch.full((m, pw), float("nan"), device=dev)
+    de_t = torch.full((nnz, heads), float("nan"), device=dev)
+    assert K.spmm_heads_grad(dT, rowstat, s2, 0.2, mode_id, dOut, Zd, t, got, de_t, heads, d)
+    torch.cuda.synchronize()
+    assert torch.equal(got[:, :F], ref[:, :F])                                   # the product: bit for bit
+    assert torch.isfinite(de_t).all()
+    scale = float(de0.abs().max())
+    assert float((de_t - de0[perm]).abs().max()) <= 2e-6 * scale                  # same entries, transposed order
+    assert rel_err(got[:, F:F + heads].cpu().numpy(), ref[:, F:F + heads].cpu().numpy()) < TOL
+    assert (got[:, F + heads:] == 0).all()                                       # pad columns are written as zero
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(nnz, device=dev)
+    ds1 = torch.empty((n, heads), device=dev)
+    K.csr_row_sums(dA, inv, de_t, heads, ds1)
+    assert rel_err(ds1.cpu().numpy(), ds1_0.cpu().numpy()) < TOL
+    # float64 check of de straight from the definition
+    a = alpha.cpu().numpy().astype(np.float64); b = beta.cpu().numpy().astype(np.float64)
+    Zn, Gn = Zd.cpu().numpy().astype(np.float64), dOut.cpu().numpy().astype(np.float64)
+    s1n, s2n, tn = s1.cpu().numpy().astype(np.float64), s2.cpu().numpy().astype(np.float64), t.cpu().numpy().astype(np.float64)
+    exp = np.empty((nnz, heads))
+    for k in range(heads):
+        dp = np.einsum("ef,ef->e", Gn[er, k * d:(k + 1) * d], Zn[ec, k * d:(k + 1) * d])
+        g = (a[k] + b[er, k]) * (dp - tn[er, k])
+        if mode == "standard":
+            g = g * np.where(s1n[er, k] + s2n[ec, k] > 0, 1.0, 0.2)
+        exp[:, k] = g
+    assert rel_err(de_t.cpu().numpy(), exp[perm.cpu().numpy()]) < 5 * TOL
+    # deterministic, and accumulate adds to what is there (features AND the ds2 columns)
+    got2, de2 = torch.empty_like(got), torch.empty_like(de_t)
+    K.spmm_heads_grad(dT, rowstat, s2, 0.2, mode_id, dOut, Zd, t, got2, de2, heads, d)
+    assert torch.equal(got, got2) and torch.equal(de_t, de2)
+    base = torch.from_numpy(rng.random((m, pw), dtype=np.float32)).to(dev)
+    acc = base.clone()
+    K.spmm_heads_grad(dT, rowstat, s2, 0.2, mode_id, dOut, Zd, t, acc, de2, heads, d, accumulate=True)
+    assert rel_err((acc - base)[:, :F + heads].cpu().numpy(), got[:, :F + heads].cpu().numpy()) < TOL
+
+
+def test_fused_edge_gradient_unsupported_shapes_fall_back(K, dev):
+    A, rng = _graph(100, 90, 5, hub=False)
+    A.sort_indices()
+    dA, dT, perm, _, _ = _structure(K, A, 1, 1 << 30)
+    heads, d = 2, 20                                                  # 5 lanes per head: no 8-entry batch, no butterfly
+    F = heads * d
+    rowstat = torch.rand((100, heads, 4), device=dev)
+    s2 = torch.rand((90, heads), device=dev)
+    out = torch.empty((90, F + 4), device=dev)
+    assert K.spmm_heads_grad(dT, rowstat, s2, 0.2, 0, torch.rand((100, F), device=dev), torch.rand((90, F), device=dev),
+                             torch.rand((100, heads), device=dev), out, torch.empty((A.nnz, heads), device=dev), heads, d) is False
+
+
 def test_full_size_gat_shard_rank_of_four(K, dev):
     """BASELINE config 5 names FOUR GPUs: rank 2 of a 4-way random partition of the Reddit-sized graph (4 heads x
     64) with the exchange emulated on the one GPU (the halo rows of [Z | s2] come from global data the test holds;

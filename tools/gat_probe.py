@@ -58,8 +58,19 @@ def main():
     out["weights_t_ms"] = timed(lambda: K.gat_edge_weights_t(eng.bwd, st.s2c, st.rowstat, heads, eng.slope, eng.mode_id, at))
     ds2 = torch.empty(n, heads, device=dev)
     out["row_sums_ms"] = timed(lambda: K.csr_row_sums(eng.bwd, eng.perm, de, heads, ds2))
-    bh = eng._scratch[("bwd_heads", heads)]
-    out["spmm_T_heads_ms"] = timed(lambda: [K.spmm(bh[k], G[:, k * d:(k + 1) * d], o[:, k * d:(k + 1) * d]) for k in range(heads)])
+    ds1t = torch.empty(n, heads, device=dev)
+    out["edge_grad_tasks_ms"] = timed(lambda: K.gat_edge_grad_tasks(eng.fwd, st.s1, st.s2c, st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1t))
+    o2 = torch.empty(n, F, device=dev)
+    out["spmm_heads_kernel_ms"] = timed(lambda: K.spmm_heads(eng.fwd, st.alpha, Zc, o2, heads, d))
+    dzc = torch.empty(Zc.shape[0], Zc.shape[1], device=dev)
+    out["heads_recompute_T_ms"] = timed(lambda: K.spmm_heads_recompute(eng.bwd, st.rowstat, st.s2c, eng.slope, eng.mode_id, G, dzc, heads, d))
+    de_t = torch.empty(max(nnz, 1), heads, device=dev)
+    ok = [True]
+    def fused():
+        ok[0] = K.spmm_heads_grad(eng.bwd, st.rowstat, st.s2c, eng.slope, eng.mode_id, G, Zc, t, dzc, de_t, heads, d)
+    out["heads_grad_fused_ms"] = timed(fused)
+    out["heads_grad_fused_covered"] = bool(ok[0])
+    out["row_sums_fwd_inv_ms"] = timed(lambda: K.csr_row_sums(eng.fwd, eng.inv_perm, de_t, heads, ds1))
     # algorithmic bytes of the streams: softmax 4 (col) + 4 (alpha) per entry and head
     out["softmax_alg_GBs"] = nnz * heads * 8 / out["softmax_ms"] / 1e6
     out["edge_grad_gather_TBs"] = nnz * F * 4 / out["edge_grad_ms"] / 1e9
