@@ -252,7 +252,8 @@ int pgcn_spmm_heads_recompute_f32(const int64_t *rowptr, const int32_t *col, con
  * the task's own row (Z, [nrows x ldz]) and dOut_i (B) is gathered anyway, so one pass yields
  *   C[j, 0 .. F)            (+)= sum_i alpha_ij dOut_i                       (as pgcn_spmm_heads_recompute_f32)
  *   de[q, k]                 = (alpha_ij + beta_i)(dp_ij - t_i)[x LeakyReLU'(s1_i + s2_j)]   entry-major [nnz x heads],
- *                              q = the entry's position in THIS (transposed) structure; t = [ncols x heads]
+ *                              q = the entry's position in THIS (transposed) structure; t = [ncols x heads];
+ *                              de = NULL: not kept (see pgcn_spmm_heads_forward2_f32)
  *   C[j, F .. F + heads)    (+)= sum_i de_ij  (= ds2_j; columns up to the next multiple of 4 are written as zero)
  * so ldc >= F + heads rounded up to 4, and a partial row is that wide.  ds1 = the column sums of de:
  * pgcn_csr_row_sums_f32 over the forward structure with the inverse permutation.  PGCN_EUNSUPPORTED unless
@@ -264,6 +265,21 @@ int pgcn_spmm_heads_grad_f32(const int64_t *rowptr, const int32_t *col, const fl
                              const int32_t *fix, int64_t nfix, const float *B, int64_t ldb, const float *Z,
                              int64_t ldz, const float *t, float *C, int64_t ldc, float *de, float *partial_ws,
                              int64_t partial_ws_elems, int64_t nslots, uint32_t flags, pgcn_stream_t stream);
+
+/* The FORWARD product with recomputed weights and a second accumulator (r03): out = A_alpha . B as pgcn_spmm_heads_f32, but
+ * alpha_ij is recomputed from rowstat[i] (the task's own row, [nrows x heads x 4]) and s2[col] ([ncols x lds2]) -- no alpha
+ * planes, pgcn_gat_edge_softmax_f32 may be called with alpha = NULL -- and the same gathered rows also give
+ *   C2[i, 0 .. F)          (+)= V_i = sum_j c_ij B_j,   c_ij = alpha_ij LeakyReLU'(s1_i + s2_j) (mode 0) | alpha_ij + beta_i (mode 1)
+ *   C2[i, F .. F + heads)  (+)= C_i = sum_j c_ij        (columns up to the next multiple of 4 are written as zero)
+ * so that the backward pass gets ds1_i = sum_j de_ij = <dOut_i, V_i> - t_i C_i from row-local data and never needs the
+ * per-entry gradient (pgcn_spmm_heads_grad_f32 with de = NULL).  ldc2 >= F + heads rounded up to 4; the work-space holds
+ * nslots x (2 F + that) floats.  PGCN_EUNSUPPORTED unless d is 32, 64, 128 or 256 (GPU/PGAT.py:144-149).            */
+int pgcn_spmm_heads_forward2_f32(const int64_t *rowptr, const int32_t *col, const float *rowstat, const float *s2,
+                                 int64_t lds2, float slope, int32_t mode, int32_t heads, int32_t d, int64_t nrows,
+                                 const int32_t *tasks, int64_t ntasks, const int64_t *seg, int32_t nslices,
+                                 const int32_t *fix, int64_t nfix, const float *B, int64_t ldb, float *C, int64_t ldc,
+                                 float *C2, int64_t ldc2, float *partial_ws, int64_t partial_ws_elems, int64_t nslots,
+                                 uint32_t flags, pgcn_stream_t stream);
 
 /* ---- GAT path: attention over the stored entries ----------------------
  * Replaces the dense n x n arithmetic of PGAT.forward, GPU/PGAT.py:138-151.  Per head k with
@@ -287,7 +303,7 @@ int pgcn_spmm_heads_grad_f32(const int64_t *rowptr, const int32_t *col, const fl
  * and its permutation this is ds2_j = sum_i de_ij.
  * pgcn_csr_permute_f32: dst[k][p] = src[k][perm[p]] (values of A^T from values of A).
  * rowstat (optional output of the softmax, [nrows x heads x 4] fp32, 16-byte aligned) = (s1, m, 1/D,
- * exp(-m) or 0) per row and head; pgcn_gat_edge_weights_t_f32 recomputes from it the alpha planes
+ * exp(-m) or 0) per row and head (with rowstat given, alpha may be NULL: statistics only); pgcn_gat_edge_weights_t_f32 recomputes from it the alpha planes
  * in the storage order of the TRANSPOSED structure (rowptr_t/col_t; s2 indexed by its rows) --
  * the same numbers as permuting alpha, without the 4-byte random gathers.
  * All sums run in a fixed order: bit-reproducible, no atomics.                                  */

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void gat_softmax_heads_kernel(
         }
         inv[k] = D > 0.f ? 1.f / D : 0.f;
     }
-    for (int64_t p = b + lane; p < e; p += 2 * TPR) {
+    for (int64_t p = b + lane; alpha && p < e; p += 2 * TPR) {   // (alpha == NULL: statistics only, the products recompute it)
         float r0[KH], r1[KH];
         const bool two = p + TPR < e;
         scores(p, r0);
@@ -604,7 +604,7 @@ extern "C" int pgcn_gat_edge_softmax_f32(const int64_t *rowptr, const int32_t *c
     int rc = check_lists(who, nrows, l);
     if (rc != PGCN_OK) return rc;
     if (nrows == 0 || l.nwave + l.nblock == 0) return PGCN_OK;
-    if (!rowptr || !s1 || (nnz && (!col || !s2 || !alpha)) || (mode == 1 && !beta))
+    if (!rowptr || !s1 || (nnz && (!col || !s2 || (!alpha && !rowstat))) || (mode == 1 && !beta))
         return pgcn_set_error2(PGCN_EINVAL, who, "null pointer");
     if ((uintptr_t)rowstat % 16) return pgcn_set_error2(PGCN_EINVAL, who, "rowstat must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;

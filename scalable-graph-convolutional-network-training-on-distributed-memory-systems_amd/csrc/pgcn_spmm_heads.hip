@@ -29,6 +29,13 @@
 // TRANSPOSED structure and its row sums -- ds2_j -- leave with the row (columns [F, F + heads) of C).  One whole gather
 // pass over the graph (the edge-gradient kernel) disappears; ds1_i = the column sums of de are
 // pgcn_csr_row_sums_f32 over the forward structure with the inverse permutation.
+//
+// FWD (r03, with RECOMPUTE): the FORWARD product with recomputed weights and a second accumulator.  alpha_ij comes from
+// the row statistics of the task's own row and s2 of the entry's column (no alpha planes: the softmax kernel stops
+// after its statistics), and the same gathered Z_j also feeds V_i = sum_j c_ij Z_j and C_i = sum_j c_ij with
+// c_ij = alpha_ij LeakyReLU'(s1_i + s2_j) (mode 0) or alpha_ij + beta_i (mode 1).  Since ds1_i = sum_j de_ij =
+// <dOut_i, V_i> - t_i C_i, the backward pass needs no per-entry gradient array at all: de is never written, its
+// column sums (a pass of 16-byte random gathers through the transpose permutation) disappear.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -76,14 +83,23 @@ struct EdgeGrad {                // GRAD: what the edge gradient needs on top of
     int32_t pw;                  // width of a partial / output row: F + heads rounded up to 4
 };
 
-template <int KH, bool RECOMPUTE, bool GRAD>
-__global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
+struct Forward2 {                // FWD: the second output of the forward product
+    float *C2;                   // [nrows x ldc2]: V in columns [0, F), C in [F, F + KH), zeros up to pw2
+    int64_t ldc2;
+    float *partial2;             // slot rows of pw2 floats (behind the F-wide slot rows of the first output)
+    int32_t pw2;                 // F + heads rounded up to 4
+};
+
+template <int KH, bool RECOMPUTE, bool GRAD, bool FWD>
+__global__ __launch_bounds__(kThreads, FWD ? 5 : 4) void spmm_heads_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ alpha,
     int64_t plane, const int4 *__restrict__ tasks, int64_t ntasks, const float *__restrict__ B, int64_t ldb,
     float *__restrict__ C, int64_t ldc, int32_t F, int32_t d, float *__restrict__ partial, uint32_t flags,
-    int32_t nslices, SliceSeg seg, Recompute rc, EdgeGrad eg) {
+    int32_t nslices, SliceSeg seg, Recompute rc, EdgeGrad eg, Forward2 f2) {
     static_assert(!GRAD || RECOMPUTE, "the fused edge gradient recomputes its weights");
-    constexpr int PS = GRAD ? 3 * KH + 1 : KH + 1;     // parked words per entry: col, alpha[KH] (, A[KH], t[KH])
+    static_assert(!FWD || (RECOMPUTE && !GRAD), "the two-accumulator forward product recomputes its weights");
+    // parked words per entry: col, alpha[KH] (GRAD: A[KH], t[KH]; FWD: c[KH])
+    constexpr int PS = GRAD ? 3 * KH + 1 : (FWD ? 2 * KH + 1 : KH + 1);
     __shared__ float park[kWaves][64 * PS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -115,6 +131,10 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
     const int fsafe = fact ? fcol : 0;
     const int head = fact ? fcol / d : 0;
     f32x2 accl = {0.f, 0.f}, acch = {0.f, 0.f};        // this lane's four features of the output row
+    f32x2 vl = {0.f, 0.f}, vh = {0.f, 0.f};            // FWD: ... and of V
+    float csum[KH];                                    // FWD: this lane's share of C_i
+#pragma unroll
+    for (int k = 0; k < KH; ++k) csum[k] = 0.f;
     float *mine = park[wave];
     const int last = len > 0 ? len - 1 : 0;
     float a2[KH];                          // RECOMPUTE: s2 of this task's row
@@ -133,8 +153,10 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
                 }
                 row = lo;
             }
+            if constexpr (!FWD) {
 #pragma unroll
-            for (int k = 0; k < KH; ++k) a2[k] = rc.s2[row * rc.lds2 + k];
+                for (int k = 0; k < KH; ++k) a2[k] = rc.s2[row * rc.lds2 + k];
+            }
         }
     }
     // GRAD: this lane's four features of Z_j, the lanes of a head, and which entry of a batch the lane finishes
@@ -155,7 +177,22 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
     // the KH weights of entry `idx` (column c): from the planes, or recomputed from the statistics of row c;
     // GRAD: also ga = (alpha + beta) [x LeakyReLU'] and gt = t of row c, so that de = ga (dp - gt)
     auto weights = [&](int64_t idx, int32_t c, float (&w)[KH], float (&ga)[KH], float (&gt)[KH]) {
-        if constexpr (RECOMPUTE) {
+        if constexpr (FWD) {               // row statistics of the task's row, s2 of the entry's column; ga = c_ij
+            float sv[KH];
+            float4 qrow[KH];               // (one line, the same for all lanes, re-read per 64 entries: no registers
+#pragma unroll                             //  held across the gather loop)
+            for (int k = 0; k < KH; ++k) qrow[k] = rc.rowstat[row * KH + k];
+#pragma unroll
+            for (int k = 0; k < KH; ++k) sv[k] = rc.s2[(int64_t)c * rc.lds2 + k];
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                const float raw = qrow[k].x + sv[k];
+                float r = raw;
+                if (rc.mode == 0) r = r > 0.f ? r : r * rc.slope;
+                w[k] = (expf(r - qrow[k].y) - qrow[k].w) * qrow[k].z;
+                ga[k] = rc.mode == 0 ? w[k] * (raw > 0.f ? 1.f : rc.slope) : w[k] + qrow[k].w * qrow[k].z;
+            }
+        } else if constexpr (RECOMPUTE) {
             const float4 *st = rc.rowstat + (int64_t)c * KH;
             float4 q[KH];
 #pragma unroll
@@ -190,6 +227,10 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
         const int e = lane < last ? lane : last;
         nc = __builtin_nontemporal_load(col + kbeg + e);
         weights(kbeg + e, nc, na, nga, ngt);
+        if constexpr (FWD) {
+#pragma unroll
+            for (int k = 0; k < KH; ++k) csum[k] += lane < len ? nga[k] : 0.f;
+        }
     }
     for (int base = 0; base < len; base += 64) {   // wave-uniform: one task per wave
         __builtin_amdgcn_wave_barrier();
@@ -203,12 +244,20 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
                 mine[lane * PS + 1 + 2 * KH + k] = ngt[k];
             }
         }
+        if constexpr (FWD) {
+#pragma unroll
+            for (int k = 0; k < KH; ++k) mine[lane * PS + 1 + KH + k] = nga[k];
+        }
         __builtin_amdgcn_wave_barrier();
         if (base + 64 < len) {
             int e = base + 64 + lane;
             e = e < last ? e : last;
             nc = __builtin_nontemporal_load(col + kbeg + e);
             weights(kbeg + e, nc, na, nga, ngt);
+            if constexpr (FWD) {
+#pragma unroll
+                for (int k = 0; k < KH; ++k) csum[k] += base + 64 + lane < len ? nga[k] : 0.f;
+            }
         }
         const int cnt = min(64, len - base);
         // GRAD: the dot products of a batch are FINISHED (16-lane butterfly, de, row sum) one batch later, after the
@@ -243,19 +292,20 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
             const int e = e0p + u_mine;        // the entry of the batch this lane finishes
             if (fact && writer && e < cnt) {
                 const float g = mine[e * PS + 1 + KH + head] * (dm - mine[e * PS + 1 + 2 * KH + head]);
-                eg.de[(kbeg + base + e) * KH + head] = g;
+                if (eg.de) eg.de[(kbeg + base + e) * KH + head] = g;
                 acc2 += g;
             }
         };
         for (int e0 = 0; e0 < cnt; e0 += kBatch) {
             int32_t c[kBatch];
-            float w[kBatch];
+            float w[kBatch], w2[kBatch];
             float x[kBatch][4];
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
                 const int e = e0 + u < cnt ? e0 + u : cnt - 1;       // ragged tail: the task's last referenced row
                 c[u] = __float_as_int(mine[e * PS]);
                 w[u] = mine[e * PS + 1 + head];
+                w2[u] = FWD ? mine[e * PS + 1 + KH + head] : 0.f;
             }
             // (lanes beyond the F features gather column 0 and are never stored: no branch around the gathers, so the
             //  rows stay in flight across the pending reduction below instead of being copied out of a conditional)
@@ -278,6 +328,11 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
                     const f32x2 xl = {x[u][0], x[u][1]}, xh = {x[u][2], x[u][3]};
                     accl = __builtin_elementwise_fma(ww, xl, accl);
                     acch = __builtin_elementwise_fma(ww, xh, acch);
+                    if constexpr (FWD) {
+                        const f32x2 w22 = {w2[u], w2[u]};
+                        vl = __builtin_elementwise_fma(w22, xl, vl);
+                        vh = __builtin_elementwise_fma(w22, xh, vh);
+                    }
                     if constexpr (GRAD) {
                         const f32x2 pr = __builtin_elementwise_fma(xh, zh, xl * zl);
                         dq[u] = pr.x + pr.y;
@@ -292,6 +347,12 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
                     const f32x2 xl = {keep ? x[u][0] : 0.f, keep ? x[u][1] : 0.f}, xh = {keep ? x[u][2] : 0.f, keep ? x[u][3] : 0.f};
                     accl = __builtin_elementwise_fma(ww, xl, accl);
                     acch = __builtin_elementwise_fma(ww, xh, acch);
+                    if constexpr (FWD) {
+                        const float w2k = keep ? w2[u] : 0.f;
+                        const f32x2 w22 = {w2k, w2k};
+                        vl = __builtin_elementwise_fma(w22, xl, vl);
+                        vh = __builtin_elementwise_fma(w22, xh, vh);
+                    }
                     if constexpr (GRAD) {
                         const f32x2 pr = __builtin_elementwise_fma(xh, zh, xl * zl);
                         dq[u] = pr.x + pr.y;
@@ -320,6 +381,35 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
             }
         }
     }
+    if constexpr (FWD) {
+        // V_i beside the output row; C_i = the wave's sum of c_ij per head: lane L < pw2 - F writes column F + L
+        float mysum = 0.f;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            float v = csum[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            mysum = lane == k ? v : mysum;
+        }
+        if (tact) {
+            float *o2 = dst >= 0 ? f2.partial2 + (int64_t)dst * f2.pw2 : f2.C2 + (int64_t)(~dst) * f2.ldc2;
+            const bool add = dst < 0 && (flags & PGCN_SPMM_ACCUMULATE);
+            if (fact) {
+                float v4[4] = {vl.x, vl.y, vh.x, vh.y};
+                if (add) {
+                    float old[4];
+                    vload<4>(old, o2 + fcol);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) v4[v] += old[v];
+                }
+                vstore<4>(o2 + fcol, v4);
+            }
+            if (lane < f2.pw2 - F) {
+                float out = lane < KH ? mysum : 0.f;
+                if (add) out += o2[F + lane];
+                o2[F + lane] = out;
+            }
+        }
+    }
     float acc[4] = {accl.x, accl.y, acch.x, acch.y};
     if (tact && fact) {
         if (dst >= 0) {
@@ -341,7 +431,7 @@ __global__ __launch_bounds__(kThreads, 4) void spmm_heads_kernel(
 
 namespace {
 int launch_heads(const char *who, const int64_t *rowptr, const int32_t *col, const float *alpha, int64_t plane_stride,
-                 const Recompute *rc, const EdgeGrad *eg, int32_t heads, int32_t d, int64_t nrows, const int32_t *tasks, int64_t ntasks,
+                 const Recompute *rc, const EdgeGrad *eg, const Forward2 *f2, int32_t heads, int32_t d, int64_t nrows, const int32_t *tasks, int64_t ntasks,
                  const int64_t *seg, int32_t nslices, const int32_t *fix, int64_t nfix, const float *B, int64_t ldb,
                  float *C, int64_t ldc, float *partial_ws, int64_t partial_ws_elems, int64_t nslots, uint32_t flags,
                  pgcn_stream_t stream) {
@@ -362,15 +452,27 @@ int launch_heads(const char *who, const int64_t *rowptr, const int32_t *col, con
     int64_t pw = F;
     if (eg) {
         const int hl = d / 4;
-        if (!rc || !eg->Z || !eg->t || !eg->de || eg->ldz < F || eg->ldz % 4 || (uintptr_t)eg->Z % 16)
-            return pgcn_set_error2(PGCN_EINVAL, who, "bad Z / t / de");
+        if (!rc || !eg->Z || !eg->t || eg->ldz < F || eg->ldz % 4 || (uintptr_t)eg->Z % 16)     // (de may be NULL: not kept)
+            return pgcn_set_error2(PGCN_EINVAL, who, "bad Z / t");
         if (hl < kBatch || (hl & (hl - 1)))
             return pgcn_set_error2(PGCN_EUNSUPPORTED, who, "the fused edge gradient needs d = 32, 64, 128 or 256");
         pw = eg->pw;
         if (pw != F + (heads + 3) / 4 * 4 || ldc < pw)
             return pgcn_set_error2(PGCN_EINVAL, who, "C must hold heads * d + heads (rounded up to 4) columns");
     }
-    if (nslots < 0 || partial_ws_elems < nslots * pw)
+    int64_t pw_all = pw;                 // floats of work-space per slot
+    Forward2 h0{};
+    if (f2) {
+        const int hl = d / 4;
+        if (!rc || eg || !f2->C2 || f2->pw2 != F + (heads + 3) / 4 * 4 || f2->ldc2 < f2->pw2 || f2->ldc2 % 4 || (uintptr_t)f2->C2 % 16)
+            return pgcn_set_error2(PGCN_EINVAL, who, "bad second output (heads * d + heads columns, rounded up to 4)");
+        if (hl < kBatch || (hl & (hl - 1)))
+            return pgcn_set_error2(PGCN_EUNSUPPORTED, who, "the two-accumulator product needs d = 32, 64, 128 or 256");
+        pw_all = F + f2->pw2;
+        h0 = *f2;
+        h0.partial2 = partial_ws ? partial_ws + nslots * F : nullptr;
+    }
+    if (nslots < 0 || partial_ws_elems < nslots * pw_all)
         return pgcn_set_error2(PGCN_ENOMEM, who, "partial work-space too small");
     SliceSeg sg{};
     int64_t grid;
@@ -391,14 +493,16 @@ int launch_heads(const char *who, const int64_t *rowptr, const int32_t *col, con
     if (rc) r0 = *rc;
     EdgeGrad g0{};
     if (eg) g0 = *eg;
-#define PGCN_HEADS_LAUNCH(KH, RC, GR)                                                                                \
-    hipLaunchKernelGGL((spmm_heads_kernel<KH, RC, GR>), dim3((unsigned)grid), dim3(kThreads), 0, s, rowptr, col, alpha, \
-                       plane_stride, t4, nt, B, ldb, C, ldc, (int32_t)F, d, partial_ws, flags, nslices, sg, r0, g0)
+#define PGCN_HEADS_LAUNCH(KH, RC, GR, FW)                                                                            \
+    hipLaunchKernelGGL((spmm_heads_kernel<KH, RC, GR, FW>), dim3((unsigned)grid), dim3(kThreads), 0, s, rowptr, col,    \
+                       alpha, plane_stride, t4, nt, B, ldb, C, ldc, (int32_t)F, d, partial_ws, flags, nslices, sg, r0,  \
+                       g0, h0)
 #define PGCN_HEADS(KH)                                                                                              \
     case KH:                                                                                                        \
-        if (eg) PGCN_HEADS_LAUNCH(KH, true, true);                                                                   \
-        else if (rc) PGCN_HEADS_LAUNCH(KH, true, false);                                                             \
-        else PGCN_HEADS_LAUNCH(KH, false, false);                                                                    \
+        if (f2) PGCN_HEADS_LAUNCH(KH, true, false, true);                                                            \
+        else if (eg) PGCN_HEADS_LAUNCH(KH, true, true, false);                                                       \
+        else if (rc) PGCN_HEADS_LAUNCH(KH, true, false, false);                                                      \
+        else PGCN_HEADS_LAUNCH(KH, false, false, false);                                                             \
         break;
     switch (heads) {
         PGCN_HEADS(1) PGCN_HEADS(2) PGCN_HEADS(3) PGCN_HEADS(4) PGCN_HEADS(5) PGCN_HEADS(6) PGCN_HEADS(7) PGCN_HEADS(8)
@@ -406,9 +510,13 @@ int launch_heads(const char *who, const int64_t *rowptr, const int32_t *col, con
 #undef PGCN_HEADS
 #undef PGCN_HEADS_LAUNCH
     PGCN_HIP_CHECK(hipGetLastError());
-    if (nfix > 0)      // (GRAD: the ds2 columns of a split row are combined with its features, one list, one launch)
-        return pgcn_spmm_fixup_f32(fix, nfix, nullptr, nullptr, partial_ws, C, ldc, (int32_t)pw,
+    if (nfix > 0) {    // (GRAD: the ds2 columns of a split row are combined with its features, one list, one launch)
+        const int rcf = pgcn_spmm_fixup_f32(fix, nfix, nullptr, nullptr, partial_ws, C, ldc, (int32_t)pw,
+                                            flags & PGCN_SPMM_ACCUMULATE, stream);
+        if (rcf != PGCN_OK || !f2) return rcf;
+        return pgcn_spmm_fixup_f32(fix, nfix, nullptr, nullptr, h0.partial2, h0.C2, h0.ldc2, h0.pw2,
                                    flags & PGCN_SPMM_ACCUMULATE, stream);
+    }
     return PGCN_OK;
 }
 }  // namespace
@@ -418,7 +526,7 @@ extern "C" int pgcn_spmm_heads_f32(const int64_t *rowptr, const int32_t *col, co
                                    const int64_t *seg, int32_t nslices, const int32_t *fix, int64_t nfix,
                                    const float *B, int64_t ldb, float *C, int64_t ldc, float *partial_ws,
                                    int64_t partial_ws_elems, int64_t nslots, uint32_t flags, pgcn_stream_t stream) {
-    return launch_heads("pgcn_spmm_heads_f32", rowptr, col, alpha, plane_stride, nullptr, nullptr, heads, d, nrows, tasks, ntasks, seg,
+    return launch_heads("pgcn_spmm_heads_f32", rowptr, col, alpha, plane_stride, nullptr, nullptr, nullptr, heads, d, nrows, tasks, ntasks, seg,
                         nslices, fix, nfix, B, ldb, C, ldc, partial_ws, partial_ws_elems, nslots, flags, stream);
 }
 
@@ -430,7 +538,7 @@ extern "C" int pgcn_spmm_heads_recompute_f32(const int64_t *rowptr, const int32_
                                              int64_t partial_ws_elems, int64_t nslots, uint32_t flags,
                                              pgcn_stream_t stream) {
     const Recompute rc{reinterpret_cast<const float4 *>(rowstat), s2, lds2, nrows, slope, mode};
-    return launch_heads("pgcn_spmm_heads_recompute_f32", rowptr, col, nullptr, 0, &rc, nullptr, heads, d, nrows, tasks, ntasks,
+    return launch_heads("pgcn_spmm_heads_recompute_f32", rowptr, col, nullptr, 0, &rc, nullptr, nullptr, heads, d, nrows, tasks, ntasks,
                         seg, nslices, fix, nfix, B, ldb, C, ldc, partial_ws, partial_ws_elems, nslots, flags, stream);
 }
 
@@ -442,6 +550,18 @@ extern "C" int pgcn_spmm_heads_grad_f32(const int64_t *rowptr, const int32_t *co
                                         int64_t partial_ws_elems, int64_t nslots, uint32_t flags, pgcn_stream_t stream) {
     const Recompute rc{reinterpret_cast<const float4 *>(rowstat), s2, lds2, nrows, slope, mode};
     const EdgeGrad eg{Z, ldz, t, de, heads * d + (heads + 3) / 4 * 4};
-    return launch_heads("pgcn_spmm_heads_grad_f32", rowptr, col, nullptr, 0, &rc, &eg, heads, d, nrows, tasks, ntasks, seg,
-                        nslices, fix, nfix, B, ldb, C, ldc, partial_ws, partial_ws_elems, nslots, flags, stream);
+    return launch_heads("pgcn_spmm_heads_grad_f32", rowptr, col, nullptr, 0, &rc, &eg, nullptr, heads, d, nrows, tasks, ntasks,
+                        seg, nslices, fix, nfix, B, ldb, C, ldc, partial_ws, partial_ws_elems, nslots, flags, stream);
+}
+
+extern "C" int pgcn_spmm_heads_forward2_f32(const int64_t *rowptr, const int32_t *col, const float *rowstat, const float *s2,
+                                            int64_t lds2, float slope, int32_t mode, int32_t heads, int32_t d, int64_t nrows,
+                                            const int32_t *tasks, int64_t ntasks, const int64_t *seg, int32_t nslices,
+                                            const int32_t *fix, int64_t nfix, const float *B, int64_t ldb, float *C,
+                                            int64_t ldc, float *C2, int64_t ldc2, float *partial_ws,
+                                            int64_t partial_ws_elems, int64_t nslots, uint32_t flags, pgcn_stream_t stream) {
+    const Recompute rc{reinterpret_cast<const float4 *>(rowstat), s2, lds2, nrows, slope, mode};
+    const Forward2 f2{C2, ldc2, nullptr, heads * d + (heads + 3) / 4 * 4};
+    return launch_heads("pgcn_spmm_heads_forward2_f32", rowptr, col, nullptr, 0, &rc, nullptr, &f2, heads, d, nrows, tasks,
+                        ntasks, seg, nslices, fix, nfix, B, ldb, C, ldc, partial_ws, partial_ws_elems, nslots, flags, stream);
 }

@@ -5,13 +5,17 @@ matrix ``z1 + z2^T`` masked with ``A > 0``, a row softmax over all n columns and
 ``attention @ Z``.  Here the same layer runs on the stored entries of rank p's row block:
 
     forward   [Z | s2] boundary rows -> all-to-all-v -> panel Zc = [local rows ; halo rows]
-              alpha = edge softmax(s1_i + s2_j)              (pgcn_gat_edge_softmax_f32)
-              out[:, head k] = A_alpha_k . Zc[:, head k]     (the CSR SpMM kernels, val = alpha plane k)
+              row statistics of the edge softmax(s1_i + s2_j) (pgcn_gat_edge_softmax_f32, alpha = NULL)
+              ONE gather pass (pgcn_spmm_heads_forward2_f32, r03): out = A_alpha . Zc with alpha recomputed per entry,
+                  and V_i = sum_j c_ij Z_j, C_i = sum_j c_ij (c = alpha x LeakyReLU' | alpha + beta) for the backward
+              [shapes it does not cover: alpha planes from the softmax kernel, then pgcn_spmm_heads_f32 / one CSR SpMM
+               per head with val = alpha plane k]
     backward  ONE gather pass over the transposed structure    (pgcn_spmm_heads_grad_f32, r03):
                   dZc[:, head k] = A_alpha_k^T . dOut[:, head k]  (weights recomputed from the row statistics)
                   de_ij = edge gradient from <dOut_i, Z_j> -- Z_j is the task's own row, dOut_i is gathered anyway
                   ds2 = row sums of de (leave with the row)
-              ds1 = column sums of de: row sums over the forward structure (pgcn_csr_row_sums_f32, inverse permutation)
+              ds1_i = sum_j de_ij = <dOut_i, V_i> - t_i C_i from the forward pass's second accumulator: de is never
+                  stored [without it: row sums of de over the forward structure, pgcn_csr_row_sums_f32]
               [shapes the fused kernel does not cover: pgcn_gat_edge_grad_*_f32 (row i gathers Z_j), then the
                transposed product, then ds2 = row sums of de over the transposed structure]
               halo rows of [dZ | ds2] travel back to their owners and are ADDED (reverse all-to-all-v)
@@ -104,10 +108,12 @@ class GatLayerState:
     """Per-layer buffers that live from forward to backward."""
     heads: int
     d: int
-    alpha: torch.Tensor                  # [heads, nnz] head-major edge weights (the SpMM `val` planes)
     beta: torch.Tensor                   # [n_local, heads]  (reference mode)
-    fwd_heads: List[object]              # forward structure with val = alpha[k]
     rowstat: torch.Tensor                # [n_local, heads, 4] (s1, m, 1/D, exp(-m)) of the softmax rows
+    alpha: Optional[torch.Tensor] = None     # [heads, nnz] head-major edge weights (the SpMM `val` planes): only for
+    fwd_heads: Optional[List[object]] = None  # ... the shapes the recomputing kernels do not cover (GatEngine.planes)
+    V: Optional[torch.Tensor] = None     # [n_local, F + heads (+pad)]: V_i | C_i of the two-accumulator forward product
+    fused: bool = False                  # the last forward ran pgcn_spmm_heads_forward2_f32 (no alpha planes, no de)
     Zc: Optional[torch.Tensor] = None    # [(n_local + n_halo), Fp] = [Z | s2 | pad] of local and halo rows
     s2c: Optional[torch.Tensor] = None   # [(n_local + n_halo), heads] s2 of local and halo rows, compact (L2 resident)
     s1: Optional[torch.Tensor] = None
@@ -140,6 +146,8 @@ class GatEngine(BoundaryExchange):
         self.multi_head = _T.gat_multihead and hasattr(kernels, "spmm_heads")
         # the edge gradient inside the transposed product's gather pass (pgcn_spmm_heads_grad_f32)
         self.fused_grad = _T.gat_fused_grad and self.multi_head and hasattr(kernels, "spmm_heads_grad")
+        # ... and the forward product with recomputed weights + the second accumulator that makes de unnecessary
+        self.fused_fwd = _T.gat_fused_forward and self.fused_grad and hasattr(kernels, "spmm_heads_forward2")
 
     @property
     def inv_perm(self) -> torch.Tensor:
@@ -158,11 +166,21 @@ class GatEngine(BoundaryExchange):
         return t
 
     def new_layer_state(self, heads: int, d: int) -> GatLayerState:
-        alpha = torch.zeros((heads, max(self.nnz, 1)), dtype=torch.float32, device=self.device)
         beta = torch.zeros((self.n_local, heads), dtype=torch.float32, device=self.device)
-        views = [self.k.with_values(self.fwd, alpha[k]) for k in range(heads)]
         rowstat = torch.zeros((self.n_local, heads, 4), dtype=torch.float32, device=self.device)
-        return GatLayerState(heads, d, alpha, beta, views, rowstat)
+        return GatLayerState(heads, d, beta, rowstat)
+
+    def planes(self, st: GatLayerState) -> torch.Tensor:
+        """The alpha planes of ``st`` (4 bytes per entry and head), allocated when a path first needs them."""
+        if st.alpha is None:
+            st.alpha = torch.zeros((st.heads, max(self.nnz, 1)), dtype=torch.float32, device=self.device)
+            st.fwd_heads = [self.k.with_values(self.fwd, st.alpha[k]) for k in range(st.heads)]
+        return st.alpha
+
+    def covers(self, heads: int, d: int) -> bool:
+        """Shapes of the recomputing kernels (pgcn_spmm_heads_forward2_f32 / _grad_f32): 8, 16, 32 or 64 lanes per head."""
+        hl = d // 4
+        return d % 4 == 0 and hl >= 8 and hl & (hl - 1) == 0 and heads * d <= 256 and heads <= 8
 
     @staticmethod
     def padded_width(F: int, heads: int) -> int:
@@ -195,12 +213,23 @@ class GatEngine(BoundaryExchange):
         if st.s2c is None or st.s2c.shape != (n_p + n_h, K):
             st.s2c = torch.empty((n_p + n_h, K), dtype=torch.float32, device=self.device)
         st.s2c.copy_(Zc[:, F:F + K])        # compact: the per-entry s2 gathers stay in L2 instead of striding the panel
-        self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,
-                                st.alpha, st.beta, st.rowstat)
         out = torch.empty((n_p, F), dtype=torch.float32, device=self.device)
-        if not (self.multi_head and self.k.spmm_heads(self.fwd, st.alpha, Zc, out, K, d)):
-            for k in range(K):            # shapes the one-launch kernel does not cover: one SpMM per head
-                self.k.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], out[:, k * d:(k + 1) * d])
+        st.fused = False
+        if self.fused_fwd and self.covers(K, d):
+            # statistics only, then ONE gather pass: out, and V | C for the backward's ds1 (no alpha planes, no de)
+            self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,
+                                    None, st.beta, st.rowstat)
+            pw2 = F + (K + 3) // 4 * 4
+            if st.V is None or st.V.shape != (n_p, pw2):
+                st.V = torch.empty((n_p, pw2), dtype=torch.float32, device=self.device)
+            st.fused = self.k.spmm_heads_forward2(self.fwd, st.rowstat, st.s2c, self.slope, self.mode_id, Zc, out, st.V, K, d)
+        if not st.fused:
+            alpha = self.planes(st)
+            self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,
+                                    alpha, st.beta, st.rowstat)
+            if not (self.multi_head and self.k.spmm_heads(self.fwd, alpha, Zc, out, K, d)):
+                for k in range(K):            # shapes the one-launch kernel does not cover: one SpMM per head
+                    self.k.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], out[:, k * d:(k + 1) * d])
         if self.mode_id == 1:                               # + beta_i * (sum over ALL vertices of Z_j)
             zsum = self._allreduce(Z.sum(0))
             out.view(n_p, K, d).addcmul_(st.beta.view(n_p, K, 1), zsum.view(1, K, d))
@@ -217,6 +246,13 @@ class GatEngine(BoundaryExchange):
         dOut = dOut.contiguous()
         t = (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
         dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
+        if st.fused:
+            # one gather pass: dZc = A_alpha^T . dOut and ds2 = the row sums of the edge gradient, which is not stored:
+            # ds1 = its column sums = <dOut_i, V_i> - t_i C_i from the forward pass's second accumulator
+            if not self.k.spmm_heads_grad(self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, st.Zc, t, dZc, None, K, d):
+                raise RuntimeError("pgcn_spmm_heads_grad_f32 refused a shape pgcn_spmm_heads_forward2_f32 took")
+            ds1 = (dOut.view(n_p, K, d) * st.V[:, :F].view(n_p, K, d)).sum(-1) - t * st.V[:, F:F + K]
+            return self._finish_backward(st, dOut, dZc, ds1)
         if self.fused_grad:
             # one gather pass: dZc = A_alpha^T . dOut, de (entry-major, TRANSPOSED storage order) and ds2 = its row sums
             de_t = self._scratch.get(("de_t", K))

@@ -456,13 +456,52 @@ class HipKernels:
         _lib.check(rc, "pgcn_spmm_heads_recompute_f32")
         return True
 
+    def spmm_heads_forward2(self, A: DeviceCSR, rowstat: torch.Tensor, s2: torch.Tensor, slope: float, mode: int,
+                            B: torch.Tensor, C: torch.Tensor, C2: torch.Tensor, heads: int, d: int,
+                            accumulate: bool = False) -> bool:
+        """The forward product with the weights recomputed from the row statistics (no alpha planes) and a second
+        accumulator (pgcn_spmm_heads_forward2_f32): C[:, :F] (+)= A_alpha . B; C2[:, :F] (+)= V = sum_j c_ij B_j and
+        C2[:, F:F+heads] (+)= sum_j c_ij with c = alpha x LeakyReLU' (standard) or alpha + beta (reference), from
+        which the backward pass gets ds1 = <dOut, V> - t C without a per-entry gradient.  rowstat: [A.nrows, heads, 4];
+        s2: [A.ncols, heads].  False = shape not covered (d must be 32, 64, 128 or 256)."""
+        F = heads * d
+        hl = d // 4
+        if d % 4 or hl < 8 or hl & (hl - 1) or F > 256 or heads > 8:
+            return False
+        pw2 = F + (heads + 3) // 4 * 4
+        self._check_rows(s2, A.ncols, heads, "s2")
+        if not (rowstat.is_cuda and rowstat.dtype is torch.float32 and rowstat.is_contiguous()
+                and rowstat.numel() == A.nrows * heads * 4):
+            raise _lib.PgcnError("rowstat must be a contiguous fp32 [nrows, heads, 4] CUDA tensor")
+        self._check_dense(B, A.ncols, "B")
+        self._check_dense(C, A.nrows, "C")
+        self._check_dense(C2, A.nrows, "C2")
+        if B.shape[1] < F or C.shape[1] < F or C2.shape[1] < pw2 or A.row_map is not None:
+            raise _lib.PgcnError("B / C narrower than heads * d, C2 narrower than heads * d + heads (rounded up to 4), "
+                                 "or a compact-row structure")
+        need = A.nslots * (F + pw2)
+        if need and (A.ws is None or A.ws.numel() < need):
+            A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            A.launch_cache.clear()
+        flags = _lib.SPMM_ACCUMULATE if accumulate else 0
+        rc = self.lib.pgcn_spmm_heads_forward2_f32(
+            A.rowptr.data_ptr(), A.col.data_ptr(), rowstat.data_ptr(), s2.data_ptr(), s2.stride(0), slope, mode, heads, d,
+            A.nrows, _ptr(A.tasks), A.ntasks, A.seg, A.nslices, _ptr(A.fix), A.nfix, B.data_ptr(), B.stride(0),
+            C.data_ptr(), C.stride(0), C2.data_ptr(), C2.stride(0), _ptr(A.ws), 0 if A.ws is None else A.ws.numel(),
+            A.nslots, flags, self._stream())
+        if rc == _lib.PGCN_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "pgcn_spmm_heads_forward2_f32")
+        return True
+
     def spmm_heads_grad(self, AT: DeviceCSR, rowstat: torch.Tensor, s2: torch.Tensor, slope: float, mode: int,
-                        B: torch.Tensor, Z: torch.Tensor, t: torch.Tensor, C: torch.Tensor, de: torch.Tensor, heads: int,
-                        d: int, accumulate: bool = False) -> bool:
+                        B: torch.Tensor, Z: torch.Tensor, t: torch.Tensor, C: torch.Tensor, de: Optional[torch.Tensor],
+                        heads: int, d: int, accumulate: bool = False) -> bool:
         """The transposed product of ``spmm_heads_recompute`` AND the edge gradient of the same (i, j) pairs in one
         gather pass (pgcn_spmm_heads_grad_f32): C[:, :F] (+)= A_alpha^T . B, de[q] = the edge gradient of entry q of
         ``AT`` (entry-major [nnz, heads]), C[:, F:F+heads] (+)= its row sums (ds2).  Z: rows of AT ([>= AT.nrows, >= F]),
-        t: [AT.ncols, heads].  False = shape not covered (d must be 32, 64, 128 or 256)."""
+        t: [AT.ncols, heads].  de = None: the per-entry gradient is not kept (ds1 then comes from the forward pass's
+        second accumulator, ``spmm_heads_forward2``).  False = shape not covered (d must be 32, 64, 128 or 256)."""
         F = heads * d
         hl = d // 4
         if d % 4 or hl < 8 or hl & (hl - 1) or F > 256 or heads > 8:
@@ -480,7 +519,8 @@ class HipKernels:
         if B.shape[1] < F or Z.shape[1] < F or C.shape[1] < pw or AT.row_map is not None or t.stride(0) != heads:
             raise _lib.PgcnError("B / Z narrower than heads * d, C narrower than heads * d + heads (rounded up to 4), "
                                  "t not contiguous, or a compact-row structure")
-        if not (de.is_cuda and de.dtype is torch.float32 and de.is_contiguous() and de.numel() >= nnz * heads):
+        if de is not None and not (de.is_cuda and de.dtype is torch.float32 and de.is_contiguous()
+                                   and de.numel() >= nnz * heads):
             raise _lib.PgcnError("de must be a contiguous fp32 CUDA tensor of nnz * heads elements")
         need = AT.nslots * pw
         if need and (AT.ws is None or AT.ws.numel() < need):
@@ -490,7 +530,7 @@ class HipKernels:
         rc = self.lib.pgcn_spmm_heads_grad_f32(
             AT.rowptr.data_ptr(), AT.col.data_ptr(), rowstat.data_ptr(), s2.data_ptr(), s2.stride(0), slope, mode, heads, d,
             AT.nrows, _ptr(AT.tasks), AT.ntasks, AT.seg, AT.nslices, _ptr(AT.fix), AT.nfix, B.data_ptr(), B.stride(0),
-            Z.data_ptr(), Z.stride(0), t.data_ptr(), C.data_ptr(), C.stride(0), de.data_ptr(), _ptr(AT.ws),
+            Z.data_ptr(), Z.stride(0), t.data_ptr(), C.data_ptr(), C.stride(0), _ptr(de), _ptr(AT.ws),
             0 if AT.ws is None else AT.ws.numel(), AT.nslots, flags, self._stream())
         if rc == _lib.PGCN_EUNSUPPORTED:
             return False
@@ -498,20 +538,27 @@ class HipKernels:
         return True
 
     def gat_edge_softmax(self, A: DeviceCSR, s1, s2, heads: int, slope: float, mode: int, n_global: int,
-                         alpha: torch.Tensor, beta: torch.Tensor, rowstat: Optional[torch.Tensor] = None) -> None:
+                         alpha: Optional[torch.Tensor], beta: torch.Tensor, rowstat: Optional[torch.Tensor] = None) -> None:
+        """alpha = None: the per-row statistics only (``rowstat`` required) -- the products recompute the weights."""
         self._check_rows(s1, A.nrows, heads, "s1")
         self._check_rows(s2, A.ncols, heads, "s2")
-        self._check_rows(alpha, heads, alpha.shape[1], "alpha")
         self._check_rows(beta, A.nrows, heads, "beta")
         nnz = A.col.numel()
-        if (nnz and alpha.shape[1] != nnz) or alpha.stride(0) != alpha.shape[1] or beta.stride(0) != heads:
-            raise _lib.PgcnError("alpha must be [heads, nnz] and beta [nrows, heads], both contiguous")
+        if alpha is None:
+            if rowstat is None:
+                raise _lib.PgcnError("alpha = None needs rowstat")
+        else:
+            self._check_rows(alpha, heads, alpha.shape[1], "alpha")
+            if (nnz and alpha.shape[1] != nnz) or alpha.stride(0) != alpha.shape[1]:
+                raise _lib.PgcnError("alpha must be [heads, nnz], contiguous")
+        if beta.stride(0) != heads:
+            raise _lib.PgcnError("beta must be [nrows, heads], contiguous")
         if rowstat is not None and not (rowstat.is_cuda and rowstat.dtype is torch.float32 and rowstat.is_contiguous()
                                         and rowstat.numel() == A.nrows * heads * 4):
             raise _lib.PgcnError("rowstat must be a contiguous fp32 [nrows, heads, 4] CUDA tensor")
         _lib.check(self.lib.pgcn_gat_edge_softmax_f32(
             A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, *self._lists(A), s1.data_ptr(),
-            s1.stride(0), s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, alpha.data_ptr(), beta.data_ptr(),
+            s1.stride(0), s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, _ptr(alpha), beta.data_ptr(),
             _ptr(rowstat), self._stream()), "pgcn_gat_edge_softmax_f32")
 
     def gat_edge_weights_t(self, AT: DeviceCSR, s2, rowstat: torch.Tensor, heads: int, slope: float, mode: int,

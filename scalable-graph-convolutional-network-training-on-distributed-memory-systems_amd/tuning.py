@@ -62,6 +62,7 @@ class Tuning:
     gat_task_grad: bool = True       # edge gradient over the SpMM plan's balanced tasks
     gat_multihead: bool = True       # all heads of attention @ Z in one launch
     gat_fused_grad: bool = True      # edge gradient inside the transposed product's gather pass (one pass fewer)
+    gat_fused_forward: bool = True   # forward product with recomputed weights + second accumulator (no alpha / de arrays)
 
 
 def _parse(spec: str, base: Tuning) -> Tuning:

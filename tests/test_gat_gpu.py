@@ -536,6 +536,10 @@ def test_edge_gradient_fused_into_the_transposed_product(K, dev, mode, heads, d,
             g = g * np.where(s1n[er, k] + s2n[ec, k] > 0, 1.0, 0.2)
         exp[:, k] = g
     assert rel_err(de_t.cpu().numpy(), exp[perm.cpu().numpy()]) < 5 * TOL
+    # de = NULL (not kept): the same product and the same ds2
+    got3 = torch.full((m, pw), float("nan"), device=dev)
+    assert K.spmm_heads_grad(dT, rowstat, s2, 0.2, mode_id, dOut, Zd, t, got3, None, heads, d)
+    assert torch.equal(got3, got)
     # deterministic, and accumulate adds to what is there (features AND the ds2 columns)
     got2, de2 = torch.empty_like(got), torch.empty_like(de_t)
     K.spmm_heads_grad(dT, rowstat, s2, 0.2, mode_id, dOut, Zd, t, got2, de2, heads, d)
@@ -544,6 +548,74 @@ def test_edge_gradient_fused_into_the_transposed_product(K, dev, mode, heads, d,
     acc = base.clone()
     K.spmm_heads_grad(dT, rowstat, s2, 0.2, mode_id, dOut, Zd, t, acc, de2, heads, d, accumulate=True)
     assert rel_err((acc - base)[:, :F + heads].cpu().numpy(), got[:, :F + heads].cpu().numpy()) < TOL
+
+
+@pytest.mark.parametrize("mode", ["standard", "reference"])
+@pytest.mark.parametrize("heads,d", [(4, 64), (2, 32), (1, 256), (3, 64), (8, 32)])
+@pytest.mark.parametrize("nslices,chunk", [(1, 1024), (8, 1024), (8, 32)])
+def test_forward_product_with_recomputed_weights_and_second_accumulator(K, dev, mode, heads, d, nslices, chunk):
+    """pgcn_spmm_heads_forward2_f32 (r03): out = A_alpha . Z with alpha recomputed from the row statistics (softmax
+    called with alpha = NULL) == the planes route BIT FOR BIT; V_i = sum_j c_ij Z_j and C_i = sum_j c_ij (c = alpha x
+    LeakyReLU' | alpha + beta) against float64; and what they are for: <dOut_i, V_i> - t_i C_i == ds1 of the edge-gradient
+    kernel.  Direct rows, split rows, XCD slices, an empty row, accumulate."""
+    n, m = 400, 360
+    A, rng = _graph(n, m, 17 * heads + d)
+    A.sort_indices()
+    mode_id = {"standard": 0, "reference": 1}[mode]
+    old, K.chunk = K.chunk, chunk
+    try:
+        dA, dT, perm, er, ec = _structure(K, A, nslices, 1 << 30)
+    finally:
+        K.chunk = old
+    nnz, F = A.nnz, heads * d
+    pw = F + (heads + 3) // 4 * 4
+    Zd = torch.from_numpy((rng.standard_normal((m, pw)) * 0.7).astype(np.float32)).to(dev)
+    s1 = torch.from_numpy((rng.standard_normal((n, heads)) * 1.5).astype(np.float32)).to(dev)
+    s2 = Zd[:, F:F + heads].contiguous()
+    alpha = torch.empty((heads, nnz), device=dev)
+    beta = torch.zeros((n, heads), device=dev)
+    rowstat = torch.empty((n, heads, 4), device=dev)
+    K.gat_edge_softmax(dA, s1, s2, heads, 0.2, mode_id, 1000, alpha, beta, rowstat)
+    beta2, rowstat2 = torch.zeros_like(beta), torch.empty_like(rowstat)
+    K.gat_edge_softmax(dA, s1, s2, heads, 0.2, mode_id, 1000, None, beta2, rowstat2)     # statistics only
+    assert torch.equal(rowstat, rowstat2) and torch.equal(beta, beta2)
+    if mode == "standard":
+        beta.zero_()
+    ref = torch.full((n, F), float("nan"), device=dev)
+    assert K.spmm_heads(dA, alpha, Zd, ref, heads, d)
+    got = torch.full((n, F), float("nan"), device=dev)
+    V = torch.full((n, pw), float("nan"), device=dev)
+    assert K.spmm_heads_forward2(dA, rowstat, s2, 0.2, mode_id, Zd, got, V, heads, d)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert torch.isfinite(V).all() and (V[:, F + heads:] == 0).all()
+    a = alpha.cpu().numpy().astype(np.float64); b = beta.cpu().numpy().astype(np.float64)
+    Zn = Zd.cpu().numpy().astype(np.float64)
+    s1n, s2n = s1.cpu().numpy().astype(np.float64), s2.cpu().numpy().astype(np.float64)
+    Vexp, Cexp = np.zeros((n, F)), np.zeros((n, heads))
+    for k in range(heads):
+        c = a[k] * np.where(s1n[er, k] + s2n[ec, k] > 0, 1.0, 0.2) if mode == "standard" else a[k] + b[er, k]
+        Vexp[:, k * d:(k + 1) * d] = sp.csr_matrix((c, (er, ec)), shape=A.shape) @ Zn[:, k * d:(k + 1) * d]
+        Cexp[:, k] = np.bincount(er, weights=c, minlength=n)
+    assert rel_err(V[:, :F].cpu().numpy(), Vexp) < 5 * TOL
+    assert rel_err(V[:, F:F + heads].cpu().numpy(), Cexp) < 5 * TOL
+    # ds1 without a per-entry gradient
+    dOut = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(dev)
+    t = torch.from_numpy(rng.standard_normal((n, heads)).astype(np.float32)).to(dev)
+    de0, ds1_0 = torch.empty((nnz, heads), device=dev), torch.empty((n, heads), device=dev)
+    K.gat_edge_grad(dA, s1, s2, alpha, beta, Zd, dOut, t, heads, d, 0.2, mode_id, de0, ds1_0)
+    ds1 = (dOut.view(n, heads, d) * V[:, :F].view(n, heads, d)).sum(-1) - t * V[:, F:F + heads]
+    assert rel_err(ds1.cpu().numpy(), ds1_0.cpu().numpy()) < 20 * TOL
+    # deterministic; accumulate adds to both outputs
+    got2, V2 = torch.empty_like(got), torch.empty_like(V)
+    K.spmm_heads_forward2(dA, rowstat, s2, 0.2, mode_id, Zd, got2, V2, heads, d)
+    assert torch.equal(got, got2) and torch.equal(V, V2)
+    b1 = torch.from_numpy(rng.random((n, F), dtype=np.float32)).to(dev)
+    b2 = torch.from_numpy(rng.random((n, pw), dtype=np.float32)).to(dev)
+    a1, a2 = b1.clone(), b2.clone()
+    K.spmm_heads_forward2(dA, rowstat, s2, 0.2, mode_id, Zd, a1, a2, heads, d, accumulate=True)
+    assert rel_err((a1 - b1).cpu().numpy(), got.cpu().numpy()) < TOL
+    assert rel_err((a2 - b2)[:, :F + heads].cpu().numpy(), V[:, :F + heads].cpu().numpy()) < TOL
 
 
 def test_fused_edge_gradient_unsupported_shapes_fall_back(K, dev):

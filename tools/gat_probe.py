@@ -45,23 +45,31 @@ def main():
     out["forward_ms"] = timed(lambda: eng.forward(st, Z, s1, s2))
     out["backward_ms"] = timed(lambda: eng.backward(st, G))
     Zc, Fh = st.Zc, F
-    out["softmax_ms"] = timed(lambda: K.gat_edge_softmax(eng.fwd, st.s1, st.s2c, heads, eng.slope, eng.mode_id, n, st.alpha, st.beta, st.rowstat))
+    alpha = eng.planes(st)            # (the engine's fused path keeps no planes; the stand-alone pieces below need them)
+    out["softmax_ms"] = timed(lambda: K.gat_edge_softmax(eng.fwd, st.s1, st.s2c, heads, eng.slope, eng.mode_id, n, alpha, st.beta, st.rowstat))
+    out["softmax_stats_only_ms"] = timed(lambda: K.gat_edge_softmax(eng.fwd, st.s1, st.s2c, heads, eng.slope, eng.mode_id, n, None, st.beta, st.rowstat))
+    o1 = torch.empty(n, F, device=dev); V = torch.empty(n, F + (heads + 3) // 4 * 4, device=dev)
+    cov = [True]
+    def fwd2():
+        cov[0] = K.spmm_heads_forward2(eng.fwd, st.rowstat, st.s2c, eng.slope, eng.mode_id, Zc, o1, V, heads, d)
+    out["heads_forward2_ms"] = timed(fwd2)
+    out["heads_forward2_covered"] = bool(cov[0])
     o = torch.empty(n, F, device=dev)
     out["spmm_heads_ms"] = timed(lambda: [K.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], o[:, k * d:(k + 1) * d]) for k in range(heads)])
     t = (G.view(n, heads, d) * st.out.view(n, heads, d)).sum(-1).contiguous()
     de = torch.empty(max(nnz, 1), heads, device=dev); ds1 = torch.empty(n, heads, device=dev)   # de: entry-major
-    out["edge_grad_ms"] = timed(lambda: K.gat_edge_grad(eng.fwd, st.s1, st.s2c, st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1))
+    out["edge_grad_ms"] = timed(lambda: K.gat_edge_grad(eng.fwd, st.s1, st.s2c, alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1))
     ds1p = torch.empty(n, 8, heads, device=dev)
-    out["edge_grad_sliced_ms"] = timed(lambda: K.gat_edge_grad_sliced(eng.fwd, st.s1, st.s2c, st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1p))
+    out["edge_grad_sliced_ms"] = timed(lambda: K.gat_edge_grad_sliced(eng.fwd, st.s1, st.s2c, alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1p))
     at = eng._plane_scratch("alpha_t", heads)
-    out["permute_ms"] = timed(lambda: K.csr_permute(st.alpha, eng.perm, at))
+    out["permute_ms"] = timed(lambda: K.csr_permute(alpha, eng.perm, at))
     out["weights_t_ms"] = timed(lambda: K.gat_edge_weights_t(eng.bwd, st.s2c, st.rowstat, heads, eng.slope, eng.mode_id, at))
     ds2 = torch.empty(n, heads, device=dev)
     out["row_sums_ms"] = timed(lambda: K.csr_row_sums(eng.bwd, eng.perm, de, heads, ds2))
     ds1t = torch.empty(n, heads, device=dev)
-    out["edge_grad_tasks_ms"] = timed(lambda: K.gat_edge_grad_tasks(eng.fwd, st.s1, st.s2c, st.alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1t))
+    out["edge_grad_tasks_ms"] = timed(lambda: K.gat_edge_grad_tasks(eng.fwd, st.s1, st.s2c, alpha, st.beta, Zc, G, t, heads, d, eng.slope, eng.mode_id, de, ds1t))
     o2 = torch.empty(n, F, device=dev)
-    out["spmm_heads_kernel_ms"] = timed(lambda: K.spmm_heads(eng.fwd, st.alpha, Zc, o2, heads, d))
+    out["spmm_heads_kernel_ms"] = timed(lambda: K.spmm_heads(eng.fwd, alpha, Zc, o2, heads, d))
     dzc = torch.empty(Zc.shape[0], Zc.shape[1], device=dev)
     out["heads_recompute_T_ms"] = timed(lambda: K.spmm_heads_recompute(eng.bwd, st.rowstat, st.s2c, eng.slope, eng.mode_id, G, dzc, heads, d))
     de_t = torch.empty(max(nnz, 1), heads, device=dev)

@@ -45,9 +45,11 @@ def main():
     G = torch.randn(n, F, device=dev, generator=gen)
     ref = eng.forward(st, Z, s1, s2).clone()
     Zc = st.Zc
+    alpha = eng.planes(st)
+    K.gat_edge_softmax(eng.fwd, st.s1, st.s2c, heads, eng.slope, eng.mode_id, n, alpha, st.beta, st.rowstat)
     out = {"n": n, "nnz": eng.nnz, "heads": heads, "d": d}
     o = torch.empty(n, F, device=dev)
-    out["heads_kernel_ms"] = timed(lambda: K.spmm_heads(eng.fwd, st.alpha, Zc, o, heads, d))
+    out["heads_kernel_ms"] = timed(lambda: K.spmm_heads(eng.fwd, alpha, Zc, o, heads, d))
     out["per_head_gather_ms"] = timed(lambda: [K.spmm(st.fwd_heads[k], Zc[:, k * d:(k + 1) * d], o[:, k * d:(k + 1) * d]) for k in range(heads)])
     dz = torch.empty(Zc.shape[0], Zc.shape[1], device=dev)
     out["heads_recompute_T_ms"] = timed(lambda: K.spmm_heads_recompute(eng.bwd, st.rowstat, st.s2c, eng.slope, eng.mode_id, G, dz, heads, d))
@@ -57,7 +59,7 @@ def main():
     c = eng.fwd.col.to(torch.int64)
     tiled = []
     for k in range(heads):
-        h = partition.csr_from_coo(r, c, st.alpha[k].clone(), n, Zc.shape[0], core=True)
+        h = partition.csr_from_coo(r, c, alpha[k].clone(), n, Zc.shape[0], core=True)
         tiled.append(K.prepare(h))
         if k == 0:
             out["parts"] = {"gather": int(h.col.numel()), "strip": 0 if h.strip is None else h.strip.nnz,
