@@ -22,6 +22,9 @@ SHAPES = {
     "cora": (2708, 10556, 16, 2),
     "reddit": (232965, 114615892, 128, 3),
     "products": (2449029, 123718280, 128, 3),
+    # config 3's shape at quarter scale: the largest products-shaped SBM graph the reference's serial PaToH front-end
+    # partitions within two hours here (tools/make_partvecs.py; the full size ran > 4 h) -- its hp vector is committed
+    "products4": (612257, 30929570, 128, 3),
     # mid-size case small enough for the reference's 32-bit PaToH / METIS front-ends: part vectors written by
     # them are committed under tests/golden/partvec/ (tools/make_partvecs.py)
     "mid": (131072, 4194304, 64, 2),

@@ -5,7 +5,8 @@ cp $src/pytest_gpu.txt $dst/${tag}_pytest_gpu.txt
 cp $src/bench.json $dst/${tag}_bench_stdout.json
 cp $src/pmc_traffic.json $dst/pmc_traffic.json
 for w in products sbm mid gat; do [ -s $src/bench_$w.json ] && cp $src/bench_$w.json $dst/${tag}_bench_${w}_stdout.json; done
-for f in $src/bench_rank_*.json $src/bench_gat_rank_*.json $src/bench_products_sbm_*.json; do [ -s "$f" ] && cp "$f" $dst/${tag}_$(basename $f); done
+for f in $src/bench_rank_*.json $src/bench_gat_rank_*.json $src/bench_products*_sbm_*.json; do [ -s "$f" ] && cp "$f" $dst/${tag}_$(basename $f); done
 for f in $src/pmc_summary_*.txt; do n=$(basename $f .txt | sed 's/pmc_summary_//'); grep -v "^$" $f > $dst/${tag}_pmc_$n.txt; done
 st=$(ls $src/prof/*kernel_stats.csv $src/prof/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$st" ] && head -45 "$st" > $dst/${tag}_bench_kernel_stats.csv
+sg=$(ls $src/prof_gat/*kernel_stats.csv $src/prof_gat/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$sg" ] && grep -E "Name|spmm_heads|gat_|csr_row_sums|fixup|nll|rows_kernel" "$sg" | head -30 > $dst/${tag}_bench_gat_kernel_stats.csv
 ls -la $dst | grep ${tag}_

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round evidence in one gpurun call: GPU tests, smoke, default bench, rocprofv3 kernel stats of the bench command, PMC
 # traffic passes per launch group (tools/group_probe.py: the block exactly as bench.py builds it), the other workloads
-# (products, SBM, mid, GAT) and the shard shapes (--emulate-rank).  usage: bash tools/final_profile.sh r03 [hp-partvec]
+# (products, SBM, mid, GAT) and the shard shapes (--emulate-rank).  usage: bash tools/final_profile.sh r03 [hp-partvec workload]
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 tag=${1:-r03}
-HP=${2:-tests/golden/partvec/products-sbm.A.mtx.8.hp.gz}
+HP=${2:-tests/golden/partvec/products4-sbm.A.mtx.8.hp.gz}; W3=${3:-products4}
 out=gpurun_out/final_$tag; rm -rf $out; mkdir -p $out
 timeout 2400 python -m pytest tests -m gpu -q > $out/pytest_gpu_full.txt 2>&1; grep -E "passed|failed|error" $out/pytest_gpu_full.txt | tail -3 | tee $out/pytest_gpu.txt
 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $out/smoke.txt
@@ -31,14 +31,16 @@ python bench.py --workload products --steps 5 --warmup 2 --no-cpu-baseline > $ou
 python bench.py --generator sbm --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_sbm.json 2>/dev/null
 python bench.py --workload mid --steps 10 --warmup 2 > $out/bench_mid.json 2>/dev/null
 python bench.py --workload reddit-gat --steps 5 --warmup 2 > $out/bench_gat.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_gat -o gat -- python bench.py --workload reddit-gat --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/prof_gat_stdout.log 2> $out/prof_gat_stderr.log
+rm -f $out/prof_gat/*kernel_trace.csv $out/prof_gat/*/*kernel_trace.csv
 for rp in 0/8 3/8 7/8 0/4 0/2; do t=$(echo $rp | tr '/' '_')
   python bench.py --emulate-rank $rp --graph --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rank_$t.json 2>/dev/null
 done
 python bench.py --workload reddit-gat --emulate-rank 0/4 --steps 5 --warmup 2 > $out/bench_gat_rank_0_4.json 2>/dev/null
 if [ -f "$HP" ]; then
   for r in 0 3; do
-    python bench.py --workload products --generator sbm --partvec $HP --emulate-rank $r/8 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_products_sbm_hp_rank_${r}_8.json 2>/dev/null
-    python bench.py --workload products --generator sbm --emulate-rank $r/8 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_products_sbm_rp_rank_${r}_8.json 2>/dev/null
+    python bench.py --workload $W3 --generator sbm --partvec $HP --emulate-rank $r/8 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_${W3}_sbm_hp_rank_${r}_8.json 2>/dev/null
+    python bench.py --workload $W3 --generator sbm --emulate-rank $r/8 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_${W3}_sbm_rp_rank_${r}_8.json 2>/dev/null
   done
 fi
 for f in $out/bench*.json; do python - <<PY

@@ -2,7 +2,7 @@
 """FALLBACK part vector for graphs the reference's partitioner front-ends cannot finish in the build container: a
 seeded COMMUNITY-BLOCK vector -- label propagation (partition.label_propagation, the same routine the engine's
 vertex order uses) finds communities, which are packed into k parts of equal stored-entry weight, largest first
-(LPT).  NOT produced by the reference's tools: files carry the extension `.cb` and the statistics say so.  Runs
+(LPT).  NOT produced by the reference's tools: files carry the extension `.cb.gz` and the statistics say so.  Runs
 anywhere (no /root/reference needed).
 
 usage: python tools/make_block_partvec.py --workload products --generator sbm --k 8"""
@@ -41,6 +41,10 @@ def main():
     label = a.workload + ("-sbm" if a.generator == "sbm" else "")
     out = os.path.join(ROOT, "tests", "golden", "partvec", "%s.A.mtx.%d.cb" % (label, a.k))
     io_.write_partvec(out, pv.numpy())
+    import gzip, shutil                      # committed compressed (partition.read_partvec reads .gz)
+    with open(out, "rb") as fi, gzip.open(out + ".gz", "wb", compresslevel=9) as fo:
+        shutil.copyfileobj(fi, fo)
+    os.remove(out)
     row, col = row.cpu(), col.cpu()
     rec = {}
     for name, v in (("cb", pv), ("rp", synth.random_partvec(n, a.k, seed=0))):
