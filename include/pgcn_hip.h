@@ -303,7 +303,8 @@ int pgcn_spmm_heads_forward2_f32(const int64_t *rowptr, const int32_t *col, cons
  * and its permutation this is ds2_j = sum_i de_ij.
  * pgcn_csr_permute_f32: dst[k][p] = src[k][perm[p]] (values of A^T from values of A).
  * rowstat (optional output of the softmax, [nrows x heads x 4] fp32, 16-byte aligned) = (s1, m, 1/D,
- * exp(-m) or 0) per row and head (with rowstat given, alpha may be NULL: statistics only); pgcn_gat_edge_weights_t_f32 recomputes from it the alpha planes
+ * exp(-m) or 0) per row and head (with rowstat given, alpha may be NULL: statistics only);
+ * pgcn_gat_edge_weights_t_f32 recomputes from it the alpha planes
  * in the storage order of the TRANSPOSED structure (rowptr_t/col_t; s2 indexed by its rows) --
  * the same numbers as permuting alpha, without the 4-byte random gathers.
  * All sums run in a fixed order: bit-reproducible, no atomics.                                  */
