@@ -199,6 +199,7 @@ def gat_layers_worker(rank, P, port, path_A, path_pv, mode, heads, f, L, seed, q
            "dH": H.grad.cpu().numpy(), "dW": [l.linear.weight.grad.cpu().numpy() for l in layers],
            "da": [l.attention.grad.cpu().numpy() for l in layers], "ok_halo": ok_halo,
            "comm_grad": H2.grad.cpu().numpy(), "n_send_rows": int(eng.n_send),
+           "fused": [bool(l._state.fused) for l in layers],
            "provider": type(M._kernel_provider).__name__})
     dist.barrier()
     dist.destroy_process_group()

@@ -107,7 +107,8 @@ def _gat_edge_softmax(self, A, s1, s2, heads, slope, mode, n_global, alpha, beta
         if nz:
             D[ne] += np.add.reduceat(w, starts)
         inv = np.where(D > 0, 1 / np.where(D > 0, D, 1), 0).astype(np.float32)
-        alpha[k, :nz] = torch.from_numpy((w - em[A.seg]) * inv[A.seg])
+        if alpha is not None:                              # (None: statistics only, like the device kernel)
+            alpha[k, :nz] = torch.from_numpy((w - em[A.seg]) * inv[A.seg])
         if mode == 1:
             beta[:, k] = torch.from_numpy(em * inv)
         if rowstat is not None:
@@ -161,6 +162,98 @@ def _gat_edge_grad_sliced(self, *a, **k):
     return False                                         # no sliced variant in the stand-in: the caller falls back
 
 
+# ---- the one-launch multi-head products and the fused passes (pgcn_spmm_heads.hip), same shape rules ----------
+def _heads_ok(heads, d):
+    return heads <= 8 and heads * d <= 256 and d % 4 == 0
+
+
+def _fused_ok(heads, d):
+    hl = d // 4
+    return _heads_ok(heads, d) and hl >= 8 and hl & (hl - 1) == 0
+
+
+def _csr(A, w):
+    import scipy.sparse as sp
+    return sp.csr_matrix((w.astype(np.float64), A.col, A.rowptr), shape=(A.nrows, A.ncols))
+
+
+def _put(C, cols, val, accumulate):
+    t = torch.from_numpy(np.ascontiguousarray(val).astype(np.float32))
+    if accumulate:
+        C[:t.shape[0], cols] += t
+    else:
+        C[:t.shape[0], cols] = t
+
+
+def _spmm_heads(self, A, alpha, B, C, heads, d, accumulate=False):
+    if not _heads_ok(heads, d):
+        return False
+    nz, Bn = A.col.shape[0], B.detach().numpy().astype(np.float64)
+    for k in range(heads):
+        _put(C, slice(k * d, (k + 1) * d), _csr(A, alpha.numpy()[k, :nz]) @ Bn[:, k * d:(k + 1) * d], accumulate)
+    return True
+
+
+def _recomputed(st, s2v, slope, mode):
+    """(alpha, raw) of entries whose softmax row has statistics ``st`` (s1, m, 1/D, exp(-m)) and whose other end has s2v."""
+    raw = st[:, 0] + s2v
+    r = np.where(raw > 0, raw, raw * np.float32(slope)) if mode == 0 else raw
+    return ((np.exp(r - st[:, 1]) - st[:, 3]) * st[:, 2]).astype(np.float32), raw
+
+
+def _spmm_heads_recompute(self, AT, rowstat, s2, slope, mode, B, C, heads, d, accumulate=False):
+    if not _heads_ok(heads, d):
+        return False
+    Bn = B.detach().numpy().astype(np.float64)
+    for k in range(heads):
+        w, _ = _recomputed(rowstat.numpy()[AT.col, k], s2.numpy()[AT.seg, k], slope, mode)
+        _put(C, slice(k * d, (k + 1) * d), _csr(AT, w) @ Bn[:, k * d:(k + 1) * d], accumulate)
+    return True
+
+
+def _spmm_heads_forward2(self, A, rowstat, s2, slope, mode, B, C, C2, heads, d, accumulate=False):
+    """out = A_alpha . B with alpha from the statistics of the entry's ROW and s2 of its column; C2 = [V | C | 0]."""
+    if not _fused_ok(heads, d):
+        return False
+    F, Bn = heads * d, B.detach().numpy().astype(np.float64)
+    for k in range(heads):
+        st = rowstat.numpy()[A.seg, k]
+        w, raw = _recomputed(st, s2.numpy()[A.col, k], slope, mode)
+        c = w * np.where(raw > 0, 1.0, slope).astype(np.float32) if mode == 0 else w + st[:, 3] * st[:, 2]
+        _put(C, slice(k * d, (k + 1) * d), _csr(A, w) @ Bn[:, k * d:(k + 1) * d], accumulate)
+        _put(C2, slice(k * d, (k + 1) * d), _csr(A, c) @ Bn[:, k * d:(k + 1) * d], accumulate)
+        _put(C2, slice(F + k, F + k + 1), np.asarray(_csr(A, c).sum(1)), accumulate)
+    pw2 = F + (heads + 3) // 4 * 4
+    if not accumulate:
+        C2[:A.nrows, F + heads:pw2] = 0
+    return True
+
+
+def _spmm_heads_grad(self, AT, rowstat, s2, slope, mode, B, Z, t, C, de, heads, d, accumulate=False):
+    """On the TRANSPOSED structure (row j, col i): dZ_j = sum_i alpha_ij dOut_i, de_ij from <dOut_i, Z_j>, ds2_j beside it."""
+    if not _fused_ok(heads, d):
+        return False
+    F = heads * d
+    Bn, Zn = B.detach().numpy().astype(np.float64), Z.detach().numpy().astype(np.float64)
+    for k in range(heads):
+        st = rowstat.numpy()[AT.col, k]
+        w, raw = _recomputed(st, s2.numpy()[AT.seg, k], slope, mode)
+        c = w * np.where(raw > 0, 1.0, slope).astype(np.float32) if mode == 0 else w + st[:, 3] * st[:, 2]
+        dp = (Bn[AT.col, k * d:(k + 1) * d] * Zn[AT.seg, k * d:(k + 1) * d]).sum(1)
+        g = c * (dp - t.numpy()[AT.col, k])
+        _put(C, slice(k * d, (k + 1) * d), _csr(AT, w) @ Bn[:, k * d:(k + 1) * d], accumulate)
+        _put(C, slice(F + k, F + k + 1), np.asarray(_csr(AT, g).sum(1)), accumulate)
+        if de is not None:
+            de[:AT.col.shape[0], k] = torch.from_numpy(g.astype(np.float32))
+    if not accumulate:
+        C[:AT.nrows, F + heads:F + (heads + 3) // 4 * 4] = 0
+    return True
+
+
+OracleKernels.spmm_heads = _spmm_heads
+OracleKernels.spmm_heads_recompute = _spmm_heads_recompute
+OracleKernels.spmm_heads_forward2 = _spmm_heads_forward2
+OracleKernels.spmm_heads_grad = _spmm_heads_grad
 OracleKernels.gat_edge_grad_sliced = _gat_edge_grad_sliced
 OracleKernels.prepare_gat = _prepare_gat
 OracleKernels.with_values = _with_values

@@ -71,6 +71,11 @@ CASES = [
     ("gemat11p.A.mtx", "gemat11.mtx.3.hp", 3, "standard", 2, 8, 2),
     ("gemat11p.A.mtx", "gemat11.mtx.2.rp", 2, "reference", 1, 8, 2),
     ("gemat11.mtx", "gemat11.mtx.3.rp", 3, "reference", 1, 5, 1),     # negative entries: A > 0 masks them (PGAT.py:146)
+    # head widths the two-pass route covers (d = 32 / 64: forward with the second accumulator, edge gradient inside the
+    # transposed product, ds1 = <dOut, V> - t C -- gat.GatEngine on the stand-ins of tests/oracle_kernels.py)
+    ("karate.A.mtx", "karate.mtx.2.rp", 2, "standard", 2, 64, 2),
+    ("gemat11p.A.mtx", "gemat11.mtx.3.hp", 3, "standard", 1, 64, 2),
+    ("gemat11p.A.mtx", "gemat11.mtx.2.rp", 2, "reference", 1, 32, 2),
 ]
 
 
@@ -88,6 +93,8 @@ def test_layers_forward_backward_any_partition(mtx, pv, P, mode, heads, f, L):
             got_out[i][r["own"]] = r["outs"][i]
         got_dH[r["own"]] = r["dH"]
         assert r["ok_halo"]
+        d = f // heads                                        # the two-pass route runs exactly where it is covered
+        assert r["fused"] == [d in (32, 64, 128, 256) and f <= 256] * L
     for i in range(L):
         assert rel_err(got_out[i], outs[i]) < 2e-5
     assert abs(sum(r["loss"] for r in res) - loss) < 1e-5 * abs(loss)       # SUM over ranks == one-process loss

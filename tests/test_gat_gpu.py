@@ -216,6 +216,7 @@ def test_layers_multi_rank_real_kernels(dev, mtx, pv, P, mode, heads, f, L):
     got_dH = np.zeros((n, f), np.float32)
     for r in res:
         assert r["provider"] == "HipKernels" and r["ok_halo"]
+        assert r["fused"] == [f // heads in (32, 64, 128, 256) and f <= 256] * L      # the two-pass route where covered
         for i in range(L):
             got_out[i][r["own"]] = r["outs"][i]
         got_dH[r["own"]] = r["dH"]
