@@ -497,8 +497,11 @@ def bench_gat(args, rank, world, dev, backend, stage):
             label = ("%s_kernel (XCD-sliced SDDMM <dOut_i, Z_j> + softmax / LeakyReLU backward, one pass over the "
                      "stored entries)" % kname)
         ach = alg / (avg * 1e-3)
+        traffic, traffic_note = (pmc_traffic_for(args, world, F, "gat_grad") if kname == "spmm_heads_grad" and not emul
+                                 else (None, "no PMC record"))
         roofline = {"bound": "hbm", "kernel": label,
-                    "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
+                    "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
+                    "traffic_note": traffic_note,
                     "alg_bytes_per_launch": alg, "avg_launch_ms": avg, "launches_timed": launches,
                     "gather_model_GBs": 4.0 * F * eng.nnz / (avg * 1e-3) / 1e9}
     out = {"metric": "edges aggregated/sec (%s-shaped %d-layer GAT, %d heads x %d, full training epoch)" % (

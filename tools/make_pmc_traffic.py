@@ -3,7 +3,7 @@
 bytes of one SpMM launch group.  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled on gfx950
 (MI355X_MICROARCH.md: the counter tallies 128-byte fabric reads at 64 B).  The file holds {"records": [...]}, one per
 (workload, generator, partvec, ranks, f); a record with the same key is replaced.
-usage: make_pmc_traffic.py SUMMARY.txt OUT.json SOURCE-NAME [workload generator ranks f partvec block]"""
+usage: make_pmc_traffic.py SUMMARY.txt OUT.json SOURCE-NAME [workload generator ranks f partvec block [kernel-substring]]"""
 import importlib.util
 import json
 import os
@@ -23,9 +23,13 @@ def source_stamp():
 def main():
     txt = open(sys.argv[1]).read().splitlines()
     per, cur = {}, None
+    only = sys.argv[10] if len(sys.argv) > 10 else None     # keep ONE kernel: a substring of its name incl. template arguments
     for ln in txt:
         m = re.search(r"counter_collection\.csv \| .*::(\w+)<", ln)
         if m:
+            if only is not None and only not in ln:
+                cur = None
+                continue
             cur = per.setdefault(m.group(1), {})
             continue
         m = re.match(r"\s+(\w+)\s+n=(\d+)\s+mean=([\d.e+]+)", ln)
@@ -34,7 +38,7 @@ def main():
         if "kernel_trace.csv" in ln:
             cur = None
             m = re.search(r"::(\w+)<.*mean=([\d.]+) us", ln)
-            if m:
+            if m and (only is None or only in ln):
                 per.setdefault(m.group(1), {}).setdefault("mean_us", float(m.group(2)))
     read = sum(2 * 1024 * v.get("FETCH_SIZE", 0) for v in per.values())
     write = sum(1024 * v.get("WRITE_SIZE", 0) for v in per.values())
@@ -42,7 +46,8 @@ def main():
     workload, generator, ranks, f, partvec, block = (extra + ["reddit", "rmat", "1", "128", "random", "loc"][len(extra):])[:6]
     out = {"workload": workload, "ranks": ranks, "f": int(f), "generator": generator, "partvec": partvec, "block": block,
            "source_stamp": source_stamp(),
-           "kernel": ("A_loc.H" if block == "loc" else "A_halo[%s].slab" % block[4:]) + " launch group: " + " + ".join(sorted(per)),
+           "kernel": (only if only is not None else ("A_loc.H" if block == "loc" else "A_halo[%s].slab" % block[4:])
+                      + " launch group: " + " + ".join(sorted(per))),
            "hbm_bytes_per_launch": int(read + write), "read_bytes": int(read), "write_bytes": int(write),
            "per_kernel": per,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes with --kernel-trace "
