@@ -226,22 +226,6 @@ int pgcn_spmm_dense_f32(const int32_t *work, int64_t nwork, const int32_t *tile_
                         pgcn_stream_t stream);
 
 
-/* The same tiles on the bf16 matrix cores at fp32 accuracy (v_mfma_f32_32x32x16_bf16, 16 x the fp32 MFMA
- * rate): every fp32 operand is the exact sum of three bf16 numbers x1 = bf16(x), x2 = bf16(x - x1),
- * x3 = x - x1 - x2 (round to nearest even), and a.h is accumulated in fp32 from the six partial products
- * a1 h1, a1 h2, a2 h1, a1 h3, a2 h2, a3 h1 (each exact; what is dropped is < 2^-23 |a h|).  A is split on
- * the host, B inside the kernel.  planes (96 KB per tile, 16-byte aligned), 16 bytes per lane:
- *   planes[tile][w][ks][p][lane] = bf16 plane p of A[32 w + (lane & 31)][16 ks + 8 (lane >> 5) + j], j = 0..7
- *   (w = 0..3 row block, ks = 0..7 k step, p = 0..2 plane, lane = 0..63; j ascending from the low bits).
- * work / tile_panel / partial_ws / structural zeros exactly as pgcn_spmm_dense_f32; any f, any
- * alignment of B (the panel is read with 4-byte loads).  Deterministic; NOT bit-identical to the fp32
- * kernel (same error class: |error| <= ~2^-21 sum |a||h| worst case).  Opt-in (tuning.dense_bf16x3).   */
-int pgcn_spmm_dense_bf16x3_f32(const int32_t *work, int64_t nwork, const int32_t *tile_panel,
-                               const void *planes, const float *B, int64_t ldb, int64_t ncols, int32_t f,
-                               float *partial_ws, int64_t partial_ws_elems, int64_t nslots_total,
-                               pgcn_stream_t stream);
-
-
 /* C[row] (+)= sum of the partial-sum slots listed for the row, in list order.
  * fix: 4 x int32 per row {row, begin, count, 0}; slot_ids (optional): the row's slots are
  * slot_ids[begin .. begin+count), or begin .. begin+count when slot_ids is NULL.        */

@@ -76,10 +76,9 @@ class DeviceCSR:
 class DeviceDense:
     work: torch.Tensor
     tile_panel: torch.Tensor
-    vals: Optional[torch.Tensor]      # fp32 tile images (fp32 matrix cores) ...
+    vals: torch.Tensor
     npieces: int
     nnz: int
-    planes: Optional[torch.Tensor] = None   # ... or their three bf16 planes (tuning.dense_bf16x3; then vals is None)
 
 
 @dataclass
@@ -233,8 +232,7 @@ class HipKernels:
             work = hd.work.clone()
             work[:, 3] += ns_rem + ns_strip + ns_core              # ... and the MFMA pieces behind those
             d.dense = DeviceDense(work.to(dev).contiguous(), hd.tile_panel.to(dev).contiguous(),
-                                  hd.vals.to(dev).contiguous() if hd.planes is None else None, hd.npieces, hd.nnz,
-                                  None if hd.planes is None else hd.planes.to(dev).contiguous())
+                                  hd.vals.to(dev).contiguous(), hd.npieces, hd.nnz)
             w64 = work.cpu().to(torch.int64)
             pieces.append(torch.stack([w64[:, 0] * CORE_TR, torch.full_like(w64[:, 0], CORE_TR), w64[:, 3]], 1))
         wk = torch.cat(pieces)
@@ -348,10 +346,7 @@ class HipKernels:
         else:
             cw = cn = ctp = ctb = cso = ccol = cval = None
         if de is not None:
-            dw, dn, dtp = de.work.data_ptr(), de.npieces, de.tile_panel.data_ptr()
-            dvals = de.vals.data_ptr() if de.planes is None else de.planes.data_ptr()
-            dense_fn, dense_name = ((lib.pgcn_spmm_dense_f32, "pgcn_spmm_dense_f32") if de.planes is None else
-                                    (lib.pgcn_spmm_dense_bf16x3_f32, "pgcn_spmm_dense_bf16x3_f32"))
+            dw, dn, dtp, dvals = de.work.data_ptr(), de.npieces, de.tile_panel.data_ptr(), de.vals.data_ptr()
         ncols, nst = A.ncols, A.nslots_total
         fixp, nfa, slots = A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr()
         gflags, fflags = flags | _lib.SPMM_NO_FIXUP, flags & _lib.SPMM_ACCUMULATE
@@ -364,7 +359,7 @@ class HipKernels:
             if st is not None:
                 check(lib.pgcn_spmm_strip_f32(sw, sn, srec, spairs, b, ldb, ncols, f, ws, ws_n, nst, s), "pgcn_spmm_strip_f32")
             if de is not None:
-                check(dense_fn(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s), dense_name)
+                check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s), "pgcn_spmm_dense_f32")
             if co is not None:
                 check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, s),
                       "pgcn_spmm_core_f32")

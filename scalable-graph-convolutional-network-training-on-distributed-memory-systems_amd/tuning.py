@@ -38,10 +38,6 @@ class Tuning:
     dense: bool = True               # fp32-MFMA tiles
     dense_tau: float = 0.30          # tiles at least this full go to the matrix cores
     dense_piece: int = 0             # tiles per MFMA piece (0 = adaptive)
-    dense_bf16x3: bool = False       # MFMA tiles as three bf16 planes on the bf16 matrix cores (pgcn_spmm_dense_bf16x3_f32:
-                                     # 6 MFMAs at 16x the fp32 MFMA rate, fp32 accuracy, not bit-identical to the fp32 tiles).
-                                     # Prepared in r03 without GPU time left to measure it in the product: opt-in until
-                                     # measured (then dense_tau ~ 0.20 is its threshold on the benchmark graph)
     strip: bool = True               # 512 x 128 strip tiles
     strip_min: int = 512             # stored entries that make a strip tile worth staging
     strip_layer_min: int = 384       # stored entries that make one more layer (record) of a tile worth it

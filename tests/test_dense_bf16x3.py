@@ -1,12 +1,24 @@
-"""Host side of the bf16 three-plane MFMA tiles (pgcn_spmm_dense_bf16x3_f32, tuning.dense_bf16x3): the exact
-three-way split, the A-operand plane layout, and the arithmetic of the six-product scheme emulated in numpy
-(every partial product exact in fp32, fp32 accumulation) against float64.  The kernel itself has a GPU test in
-tests/test_hip_gpu.py (opt-in path)."""
+"""Host side of the bf16 three-plane MFMA tiles (tools/experiments/dense3, prepared and harness-measured in r03,
+not in the library yet): the exact three-way split, the A-operand plane layout built from the product's own MFMA
+tile image, the arithmetic of the six-product scheme emulated in numpy (every partial product exact in fp32, fp32
+accumulation) against float64, and that integrate.patch -- the wiring into partition.py / kernels.py / the C ABI --
+still applies to the tree.  The kernel itself ran on the MI355X through tools/experiments/dense3/dense3_bench.cpp
+(profiles/r03_dense3_bench.txt), whose C++ layout builder follows the same formula as the test below."""
+import importlib.util
+import os
+import subprocess
+
 import numpy as np
 import scipy.sparse as sp
 import torch
 
 from conftest import pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXP = os.path.join(ROOT, "tools", "experiments", "dense3")
+_spec = importlib.util.spec_from_file_location("dense3_planes", os.path.join(EXP, "planes.py"))
+planes_mod = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(planes_mod)
 
 
 def _is_bf16(x: np.ndarray) -> bool:
@@ -14,7 +26,7 @@ def _is_bf16(x: np.ndarray) -> bool:
 
 
 def test_split_is_exact_and_every_term_is_bf16():
-    partition = pkg("partition")
+    partition = planes_mod
     rng = np.random.default_rng(0)
     x = np.concatenate([
         rng.standard_normal(20000).astype(np.float32),
@@ -50,17 +62,13 @@ def test_planes_are_the_a_operand_order_of_the_bf16_mfma():
     rng = np.random.default_rng(3)
     n, m = 300, 384
     D = ((rng.random((n, m)) < 0.5) * rng.standard_normal((n, m))).astype(np.float32)
-    old = partition.DENSE_BF16X3
-    partition.DENSE_BF16X3 = True
-    try:
-        h = partition.csr_from_scipy(sp.coo_matrix(D), nslices=1, core=True, tau=0.05, dense_tau=0.2, strip=False)
-    finally:
-        partition.DENSE_BF16X3 = old
+    h = partition.csr_from_scipy(sp.coo_matrix(D), nslices=1, core=True, tau=0.05, dense_tau=0.2, strip=False)
     hd = h.dense
-    assert hd is not None and hd.planes is not None
+    assert hd is not None
     nt = hd.tile_row.numel()
-    assert tuple(hd.planes.shape) == (nt, 4, 8, 3, 64, 8) and hd.planes.dtype == torch.int16
-    pl = hd.planes.numpy().view(np.uint16).astype(np.uint32) << 16
+    planes = planes_mod.dense_planes(hd.vals)                                    # from the product's own fp32 tile image
+    assert tuple(planes.shape) == (nt, 4, 8, 3, 64, 8) and planes.dtype == torch.int16
+    pl = planes.numpy().view(np.uint16).astype(np.uint32) << 16
     pl = pl.view(np.float32)                                                     # the planes as fp32 numbers
     Dp = np.zeros((384, 384), np.float32); Dp[:n, :m] = D
     i, k = np.meshgrid(np.arange(128), np.arange(128), indexing="ij")
@@ -70,20 +78,27 @@ def test_planes_are_the_a_operand_order_of_the_bf16_mfma():
         tile = Dp[tr * 128:(tr + 1) * 128, tp * 128:(tp + 1) * 128]
         terms = [pl[t][w, ks, p, 32 * hk + il, j] for p in range(3)]
         np.testing.assert_array_equal(terms[0].astype(np.float64) + terms[1] + terms[2], tile.astype(np.float64))
-        x1, x2, x3 = (x.numpy() for x in partition.bf16_split3(torch.from_numpy(tile.copy())))
+        x1, x2, x3 = (x.numpy() for x in planes_mod.bf16_split3(torch.from_numpy(tile.copy())))
         np.testing.assert_array_equal(terms[0], x1)
         np.testing.assert_array_equal(terms[1], x2)
         np.testing.assert_array_equal(terms[2], x3)
-    # off (the default): no planes, same fp32 image
-    h0 = partition.csr_from_scipy(sp.coo_matrix(D), nslices=1, core=True, tau=0.05, dense_tau=0.2, strip=False)
-    assert h0.dense.planes is None and torch.equal(h0.dense.vals, hd.vals)
+
+
+def test_integration_patch_applies():
+    """integrate.patch = the edits that put the kernel into the library behind tuning.dense_bf16x3 (header entry,
+    build.sh, ctypes signature, HostDense.planes, the dispatch in kernels.py): it must keep applying to the tree."""
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        import pytest
+        pytest.skip("not a git checkout (a gpurun snapshot)")
+    out = subprocess.run(["git", "apply", "--check", os.path.join(EXP, "integrate.patch")], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
 
 
 def test_six_products_reach_fp32_accuracy():
     """The kernel's arithmetic, emulated: a.h from the six partial products a1h1, a1h2, a2h1, a1h3, a2h2, a3h1
     (each exact in fp32), summed in fp32 over k -- against float64.  Error within 2^-21 sum |a||h| per output
     (the documented worst case), and in practice of the size of an fp32 dot product's own rounding."""
-    partition = pkg("partition")
+    partition = planes_mod
     rng = np.random.default_rng(5)
     K, N = 128, 64
     A = (rng.random((128, K)) < 0.3) * rng.random((128, K)).astype(np.float32) * 0.1

@@ -1,4 +1,8 @@
 // pgcn_spmm_dense3.hip -- dense 128 x 128 tiles of A on the bf16 matrix cores at fp32 accuracy.
+// EXPERIMENT (r03, tools/experiments/dense3): measured on the stand-alone harness only -- 7.75 us per tile and CU
+// against 10.98 for the fp32-MFMA kernel of the library, same error class, all edge cases green
+// (profiles/r03_dense3_bench.txt); not in libpgcn_hip.so until it is measured inside the launch group
+// (integrate.patch wires it in behind tuning.dense_bf16x3).
 //
 // The fp32 MFMA (pgcn_spmm_dense.hip) runs at the fp32 VECTOR rate: v_mfma_f32_32x32x2_f32 is 64
 // flop/clk/SIMD, 1/16 of v_mfma_f32_32x32x16_bf16.  Here every fp32 operand is written as the exact sum of
@@ -29,7 +33,11 @@
 #include <math.h>
 #include <stdint.h>
 
+#if __has_include("pgcn_internal.h")       // (copied into csrc/ by the integration)
 #include "pgcn_internal.h"
+#else
+#include "../../../scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd/csrc/pgcn_internal.h"
+#endif
 
 namespace {
 
@@ -40,6 +48,13 @@ constexpr int kRS = 2 * kQ + 16;         // bytes per feature row of a plane (64
 constexpr int kPL = kT * kRS;            // bytes per plane of a quarter
 constexpr int kBuf = 3 * kPL;            // bytes per quarter buffer
 constexpr size_t kSmem3 = 2 * (size_t)kBuf;
+// tools/micro/dense3_bench.cpp compiles this file a second and third time with PGCN_DENSE3_PROBE = 1 (the panel is
+// staged once per piece: no loads / splits / LDS writes in the loop) and 2 (no A loads either): timing only, wrong
+// sums -- where the time of a tile goes.  The library is built with 0: the branches below fold away.
+#ifndef PGCN_DENSE3_PROBE
+#define PGCN_DENSE3_PROBE 0
+#endif
+constexpr int kProbe = PGCN_DENSE3_PROBE;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -58,7 +73,19 @@ __device__ __forceinline__ f32x16 mma(const u32x4 &a, const u32x4 &b, const f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// One pass over the tiles of a piece on the matrix cores.
+// x, y -> the three bf16 planes of both, packed {x in bits 0-15, y in bits 16-31}
+__device__ __forceinline__ void split_pair(float x, float y, uint32_t &u1, uint32_t &u2, uint32_t &u3) {
+    u1 = pack_bf16(x, y);
+    const float rx = x - lo_as_f32(u1), ry = y - hi_as_f32(u1);          // exact
+    u2 = pack_bf16(rx, ry);
+    u3 = pack_bf16(rx - lo_as_f32(u2), ry - hi_as_f32(u2));              // exact, and a bf16 number
+}
+
+// One pass over the tiles of a piece on the matrix cores.  The loop runs over QUARTER panels (32 k rows), two per
+// trip so that registers alternate without copies:
+//   step q:  request the panel rows of quarter q + 2 (consumed at the end of step q + 1: two steps of cover) and the
+//            A operands of quarter q + 1 | barrier | MFMAs of quarter q from LDS buffer q & 1 | split the rows of
+//            quarter q + 1 and write them to buffer (q + 1) & 1.
 template <int NBLK>
 __device__ __forceinline__ void dense3_piece(const int4 wk, const int32_t *__restrict__ tile_panel,
                                              const u32x4 *__restrict__ planes, const float *__restrict__ B, int64_t ldb,
@@ -66,40 +93,58 @@ __device__ __forceinline__ void dense3_piece(const int4 wk, const int32_t *__res
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, lo = lane & 31;
-    // staging role: feature column sn, k rows [8 sg, 8 sg + 16) of every quarter
+    // staging role: feature column sn, k rows [8 sg, 8 sg + 16) of every quarter (sg is the same for a whole wave)
     const int sn = threadIdx.x & (kT - 1);
-    const int sg = (threadIdx.x >> 7) * 2;
+    const int sg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) * 2;
     const bool sn_ok = sn < fw;
-    const float *Bcol = B + fcol0 + (sn_ok ? sn : 0);
-    float st[16];
-    u32x4 a_cur[2][3], a_nxt[2][3];
+    const uint32_t coff = (uint32_t)(fcol0 + (sn_ok ? sn : 0));
+    float st0[16], st1[16];
+    u32x4 aA[2][3], aB[2][3];            // bf16 planes [k step][plane]
 
-    auto load_q = [&](int64_t ti, int q) {
-        const int64_t r0 = (int64_t)tile_panel[ti] * kT + q * kQ + 8 * sg;
+    auto row0 = [&](int qi) -> int64_t {              // first operand row of this wave's share of quarter qi (wave-uniform)
+        return (int64_t)tile_panel[(int64_t)wk.y + (qi >> 2)] * kT + (qi & 3) * kQ + 8 * sg;
+    };
+    auto load_q = [&](int qi, float (&st)[16]) {      // unconditional loads from clamped rows: masked when stored
+        const int64_t r0 = row0(qi);
+        if (r0 + 16 <= ncols) {                       // (wave-uniform branch) all rows exist: one scalar add per row
+            const float *rowp = B + r0 * ldb;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t r = r0 + i;
-            st[i] = (sn_ok && r < ncols) ? Bcol[r * ldb] : 0.f;
+            for (int i = 0; i < 16; ++i) {
+                st[i] = rowp[coff];
+                rowp += ldb;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int64_t r = r0 + i;
+                r = r < ncols ? r : ncols - 1;
+                st[i] = (B + r * ldb)[coff];
+            }
         }
     };
-    auto load_a = [&](int64_t ti, int q, u32x4 (&a)[2][3]) {
-        const u32x4 *ap = planes + ((ti * 4 + w) * 8 + 2 * q) * 3 * 64 + lane;
+    auto load_a = [&](int qi, u32x4 (&a)[2][3]) {
+        const int64_t ti = (int64_t)wk.y + (qi >> 2);
+        const u32x4 *ap = planes + ((ti * 4 + w) * 8 + 2 * (qi & 3)) * 3 * 64 + lane;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int p = 0; p < 3; ++p) a[s][p] = ap[(s * 3 + p) * 64];
     };
-    auto store_q = [&](int buf) {
+    auto store_q = [&](int qi, const float (&st)[16], int buf) {
+        const int64_t left = ncols - row0(qi);                       // rows of this share that exist (wave-uniform)
+        const bool full = left >= 16 && fw == kT;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             u32x4 p1, p2, p3;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const float x = st[8 * g + 2 * d], y = st[8 * g + 2 * d + 1];
-                const uint32_t u1 = pack_bf16(x, y);
-                const float rx = x - lo_as_f32(u1), ry = y - hi_as_f32(u1);       // exact
-                const uint32_t u2 = pack_bf16(rx, ry);
-                const uint32_t u3 = pack_bf16(rx - lo_as_f32(u2), ry - hi_as_f32(u2));   // exact, and a bf16 number
+                float x = st[8 * g + 2 * d], y = st[8 * g + 2 * d + 1];
+                if (!full) {
+                    x = (sn_ok && 8 * g + 2 * d < left) ? x : 0.f;
+                    y = (sn_ok && 8 * g + 2 * d + 1 < left) ? y : 0.f;
+                }
+                uint32_t u1, u2, u3;
+                split_pair(x, y, u1, u2, u3);
                 p1[d] = u1; p2[d] = u2; p3[d] = u3;
             }
             char *dst = smem + buf * kBuf + sn * kRS + (sg + g) * 16;
@@ -108,52 +153,60 @@ __device__ __forceinline__ void dense3_piece(const int4 wk, const int32_t *__res
             *reinterpret_cast<u32x4 *>(dst + 2 * kPL) = p3;
         }
     };
+    // MFMAs of one quarter.  The B operands are read HALF A K STEP ahead (two column blocks x three planes = six
+    // ds_read_b128 in flight under twelve MFMAs): the scheduler left to itself keeps one operand in flight and
+    // waits for the LDS before almost every MFMA (r03 harness: 41 % of the matrix rate with nothing else in the loop).
     auto compute_q = [&](int buf, const u32x4 (&a)[2][3]) {
         const char *base = smem + buf * kBuf + lo * kRS + hi * 16;
+        constexpr int NH = (NBLK + 1) / 2;            // half steps per k step: pairs of 32-column blocks
+        u32x4 b[2][2][3];
+        auto rd = [&](int t, u32x4 (&bb)[2][3]) {
+            const int s = t / NH, h = t % NH;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4 b[NBLK][3];
+            for (int e = 0; e < 2; ++e)
+                if (2 * h + e < NBLK) {
 #pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb)
+                    for (int p = 0; p < 3; ++p)
+                        bb[e][p] = *reinterpret_cast<const u32x4 *>(base + (2 * h + e) * 32 * kRS + s * 32 + p * kPL);
+                }
+        };
+        auto mm = [&](int t, const u32x4 (&bb)[2][3]) {
+            const int s = t / NH, h = t % NH;
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    b[nb][p] = *reinterpret_cast<const u32x4 *>(base + nb * 32 * kRS + s * 32 + p * kPL);
-            // smallest terms first; the four column blocks interleaved (independent accumulators back to back)
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mma(a[s][2], b[nb][0], acc[nb]);
+                for (int e = 0; e < 2; ++e)
+                    if (2 * h + e < NBLK) acc[2 * h + e] = mma(a[s][pa[i]], bb[e][pb[i]], acc[2 * h + e]);
+        };
+        rd(0, b[0]);
 #pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mma(a[s][0], b[nb][2], acc[nb]);
-#pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mma(a[s][1], b[nb][1], acc[nb]);
-#pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mma(a[s][1], b[nb][0], acc[nb]);
-#pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mma(a[s][0], b[nb][1], acc[nb]);
-#pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mma(a[s][0], b[nb][0], acc[nb]);
+        for (int t = 0; t < 2 * NH; ++t) {
+            if (t + 1 < 2 * NH) rd(t + 1, b[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0x16);     // VALU / SALU / VMEM may move across, LDS reads and MFMAs may not
+            mm(t, b[t & 1]);
+            __builtin_amdgcn_sched_barrier(0x16);
         }
     };
 
-    const int nq = wk.z * 4;
-    load_q(wk.y, 0);
-    load_a(wk.y, 0, a_cur);
-    store_q(0);
-    for (int it = 0; it < nq; ++it) {
-        const int buf = it & 1;
-        const bool more = it + 1 < nq;
-        if (more) {
-            load_q((int64_t)wk.y + ((it + 1) >> 2), (it + 1) & 3);
-            load_a((int64_t)wk.y + ((it + 1) >> 2), (it + 1) & 3, a_nxt);
-        }
-        __syncthreads();       // buffer `buf` is complete; nobody reads buffer `buf ^ 1` (quarter it - 1) any more
-        compute_q(buf, a_cur);
-        if (more) {
-            store_q(buf ^ 1);
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) a_cur[s][p] = a_nxt[s][p];
-        }
+    const int nq = wk.z * 4;                          // even, >= 4
+    load_q(0, st0);
+    load_a(0, aA);
+    load_q(1, st1);
+    store_q(0, st0, 0);
+    for (int it = 0; it < nq; it += 2) {
+        // quarter it: buffer 0, operands aA
+        if (kProbe < 1 && it + 2 < nq) load_q(it + 2, st0);
+        if (kProbe < 2) load_a(it + 1, aB);
+        __syncthreads();       // buffer 0 is complete; nobody reads buffer 1 (quarter it - 1) any more
+        compute_q(0, aA);
+        if (kProbe < 1) store_q(it + 1, st1, 1);
+        // quarter it + 1: buffer 1, operands aB
+        if (kProbe < 1 && it + 3 < nq) load_q(it + 3, st1);
+        if (kProbe < 2 && it + 2 < nq) load_a(it + 2, aA);
+        __syncthreads();
+        compute_q(kProbe < 1 ? 1 : 0, kProbe < 2 ? aB : aA);
+        if (kProbe < 1 && it + 2 < nq) store_q(it + 2, st0, 0);
     }
 }
 
