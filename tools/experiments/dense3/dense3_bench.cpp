@@ -24,6 +24,10 @@ extern "C" int pgcn_spmm_dense_bf16x3_probe1_f32(const int32_t *, int64_t, const
                                                  int64_t, int32_t, float *, int64_t, int64_t, void *);
 extern "C" int pgcn_spmm_dense_bf16x3_probe2_f32(const int32_t *, int64_t, const int32_t *, const void *, const float *, int64_t,
                                                  int64_t, int32_t, float *, int64_t, int64_t, void *);
+// ... and with PGCN_DENSE3_PROBE = 3: the real kernel with per-wave phase timers
+extern "C" int pgcn_spmm_dense_bf16x3_probe3_f32(const int32_t *, int64_t, const int32_t *, const void *, const float *, int64_t,
+                                                 int64_t, int32_t, float *, int64_t, int64_t, void *);
+extern "C" int pgcn_dense3_set_timers(void *);
 extern "C" const char *pgcn_last_error(void);
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -129,6 +133,7 @@ static int launch(int which, const Case &c, const Dev &d, int64_t npieces) {
     const int64_t ns = npieces * 128;
     if (which == 0) return pgcn_spmm_dense_f32(d.work, npieces, d.panel, d.vals, d.B, c.ldb, c.ncols, c.f, d.ws, ns * c.f, ns, nullptr);
     if (which == 2) return pgcn_spmm_dense_bf16x3_probe1_f32(d.work, npieces, d.panel, d.planes, d.B, c.ldb, c.ncols, c.f, d.ws, ns * c.f, ns, nullptr);
+    if (which == 5) return pgcn_spmm_dense_bf16x3_probe3_f32(d.work, npieces, d.panel, d.planes, d.B, c.ldb, c.ncols, c.f, d.ws, ns * c.f, ns, nullptr);
     if (which == 3) return pgcn_spmm_dense_bf16x3_probe2_f32(d.work, npieces, d.panel, d.planes, d.B, c.ldb, c.ncols, c.f, d.ws, ns * c.f, ns, nullptr);
     return pgcn_spmm_dense_bf16x3_f32(d.work, npieces, d.panel, d.planes, d.B, c.ldb, c.ncols, c.f, d.ws, ns * c.f, ns, nullptr);
 }
@@ -203,6 +208,27 @@ int main(int argc, char **argv) {
                 printf("%s 6 tiles/piece: %8.1f us per launch, %6.2f us per tile and CU (timing only)\n", pn[which - 2], 1e3 * ms / 20,
                        1e3 * ms / 20 * prop.multiProcessorCount / ntiles);
             }
+        }
+        {   // ---- per-wave phase timers of the real kernel (s_memtime ticks, summed over the 24 quarters of a 6-tile piece) ----
+            const std::vector<int32_t> work = make_work(ntiles, 6);
+            const int64_t np = (int64_t)work.size() / 4;
+            CHECK(hipMemcpy(d.work, work.data(), work.size() * 4, hipMemcpyHostToDevice));
+            unsigned long long *tb = nullptr;
+            CHECK(hipMalloc(&tb, (size_t)np * 4 * 6 * 8));
+            CHECK(hipMemset(tb, 0, (size_t)np * 4 * 6 * 8));
+            PCHECK(pgcn_dense3_set_timers(tb));
+            for (int i = 0; i < 3; ++i) PCHECK(launch(5, c, d, np));
+            CHECK(hipDeviceSynchronize());
+            std::vector<unsigned long long> t((size_t)np * 4 * 6);
+            CHECK(hipMemcpy(t.data(), tb, t.size() * 8, hipMemcpyDeviceToHost));
+            double m[6] = {0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < t.size(); ++i) m[i % 6] += (double)t[i];
+            const double nw = (double)np * 4, nqt = 24.0;
+            printf("phase timers (ticks per wave; per quarter = / 24): requests issued %.0f (%.0f), barrier wait %.0f (%.0f), MFMA block %.0f (%.0f), "
+                   "split + LDS writes %.0f (%.0f), prologue %.0f, whole loop + prologue %.0f; 48 MFMAs of a quarter = 1536 pipe cycles\n",
+                   m[0] / nw, m[0] / nw / nqt, m[1] / nw, m[1] / nw / nqt, m[2] / nw, m[2] / nw / nqt, m[3] / nw, m[3] / nw / nqt, m[4] / nw, m[5] / nw);
+            PCHECK(pgcn_dense3_set_timers(nullptr));
+            CHECK(hipFree(tb));
         }
         // ---- an Inf in an operand row that only structural zeros touch: the exact path must keep it out -----------
         {

@@ -55,6 +55,22 @@ constexpr size_t kSmem3 = 2 * (size_t)kBuf;
 #define PGCN_DENSE3_PROBE 0
 #endif
 constexpr int kProbe = PGCN_DENSE3_PROBE;
+// PGCN_DENSE3_PROBE = 3: the real kernel with per-wave phase timers (s_memtime ticks = shader cycles): lane 0 of every
+// wave adds up, over the quarters of its piece, {requests issued, barrier wait, MFMA block, split + LDS writes} and
+// stores them with the prologue and the whole loop to timers[piece][wave][6] (pgcn_dense3_set_timers).
+#if PGCN_DENSE3_PROBE == 3
+__device__ unsigned long long *g_dense3_timers = nullptr;
+#endif
+__device__ __forceinline__ unsigned long long tick() {
+#if PGCN_DENSE3_PROBE == 3
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+#else
+    return 0;
+#endif
+}
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -190,24 +206,45 @@ __device__ __forceinline__ void dense3_piece(const int4 wk, const int32_t *__res
     };
 
     const int nq = wk.z * 4;                          // even, >= 4
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tp = tick();
     load_q(0, st0);
     load_a(0, aA);
     load_q(1, st1);
     store_q(0, st0, 0);
+    unsigned long long t0 = tick();
+    tm[4] = t0 - tp;
     for (int it = 0; it < nq; it += 2) {
         // quarter it: buffer 0, operands aA
-        if (kProbe < 1 && it + 2 < nq) load_q(it + 2, st0);
-        if (kProbe < 2) load_a(it + 1, aB);
+        if (kProbe != 1 && kProbe != 2 && it + 2 < nq) load_q(it + 2, st0);
+        if (kProbe != 2) load_a(it + 1, aB);
+        unsigned long long t1 = tick();
         __syncthreads();       // buffer 0 is complete; nobody reads buffer 1 (quarter it - 1) any more
+        unsigned long long t2 = tick();
         compute_q(0, aA);
-        if (kProbe < 1) store_q(it + 1, st1, 1);
+        unsigned long long t3 = tick();
+        if (kProbe != 1 && kProbe != 2) store_q(it + 1, st1, 1);
+        unsigned long long t4 = tick();
+        tm[0] += t1 - t0; tm[1] += t2 - t1; tm[2] += t3 - t2; tm[3] += t4 - t3;
         // quarter it + 1: buffer 1, operands aB
-        if (kProbe < 1 && it + 3 < nq) load_q(it + 3, st1);
-        if (kProbe < 2 && it + 2 < nq) load_a(it + 2, aA);
+        if (kProbe != 1 && kProbe != 2 && it + 3 < nq) load_q(it + 3, st1);
+        if (kProbe != 2 && it + 2 < nq) load_a(it + 2, aA);
+        t1 = tick();
         __syncthreads();
-        compute_q(kProbe < 1 ? 1 : 0, kProbe < 2 ? aB : aA);
-        if (kProbe < 1 && it + 2 < nq) store_q(it + 2, st0, 0);
+        t2 = tick();
+        compute_q((kProbe == 1 || kProbe == 2) ? 0 : 1, kProbe != 2 ? aB : aA);
+        t3 = tick();
+        if (kProbe != 1 && kProbe != 2 && it + 2 < nq) store_q(it + 2, st0, 0);
+        t0 = tick();
+        tm[0] += t1 - t4; tm[1] += t2 - t1; tm[2] += t3 - t2; tm[3] += t0 - t3;
     }
+#if PGCN_DENSE3_PROBE == 3
+    tm[5] = t0 - tp;
+    if (lane == 0 && g_dense3_timers) {
+        unsigned long long *o = g_dense3_timers + ((size_t)blockIdx.x * 4 + w) * 6;
+        for (int i = 0; i < 6; ++i) o[i] = tm[i];
+    }
+#endif
 }
 
 // Exact redo of a piece: products only where A != 0, k ascending, operands from global memory.
@@ -327,3 +364,11 @@ extern "C" int pgcn_spmm_dense_bf16x3_f32(const int32_t *work, int64_t nwork, co
     PGCN_HIP_CHECK(hipGetLastError());
     return PGCN_OK;
 }
+
+#if PGCN_DENSE3_PROBE == 3
+extern "C" int pgcn_dense3_set_timers(void *buf) {           // buf: npieces x 4 waves x 6 uint64 (device memory), or null
+    unsigned long long *p = static_cast<unsigned long long *>(buf);
+    PGCN_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dense3_timers), &p, sizeof(p)));
+    return PGCN_OK;
+}
+#endif
