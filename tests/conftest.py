@@ -70,3 +70,12 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def free_port() -> int:
+    """A TCP port the kernel just handed out on 127.0.0.1 (fixed port numbers collide under pytest-xdist and with
+    sockets of an earlier test still in TIME_WAIT)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

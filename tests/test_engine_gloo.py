@@ -15,18 +15,17 @@ import torch.multiprocessing as mp
 from scipy.io import mmread
 
 import _workers
-from conftest import SPMM_CASES, TRAIN_CASES, golden, golden_inputs, gpath, pkg, read_partvec, rel_err
+from conftest import SPMM_CASES, TRAIN_CASES, free_port, golden, golden_inputs, gpath, pkg, read_partvec, rel_err
 from oracle import oracle
 
 TOL = 1e-5
-_port = [29800]
 
 
 def _spawn(fn, P, *args, **kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    _port[0] += 1
-    procs = [ctx.Process(target=fn, args=(r, P, _port[0]) + args + (q,), kwargs=kw) for r in range(P)]
+    port = free_port()
+    procs = [ctx.Process(target=fn, args=(r, P, port) + args + (q,), kwargs=kw) for r in range(P)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(P)]

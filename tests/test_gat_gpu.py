@@ -8,7 +8,7 @@ import torch
 from scipy.io import mmread
 
 import _workers
-from conftest import golden, gpath, pkg, rel_err
+from conftest import free_port, golden, gpath, pkg, rel_err
 from oracle import oracle
 from test_engine_gloo import _spawn
 from test_gat_gloo import CASES, _expected, _losses, _pattern
@@ -301,7 +301,7 @@ def test_pgat_cli_spawns_all_ranks(dev):
     _, meta = golden("ref_gat_run_karateA")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SLURM_PROCID", "SLURM_NPROCS")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29877")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     # seeded parameters: the CLI has no seed flag, so only the line format and a sane first loss are checked here;
     # the numbers themselves are pinned by test_run_reference_mode_real_kernels
     out = subprocess.run([sys.executable, os.path.join(root, "PGAT.py"), "-a", gpath(meta["mtx"]), "-p",

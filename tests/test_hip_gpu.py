@@ -16,7 +16,7 @@ import scipy.sparse as sp
 import torch
 from scipy.io import mmread
 
-from conftest import (SPMM_CASES, TRAIN_CASES, golden, golden_inputs, gpath, pkg, read_partvec,
+from conftest import (SPMM_CASES, TRAIN_CASES, free_port, golden, golden_inputs, gpath, pkg, read_partvec,
                       rel_err)
 from oracle import oracle
 
@@ -661,7 +661,8 @@ def test_run_multi_rank_on_one_gpu(dev, mtx, pv, P, L, f):
     seed = 11
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_workers.run_worker_gpu, args=(r, P, 29931 + P, gpath(mtx), gpath(pv), L, f, seed, q))
+    port = free_port()
+    procs = [ctx.Process(target=_workers.run_worker_gpu, args=(r, P, port, gpath(mtx), gpath(pv), L, f, seed, q))
              for r in range(P)]
     for p_ in procs:
         p_.start()
@@ -727,8 +728,9 @@ def test_minibatch_driver_real_kernels(dev, name, P, tmp_path):
             pickle.dump([int(x) for x in np.random.default_rng(0).integers(0, P, n)], f)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
+    port = free_port()
     procs = [ctx.Process(target=_workers.minibatch_worker,
-                         args=(r, P, 29950 + P, gpath(meta["mtx"]), pv, meta["f"], meta["batch_size"], meta["seed"], True, q))
+                         args=(r, P, port, gpath(meta["mtx"]), pv, meta["f"], meta["batch_size"], meta["seed"], True, q))
              for r in range(P)]
     for p_ in procs:
         p_.start()

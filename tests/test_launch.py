@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, gpath
+from conftest import ROOT, free_port, gpath
 
 _STRIP = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "SLURM_PROCID", "SLURM_NPROCS", "MASTER_PORT",
           "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")
@@ -110,7 +110,7 @@ def test_pgcn_main_single_rank_rccl_backend():
     """a10: `python PGCN.py ... -b nccl -s 1` with SLURM_* in the environment, through main() -> spawn ->
     init_process(nccl = RCCL) -> run()."""
     L, f = 3, 16
-    (out,) = _run_pgcn_cli([0], 1, "nccl", "karate.A.mtx", "karate.mtx.1.rp", L, f, 29741)
+    (out,) = _run_pgcn_cli([0], 1, "nccl", "karate.A.mtx", "karate.mtx.1.rp", L, f, free_port())
     stats, tot, losses = _check_stdout(out, 0, 1, L)
     assert stats == [0, 0, 0, 0] and tot == [0, 0]
     assert losses[-1] <= losses[0]
@@ -125,7 +125,7 @@ def test_pgcn_main_three_ranks_share_the_gpu():
     from oracle import oracle
     from conftest import read_partvec
     L, f, P = 2, 16, 3
-    outs = _run_pgcn_cli(range(P), P, "gloo", "gemat11p.A.mtx", "gemat11.mtx.3.hp", L, f, 29743)
+    outs = _run_pgcn_cli(range(P), P, "gloo", "gemat11p.A.mtx", "gemat11.mtx.3.hp", L, f, free_port())
     A = sp.csr_matrix(mmread(gpath("gemat11p.A.mtx"))).astype(np.float32)
     part = read_partvec(gpath("gemat11.mtx.3.hp"))
     rows_total = 0

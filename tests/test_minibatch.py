@@ -10,16 +10,13 @@ import pytest
 import torch.multiprocessing as mp
 
 import _workers
-from conftest import GOLDEN, gpath, rel_err
-
-_port = [29860]
-
+from conftest import GOLDEN, free_port, gpath, rel_err
 
 def _spawn(P, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    _port[0] += 1
-    procs = [ctx.Process(target=_workers.minibatch_worker, args=(r, P, _port[0]) + args + (q,)) for r in range(P)]
+    port = free_port()
+    procs = [ctx.Process(target=_workers.minibatch_worker, args=(r, P, port) + args + (q,)) for r in range(P)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(P)], key=lambda r: r["rank"])
