@@ -25,8 +25,15 @@ Every function cites the reference file:line it follows (paths relative to
 header: the aggregation operator and the PGCN.py training loop are pinned by
 golden vectors generated from the reference's own ``GPU/PGCN.py``
 (``tests/golden/make_golden.py``); the GraphBLAS/MPI training loop of
-``Parallel-GCN/main.c`` is UNPINNED against a reference binary (GraphBLAS is
-absent and unfetchable), and only cross-checked float32-C vs float64-numpy.
+``Parallel-GCN/main.c`` is pinned by the outputs of that very file, compiled
+UNMODIFIED and run in the build container (``make -C oracle ref``:
+SuiteSparse:GraphBLAS and MPI are absent and unfetchable, so the calls main.c
+makes into them resolve to the minimal stand-ins under ``oracle/shim/`` --
+written from the published interfaces, see the header of
+``oracle/shim/GraphBLAS.h`` for what that does and does not prove;
+``tests/golden/make_pargcn_ref.py`` -> ``tests/golden/pargcn_ref_*``,
+``tests/test_reference_grbgcn.py``: the C loop ends on the binary's weights
+bit for bit in all six cases, P = 1, 2, 3, L = 2, 3, 4).
 """
 from __future__ import annotations
 
@@ -192,6 +199,60 @@ def pargcn_train(A: sp.spmatrix, part: Sequence[int], P: int, d: Sequence[int],
     if rc != 0:
         raise ValueError("oracle_pargcn_train rc=%d" % rc)
     return err, Wc, Hl, stats
+
+
+def delivered_rows(conn: Sequence, part: Sequence[int], P: int) -> np.ndarray:
+    """vis[p, j]: rank p ever holds row j of H / G -- its own rows plus the rows its peers' ``conn.q`` files list for
+    target p (main.c:526-551 builds the selectors Hsend[target] from those lists, :250 sends exactly those rows,
+    :293-295 multiplies by nothing else).  ``conn[q]`` = (``{target: ids}``, nrecvs) as pargcn_io.read_connectivity
+    returns it."""
+    part = np.asarray(part)
+    vis = np.zeros((P, part.shape[0]), dtype=bool)
+    for p in range(P):
+        vis[p, part == p] = True
+    for q in range(P):
+        for t, ids in conn[q][0].items():
+            vis[t, np.asarray(ids, dtype=np.int64)] = True
+    return vis
+
+
+def drop_undelivered(A: sp.spmatrix, part: Sequence[int], conn: Sequence, P: int) -> Tuple[sp.csr_matrix, int]:
+    """The matrix the reference's CPU engine effectively multiplies by, and the number of stored entries it ignores.
+
+    GCN-HP writes the send lists from the ROWS of the sender (GCN-HP/main.cpp:147-176: vertex i goes to the owners
+    of the columns of row i), which is what the receivers' rows need only when the pattern is symmetric.  On an
+    unsymmetric pattern (HB/gemat11 in tests/golden/pargcn/) rank p never receives some rows its entries refer to;
+    main.c then simply has no H row for those columns (H holds owned rows only, Hcap the delivered ones), i.e. the
+    entries contribute nothing.  Found when the reference's own main.c was run here (tests/golden/make_pargcn_ref.py):
+    with those entries dropped the restated loop ends on the binary's weights bit for bit, without them it is 1e-2
+    away.  Rows delivered but referred to by no entry change nothing (they only count in the statistics)."""
+    part = np.asarray(part, dtype=np.int64)
+    vis = delivered_rows(conn, part, P)
+    A = sp.coo_matrix(A)
+    keep = vis[part[A.row], A.col]
+    out = sp.csr_matrix((A.data[keep], (A.row[keep], A.col[keep])), shape=A.shape)
+    out.sort_indices()
+    return out, int((~keep).sum())
+
+
+def pargcn_statistics(conn: Sequence, d: Sequence[int], P: int, epochs: int = 3) -> List[int]:
+    """The eight numbers of statistics() (main.c:506-524) from the connectivity lists alone: a message to target t
+    carries ``len(list) * width`` scalars (the selected rows of a dense H or G, nvals of main.c:253,264), once per
+    layer forward (widths d[1..L-1]) and once per layer backward (widths d[L..2]) in each epoch; a receiver counts
+    the same numbers on arrival (:287-288)."""
+    L = len(d) - 1
+    widths = [d[l] for l in range(1, L)] + [d[l + 1] for l in range(L - 1, 0, -1)]
+    send_vol, recv_vol = np.zeros(P, np.int64), np.zeros(P, np.int64)
+    send_msg, recv_msg = np.zeros(P, np.int64), np.zeros(P, np.int64)
+    for q in range(P):
+        for t, ids in conn[q][0].items():
+            rows = len(ids)
+            send_vol[q] += rows * sum(widths) * epochs
+            recv_vol[t] += rows * sum(widths) * epochs
+            send_msg[q] += len(widths) * epochs
+            recv_msg[t] += len(widths) * epochs
+    return [int(send_vol.sum()), int(send_vol.sum() // P), int(send_vol.max()), int(recv_vol.max()),
+            int(send_msg.sum()), int(send_msg.sum() // P), int(send_msg.max()), int(recv_msg.max())]
 
 
 # --------------------------------------------------------------------------

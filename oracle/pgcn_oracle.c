@@ -24,9 +24,20 @@
  * GPU/PGCN.py (PSpMM forward/backward, compute_communication_maps, full P=1
  * training) generated in the build container by tests/golden/make_golden.py;
  * see tests/test_oracle_golden.py.  The sigmoid/BCE/SGD training loop of
- * main.c cannot be executed here (GraphBLAS absent) => for that part parity is
- * UNPINNED against a reference binary; it is cross-checked against an
- * independent float64 numpy restatement only (oracle/oracle.py).
+ * main.c is pinned by main.c ITSELF: the file compiles unmodified, from where
+ * it lies, against minimal stand-ins for the GraphBLAS / MPI calls it makes
+ * (oracle/shim/, `make -C oracle ref` -> oracle/_ref/grbgcn; the stand-ins are
+ * restatements of the published interfaces, not SuiteSparse -- what is pinned
+ * is main.c's own control flow, operator definitions, message contents and
+ * update rule, on top of the textbook meaning of mxm / eWiseAdd / eWiseMult /
+ * apply / reduce).  tests/golden/make_pargcn_ref.py runs it on six data
+ * directories (P = 1, 2, 3; 2, 3 and 4 layers; three of them written by the
+ * reference's own preprocess + GCN-HP tools) and commits what it printed and
+ * the weights it ended with; oracle_pargcn_train ends on the same weights BIT
+ * FOR BIT (tests/test_reference_grbgcn.py).  That run also showed a property
+ * of the reference this file now follows: on an unsymmetric pattern the send
+ * lists GCN-HP writes are not what the receivers' rows need, and main.c
+ * ignores the entries whose rows never arrive (oracle.drop_undelivered).
  *
  * Summation order.  GraphBLAS leaves the order of the PLUS reduction to its
  * kernels and main.c:278 accumulates remote pieces in message-arrival order,

@@ -62,11 +62,45 @@ def train(engine, d: Sequence[int], W: Dict[int, torch.Tensor], H0: torch.Tensor
     return errs, W, H[L - 1]
 
 
-def init_weights(d: Sequence[int], seed: int = 0) -> Dict[int, np.ndarray]:
-    """main.c:578-595: W[l] ~ U(-sd, sd), sd = sqrt(6 / (ni + no)).  The reference seeds rand()
-    with time(NULL) on every rank (unreproducible, replicas may differ); here: a seeded stream."""
-    rng = np.random.default_rng(seed)
+def glibc_rand(seed: int, count: int) -> np.ndarray:
+    """``srand(seed)`` followed by ``count`` calls of ``rand()`` as glibc computes them (the TYPE_3 additive-feedback
+    generator of random_r.c: 31 words from a Lehmer sequence, r[i] = r[i-31] + r[i-3], 310 outputs discarded, top 31
+    bits returned) -- the stream main.c:555,569-571 draws its weights from."""
+    seed = int(seed) & 0xffffffff
+    word = (seed - (1 << 32) if seed >= (1 << 31) else seed) or 1          # the int32 the state starts from; 0 -> 1
+    r = [word]
+    for _ in range(30):
+        sign = -1 if r[-1] < 0 else 1
+        hi, lo = sign * (abs(r[-1]) // 127773), sign * (abs(r[-1]) % 127773)   # C division: towards zero
+        w = 16807 * lo - 2836 * hi
+        r.append(w + 2147483647 if w < 0 else w)
+    r = [v & 0xffffffff for v in r]
+    r += r[0:3]
+    for i in range(34, 344 + count):
+        r.append((r[i - 31] + r[i - 3]) & 0xffffffff)
+    return np.asarray(r[344:], dtype=np.int64) >> 1
+
+
+def init_weights(d: Sequence[int], seed: int = 0, stream: str = "numpy") -> Dict[int, np.ndarray]:
+    """main.c:578-595: W[l] ~ U(-sd, sd), sd = sqrt(6 / (ni + no)).  The reference seeds rand() with time(NULL) on
+    every rank (unreproducible, replicas may differ).  ``stream="numpy"``: a seeded numpy stream;
+    ``stream="glibc"``: the reference's own arithmetic on glibc's ``srand(seed)`` stream -- bit for bit the weights
+    the reference binary draws when its clock reads ``seed`` (get_random, main.c:93-96: float division by RAND_MAX,
+    ``x + (y - x) * r`` in float; layers, rows and columns in the order of main.c:566-573)."""
     L = len(d) - 1
+    if stream == "glibc":
+        sizes = [d[l] * d[l + 1] for l in range(1, L)]
+        draws = glibc_rand(seed, sum(sizes)).astype(np.float32) / np.float32(2147483647)
+        W, at = {}, 0
+        for l in range(1, L):
+            sd = np.float32(np.sqrt(6.0 / float(np.float32(d[l] + d[l + 1]))))
+            r = draws[at:at + sizes[l - 1]].reshape(d[l], d[l + 1])
+            W[l] = (-sd) + (sd - (-sd)) * r
+            at += sizes[l - 1]
+        return W
+    if stream != "numpy":
+        raise ValueError("unknown weight stream %r" % (stream,))
+    rng = np.random.default_rng(seed)
     return {l: ((rng.random((d[l], d[l + 1]), dtype=np.float32) * 2 - 1) *
                 np.float32(np.sqrt(6.0 / (d[l] + d[l + 1])))) for l in range(1, L)}
 
@@ -116,13 +150,25 @@ def main(argv, kernels=None, out=None):
     else:
         dev = torch.device("cpu")
     A = prob["A"]
+    # The reference multiplies by what its conn.* files deliver, not by what the pattern needs (main.c:250,293-295);
+    # GCN-HP derives those lists from the sender's rows (GCN-HP/main.cpp:147-176), so on an unsymmetric pattern some
+    # entries refer to rows that never arrive and contribute nothing.  Same inputs, same numbers: drop them here too.
+    keep = _io.delivered_rows(prob["conn"], prob["part"], prob["k"])[prob["part"][A.row], A.col]
+    if not keep.all():
+        if rank == 0:
+            print("pargcn: %d of %d stored entries refer to rows that the conn.* files of %s never deliver (unsymmetric "
+                  "pattern); the reference engine ignores them and so does this run" % (int((~keep).sum()), A.nnz, path),
+                  file=sys.stderr)
+        A = type(A)((A.data[keep], (A.row[keep], A.col[keep])), shape=A.shape)
     partvec = torch.from_numpy(prob["part"] if world > 1 else np.zeros(n, dtype=np.int64))
     part = _partition.build_partition(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
                                       torch.from_numpy(A.data.astype(np.float32)), n, partvec, rank, world)
     exch = _engine.make_exchanger(rank, world, dev) if world > 1 else None
     eng = _engine.AggregationEngine(part, kernels, dev, exch)
     own = part.owned.numpy()
-    W = {l: torch.from_numpy(w).to(dev) for l, w in init_weights(d, int(os.environ.get("PGCN_SEED", "0"))).items()}
+    seed = os.environ.get("PGCN_SEED", "0")                # "7": numpy stream; "glibc:7": the reference's srand(7) stream
+    stream, seed = ("glibc", seed[6:]) if seed.startswith("glibc:") else ("numpy", seed)
+    W = {l: torch.from_numpy(w).to(dev) for l, w in init_weights(d, int(seed), stream).items()}
     H0 = torch.ones((own.size, d[1]), device=dev)                                  # main.c:650-685
     Y = torch.from_numpy(prob["Y"][own]).to(dev)
     Ym = torch.from_numpy(prob["Ymask"][own]).to(dev)

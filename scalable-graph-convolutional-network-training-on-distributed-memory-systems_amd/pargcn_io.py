@@ -113,6 +113,20 @@ def load_directory(directory: str, config_path: str = None):
     return {"L": L, "d": d, "A": A, "part": part, "Y": Y, "Ymask": Ymask, "conn": conn, "buff": buff, "k": k}
 
 
+def delivered_rows(conn, part, k: int) -> np.ndarray:
+    """vis[p, j]: rank p of the reference engine ever holds row j of H / G -- the rows it owns plus the rows its
+    peers' conn files list for target p (main.c:526-551 builds the row selectors from those lists, :250 sends exactly
+    those rows, :293-295 multiplies by nothing else).  ``conn`` as load_directory returns it."""
+    part = np.asarray(part)
+    vis = np.zeros((k, part.shape[0]), dtype=bool)
+    for p in range(k):
+        vis[p, part == p] = True
+    for q in range(k):
+        for t, ids in conn[q][0].items():
+            vis[t, np.asarray(ids, dtype=np.int64)] = True
+    return vis
+
+
 # --------------------------------------------------------------------------------------------
 # Writers (SURVEY 8f row N2): the same files the reference's tools write, so that directories produced
 # here feed the reference's CPU engine and vice versa.

@@ -75,7 +75,8 @@ def test_cli_single_rank_matches_oracle(gemat_dir):
     prob = io_.load_directory(gemat_dir)
     d = prob["d"]
     n = d[0]
-    A = sp.csr_matrix(prob["A"])
+    A, dropped = oracle.drop_undelivered(prob["A"], prob["part"], prob["conn"], prob["k"])      # unsymmetric pattern
+    assert dropped > 0
     W0 = pargcn.init_weights(d, 5)
     err, Wc, Hl, st = oracle.pargcn_train(A, [0] * n, 1, d, W0, np.ones((n, d[1]), np.float32),
                                           prob["Y"], prob["Ymask"])
