@@ -15,7 +15,8 @@ first `err:` line checks.  tests/test_reference_grbgcn.py holds the oracle (and,
 Cases: the two karate directories and the gemat11 directory that the reference's own preprocess + GCN-HP tools wrote
 (tests/golden/pargcn/, values rounded to two decimals by those tools), plus three directories written by
 pargcn_io.write_directory (byte-identical to the tools' output on the same input, tests/test_formats_order.py) to
-cover one rank, two layers (no hidden gradient, main.c:406), four layers and lossless values."""
+cover one rank, two layers (no hidden gradient, main.c:406), four layers and lossless values, and two on the Cora
+shape of BASELINE.json configs[0] (the reference's own CPU-runnable case)."""
 import json
 import os
 import re
@@ -47,6 +48,11 @@ CASES = {
                                "value_format": "%.9g"}, "P": 1, "seed": 3},
     "gemat11p_k2_l4": {"write": {"mtx": "gemat11p.A.mtx", "partvec": "gemat11.mtx.2.rp", "k": 2, "L": 4, "f": 8,
                                  "value_format": "%.9g"}, "P": 2, "seed": 2024},
+    # BASELINE.json configs[0]: the Cora shape (2 708 vertices, 10 556 directed edges), 2 layers, f = 16, on the reference's
+    # CPU path with one rank -- and over two ranks under a random part vector.  Synthetic stand-in (no data sets here):
+    # synth.make_graph("cora") draws from the portable stream, so the test rebuilds the same directory anywhere.
+    "cora_k1": {"synth": {"workload": "cora", "seed": 0, "k": 1, "L": 2, "f": 16}, "P": 1, "seed": 42},
+    "cora_k2": {"synth": {"workload": "cora", "seed": 0, "k": 2, "L": 2, "f": 16}, "P": 2, "seed": 43},
     "gemat11p_k3_f32": {"write": {"mtx": "gemat11p.A.mtx", "partvec": "gemat11.mtx.3.hp", "k": 3, "L": 3, "f": 32,
                                   "value_format": "%.9g"}, "P": 3, "seed": 99},
 }
@@ -61,6 +67,15 @@ def materialise(case: dict, tmp: str) -> str:
             tf.extractall(tmp)
         (sub,) = [d for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d))]
         return os.path.join(tmp, sub)
+    if "synth" in case:
+        w = case["synth"]
+        synth = pkg("synth")
+        n, row, col, val = synth.make_graph(w["workload"], seed=w["seed"])
+        A = sp.csr_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n, n))
+        pv = synth.random_partvec(n, w["k"], seed=w["seed"]).numpy() if w["k"] > 1 else np.zeros(n, np.int64)
+        out = os.path.join(tmp, "data")
+        pkg("pargcn_io").write_directory(out, A, pv, w["k"], w["L"], w["f"], value_format="%.9g")
+        return out
     w = case["write"]
     A = sp.csr_matrix(mmread(os.path.join(HERE, w["mtx"]))).astype(np.float32)
     out = os.path.join(tmp, "data")

@@ -1,7 +1,7 @@
 """the training loop of the reference's CPU engine, pinned by that engine itself.
 
 tests/golden/pargcn_ref_*.{json,npz} hold what /root/reference/Parallel-GCN/main.c -- compiled UNMODIFIED against the
-GraphBLAS / MPI stand-ins of oracle/shim/ (`make -C oracle ref`) -- printed and the weights it ended with, on six data
+GraphBLAS / MPI stand-ins of oracle/shim/ (`make -C oracle ref`) -- printed and the weights it ended with, on eight data
 directories in the reference's on-disk format (tests/golden/make_pargcn_ref.py).  Here: the oracle's restatement of
 that loop ends on the same weights bit for bit; the product's `pargcn.main` (numpy stand-in kernels over gloo on the
 CPU box, the HIP engine under -m gpu) prints the binary's `err:` lines and ends on its weights within fp32
@@ -28,7 +28,12 @@ sys.path.insert(0, GOLDEN)
 import make_pargcn_ref as ref  # noqa: E402  (case table + directory recipe shared with the generator)
 
 CASE_NAMES = list(ref.CASES)
-SYMMETRIC = ("karate_k2", "karate_k3", "karate_k1_l2")          # HB/gemat11 has an unsymmetric pattern
+# The printed loss is an fp32 RUNNING sum over the n x d[L] entries of T (GrB_reduce on the PLUS_FP32 monoid, main.c:320;
+# the stand-in folds in (i, j) order, the oracle restates that order and matches to the printed digit).  On the Cora
+# shape that running sum is itself 1.8e-5 from the exact sum (2434.70 vs 2434.7435), so anything that adds in another
+# order -- the float64 shadow, torch's pairwise sum in pargcn.py -- is held to 5e-5 on the loss; weights keep 1e-5.
+ERR_RTOL = 5e-5
+SYMMETRIC = ("karate_k2", "karate_k3", "karate_k1_l2", "cora_k1", "cora_k2")          # HB/gemat11 has an unsymmetric pattern
 
 
 def _fixture(name):
@@ -83,7 +88,7 @@ def test_oracle_ends_on_the_reference_weights(name, tmp_path):
     assert oracle.pargcn_statistics(prob["conn"], d, P) == meta["stats"]
     # the float64 shadow arbitrates the arithmetic: same numbers to fp32 round-off
     errd, Wd, _ = oracle.pargcn_train_np(A, d, W0, np.ones((n, d[1]), np.float32), prob["Y"], prob["Ymask"])
-    np.testing.assert_allclose(errd, printed, rtol=6e-6)
+    np.testing.assert_allclose(errd, printed, rtol=ERR_RTOL)
     for l in Wend:
         assert rel_err(Wd[l], Wend[l]) < 2e-6
 
@@ -143,7 +148,7 @@ def test_product_main_over_gloo_prints_the_reference_lines(name, tmp_path):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    _check_product(name, res[0]["stdout"], res[0]["errs"], res[0]["W"], printed, Wend, meta, 1e-5, 1e-5)
+    _check_product(name, res[0]["stdout"], res[0]["errs"], res[0]["W"], printed, Wend, meta, ERR_RTOL, 1e-5)
     for r in res[1:]:
         for l in Wend:
             assert np.array_equal(r["W"][l], res[0]["W"][l])
@@ -182,7 +187,7 @@ def test_hip_engine_on_the_reference_outputs(name, tmp_path, monkeypatch):
     buf = io.StringIO()
     errs, Wn, _, _ = pkg("pargcn").main(["-p", directory, "-c", os.path.join(directory, "config")], out=buf)
     got = [float(x) for x in re.findall(r"^err:(\S+)$", buf.getvalue(), re.M)]
-    np.testing.assert_allclose(got, printed, rtol=3e-5)
-    np.testing.assert_allclose([float(e) for e in errs], printed, rtol=3e-5)
+    np.testing.assert_allclose(got, printed, rtol=ERR_RTOL)
+    np.testing.assert_allclose([float(e) for e in errs], printed, rtol=ERR_RTOL)
     for l in Wend:
         assert rel_err(Wn[l].cpu().numpy(), Wend[l]) < 5e-5
