@@ -29,6 +29,9 @@ class HostPlanner:
     def prepare(self, csr, pattern_only=False):
         return self._k.HipKernels.prepare(self, csr, pattern_only)
 
+    def prepare_gat(self, csr, rows_wave, rows_block):
+        return self._k.HipKernels.prepare_gat(self, csr, rows_wave, rows_block)
+
     def _attach_core(self, d, csr, fix_rem):
         return self._k.HipKernels._attach_core(self, d, csr, fix_rem)
 

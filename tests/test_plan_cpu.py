@@ -201,3 +201,41 @@ def test_partition_blocks_forward_and_backward_through_their_plans(mtx, pv, P):
         for u in pt.unpack:
             dH, _ = run_plan(K.prepare(u, pattern_only=True), back, C0=dH, accumulate=True)
         assert np.abs(dH - ATG[own]).max() < TOL, "backward, rank %d" % q
+
+
+def test_attention_structures_of_a_rank():
+    """What the GAT kernels read besides the SpMM plan (gat.build_gat_graph + HipKernels.prepare_gat): the forward
+    pattern over [local ; halo] columns, its transpose with the entry permutation, the wave / workgroup row lists
+    (every row in exactly one) and the per-row offsets of the eight col % 8 slices."""
+    partition, gat = pkg("partition"), pkg("gat")
+    A = sp.coo_matrix(mmread(gpath("gemat11p.A.mtx"))).astype(np.float32)
+    n = A.shape[0]
+    part = torch.tensor(read_partvec(gpath("gemat11.mtx.3.hp")))
+    pt = partition.build_partition(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
+                                   torch.from_numpy(A.data), n, part, 1, 3)
+    g = gat.build_gat_graph(pt)
+    K = HostPlanner()
+    for h, wave, block in ((g.fwd, g.fwd_wave, g.fwd_block), (g.bwd, g.bwd_wave, g.bwd_block)):
+        d = K.prepare_gat(h, wave, block)
+        listed = np.sort(np.concatenate([d.rows_wave.numpy(), d.rows_block.numpy()]))
+        ln = (h.rowptr[1:] - h.rowptr[:-1]).numpy()
+        assert np.array_equal(listed, np.nonzero(ln > 0)[0]) or np.array_equal(listed, np.arange(h.nrows))
+        if d.slice_off is not None:
+            off, col, rp = d.slice_off.numpy().astype(np.int64), h.col.numpy().astype(np.int64), h.rowptr.numpy()
+            assert np.array_equal(off[:, 8], ln) and (np.diff(off, axis=1) >= 0).all()
+            for r in np.argsort(-ln)[:50]:
+                for s_ in range(8):
+                    assert (col[rp[r] + off[r, s_]:rp[r] + off[r, s_ + 1]] % 8 == s_).all()
+            assert np.array_equal(np.sort(d.rows_all.numpy()), np.arange(h.nrows))
+            assert (np.diff(ln[d.rows_all.numpy().astype(np.int64)]) <= 0).all()              # longest first
+        # the pattern SpMM plan of the structure reproduces the product with all values one
+        B = np.random.default_rng(0).standard_normal((h.ncols, 3))
+        C, _ = run_plan(d, B)
+        ones = sp.csr_matrix((np.ones(h.col.numel()), h.col.numpy(), h.rowptr.numpy()), shape=(h.nrows, h.ncols))
+        assert np.abs(np.nan_to_num(C) - ones @ B).max() < TOL
+    # entry p of the transposed structure is entry perm[p] of the forward one
+    fr, fc, _ = g.fwd.to_coo()
+    br, bc, _ = g.bwd.to_coo()
+    perm = g.perm.numpy()
+    assert np.array_equal(np.sort(perm), np.arange(perm.size))
+    assert np.array_equal(br.numpy(), fc.numpy()[perm]) and np.array_equal(bc.numpy(), fr.numpy()[perm])
