@@ -239,3 +239,31 @@ def test_attention_structures_of_a_rank():
     perm = g.perm.numpy()
     assert np.array_equal(np.sort(perm), np.arange(perm.size))
     assert np.array_equal(br.numpy(), fc.numpy()[perm]) and np.array_equal(bc.numpy(), fr.numpy()[perm])
+
+
+def test_default_tuning_on_a_dense_graph_reaches_every_tile_path():
+    """The Reddit shape at 1/8 of its vertices with its average degree (492 stored entries per row) under the SHIPPED
+    tuning, through build_partition as bench.py calls it: one rank gets strip tiles + MFMA tiles (and the same for the
+    pre-built transpose), a rank of four gets a gather-only local block and a halo block with LDS-core + MFMA tiles.
+    Forward through the plans = (A . H)[owned rows], transposed block = A^T . H."""
+    partition, synth = pkg("partition"), pkg("synth")
+    n, row, col, val = synth.make_graph(29120, 14326986, seed=0)
+    A = sp.csr_matrix((val.numpy().astype(np.float64), (row.numpy(), col.numpy())), shape=(n, n))
+    H = np.random.default_rng(0).standard_normal((n, 2))
+    AH, ATH = A @ H, A.T @ H
+    K = HostPlanner()
+    pt = partition.build_partition(row, col, val, n, torch.zeros(n, dtype=torch.int64), 0, 1)
+    own = pt.owned.numpy()
+    for blk, ref in ((pt.A_loc, AH), (pt.A_loc_T, ATH)):
+        assert blk.strip is not None and blk.dense is not None and blk.col.numel() > 0 and blk.nnz == A.nnz
+        assert blk.strip.nnz > 0.3 * A.nnz and blk.dense.nnz > 0.2 * A.nnz
+        C, info = run_plan(K.prepare(blk), H[own])
+        assert np.abs(C - ref[own]).max() < TOL
+    pt = partition.build_partition(row, col, val, n, synth.random_partvec(n, 4, seed=0), 1, 4)
+    own, hg = pt.owned.numpy(), pt.halo_global.numpy()
+    assert pt.A_loc.strip is None and pt.A_loc.core is None and pt.A_loc.dense is None          # a small block: gather only
+    assert any(a.core is not None or a.dense is not None or a.strip is not None for a in pt.A_halo)
+    C, _ = run_plan(K.prepare(pt.A_loc), H[own])
+    for a in pt.A_halo:
+        C, _ = run_plan(K.prepare(a), H[hg], C0=C, accumulate=True)
+    assert np.abs(C - AH[own]).max() < TOL
