@@ -28,13 +28,15 @@ struct shared {
     size_t arena_used;
     struct msg msgs[MAX_MSGS];
 };
-struct req { int active, src, tag; void *buf; size_t cap; };
+struct req { int active, src, tag; void *buf; size_t cap; unsigned long seq; };
 
 static struct shared *sh = NULL;
 static char *arena = NULL, *coll = NULL;
 static int np = 1, me = 0;
 static pid_t kids[MAX_RANKS];
 static struct req reqs[MAX_REQS];
+static unsigned long post_seq = 0;           /* order in which this rank posted its receives */
+static int req_hi = 0;                       /* one past the highest request slot ever used */
 #define SEND_DONE (MAX_REQS + 1)               /* sends complete inside MPI_Isend (the payload is copied) */
 
 static void die(const char *what) { fprintf(stderr, "mpi_shim[%d]: %s\n", me, what); _exit(97); }
@@ -150,6 +152,8 @@ int MPI_Irecv(void *buf, int count, MPI_Datatype type, int source, int tag, MPI_
         if (!reqs[i].active) {
             reqs[i].active = 1; reqs[i].src = source; reqs[i].tag = tag; reqs[i].buf = buf;
             reqs[i].cap = (size_t) count * type_size(type);
+            reqs[i].seq = ++post_seq;
+            if (i + 1 > req_hi) req_hi = i + 1;
             *request = i + 1;
             return MPI_SUCCESS;
         }
@@ -157,10 +161,14 @@ int MPI_Irecv(void *buf, int count, MPI_Datatype type, int source, int tag, MPI_
     return 1;
 }
 
-/* the earliest message for (source, tag) that nobody took: non-overtaking order */
+/* The earliest message for (source, tag) that nobody took goes to the EARLIEST-POSTED receive for that (source, tag):
+ * a receive posted later must not overtake one posted before it (MPI's matching rule; without the check a message that
+ * lands between two polls of MPI_Waitany could be taken by the later request). */
 static int try_complete(MPI_Request *request, MPI_Status *status) {
     struct req *r = &reqs[*request - 1];
     int hit = 0;
+    for (int i = 0; i < req_hi; ++i)
+        if (reqs[i].active && reqs[i].src == r->src && reqs[i].tag == r->tag && reqs[i].seq < r->seq) return 0;
     pthread_mutex_lock(&sh->mtx);
     for (int k = 0; k < sh->nmsg; ++k) {
         struct msg *m = &sh->msgs[k];
