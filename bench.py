@@ -186,7 +186,7 @@ def cpu_baseline(part, f, budget_s=20.0):
     try:
         ep = cpu_baseline_epoch(rp, ci, va, n, f, budget_s)
         out["epoch"] = ep
-        out["kind"] = "port (SpMM) + port-epoch"
+        out["kind"] = "port"                 # both legs run oracle/pgcn_oracle.c (the restatement), none the reference's binary
         out["sample"] += "; plus %d epoch(s) of the restated Parallel-GCN training loop, %.0f ms/epoch = %.3g edges/s" % (
             ep["epochs"], ep["ms_per_epoch"], ep["edges_per_s"])
     except Exception as e:          # the SpMM figure stands on its own
