@@ -5,7 +5,7 @@
  * Ranks are PROCESSES: MPI_Init forks MPISHIM_NP - 1 children (default 1 rank) that share one anonymous mapping
  * holding the mailboxes and the scratch of the collectives; rank 0 is the process that was started and waits for
  * the others in MPI_Finalize.  Semantics kept: non-overtaking point-to-point messages per (source, tag),
- * MPI_Waitany over receive requests, MPI_Pack / MPI_Unpack as plain byte copies (8 B per MPI_UNSIGNED_LONG,
+ * MPI_Waitany over receive requests (completions handed out in request order: deterministic sums, see mpi_shim.c), MPI_Pack / MPI_Unpack as plain byte copies (8 B per MPI_UNSIGNED_LONG,
  * 4 B per MPI_FLOAT: the reference's 20 B per scalar on the wire), reductions in rank order 0, 1, ..., P-1.
  * Also here: time() returns MPISHIM_SEED when that is set, which makes main.c:555 `srand(time(NULL))` -- and with
  * it the weights every rank draws -- reproducible. */

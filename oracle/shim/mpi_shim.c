@@ -194,18 +194,21 @@ int MPI_Wait(MPI_Request *request, MPI_Status *status) {
     return MPI_SUCCESS;
 }
 
+/* Completes the FIRST pending request of the array (waits for it): a legal MPI_Waitany schedule, and a DETERMINISTIC one.
+ * main.c:275-299 adds the product of every received piece in the order MPI_Waitany hands the messages over, so with two
+ * or more sources the reference's fp32 sums depend on arrival order (seen here: a 4-rank run did not repeat its own
+ * weights bit for bit when completions were taken as they came).  With this schedule the pieces are added by ascending
+ * source rank -- the order main.c posts its receives in (:239-243), and the one oracle/pgcn_oracle.c restates. */
 int MPI_Waitany(int count, MPI_Request requests[], int *index, MPI_Status *status) {
-    for (;;) {
-        int pending = 0;
-        for (int i = 0; i < count; ++i) {
-            if (requests[i] == MPI_REQUEST_NULL) continue;
-            if (requests[i] == SEND_DONE) { requests[i] = MPI_REQUEST_NULL; *index = i; return MPI_SUCCESS; }
-            pending = 1;
-            if (try_complete(&requests[i], status)) { *index = i; return MPI_SUCCESS; }
-        }
-        if (!pending) { *index = -1; return MPI_SUCCESS; }     /* MPI_UNDEFINED */
-        sched_yield();
+    for (int i = 0; i < count; ++i) {
+        if (requests[i] == MPI_REQUEST_NULL) continue;
+        if (requests[i] == SEND_DONE) requests[i] = MPI_REQUEST_NULL;
+        else while (!try_complete(&requests[i], status)) sched_yield();
+        *index = i;
+        return MPI_SUCCESS;
     }
+    *index = -1;                                   /* MPI_UNDEFINED: nothing pending */
+    return MPI_SUCCESS;
 }
 
 static void fold(void *acc, const void *x, int count, MPI_Datatype type, MPI_Op op) {

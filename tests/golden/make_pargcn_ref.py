@@ -53,6 +53,8 @@ CASES = {
     # synth.make_graph("cora") draws from the portable stream, so the test rebuilds the same directory anywhere.
     "cora_k1": {"synth": {"workload": "cora", "seed": 0, "k": 1, "L": 2, "f": 16}, "P": 1, "seed": 42},
     "cora_k2": {"synth": {"workload": "cora", "seed": 0, "k": 2, "L": 2, "f": 16}, "P": 2, "seed": 43},
+    # four ranks, a power-law graph with hubs (8 192 vertices, 32 stored entries per row on average), width 64
+    "rmat_k4_f64": {"synth": {"workload": 8192, "nnz": 262144, "seed": 3, "k": 4, "L": 3, "f": 64}, "P": 4, "seed": 2025},
     "gemat11p_k3_f32": {"write": {"mtx": "gemat11p.A.mtx", "partvec": "gemat11.mtx.3.hp", "k": 3, "L": 3, "f": 32,
                                   "value_format": "%.9g"}, "P": 3, "seed": 99},
 }
@@ -70,7 +72,7 @@ def materialise(case: dict, tmp: str) -> str:
     if "synth" in case:
         w = case["synth"]
         synth = pkg("synth")
-        n, row, col, val = synth.make_graph(w["workload"], seed=w["seed"])
+        n, row, col, val = synth.make_graph(w["workload"], w.get("nnz"), seed=w["seed"])
         A = sp.csr_matrix((val.numpy(), (row.numpy(), col.numpy())), shape=(n, n))
         pv = synth.random_partvec(n, w["k"], seed=w["seed"]).numpy() if w["k"] > 1 else np.zeros(n, np.int64)
         out = os.path.join(tmp, "data")
