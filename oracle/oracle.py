@@ -33,7 +33,7 @@ written from the published interfaces, see the header of
 ``oracle/shim/GraphBLAS.h`` for what that does and does not prove;
 ``tests/golden/make_pargcn_ref.py`` -> ``tests/golden/pargcn_ref_*``,
 ``tests/test_reference_grbgcn.py``: the C loop ends on the binary's weights
-bit for bit in all nine cases, P = 1, 2, 3, 4, L = 2, 3, 4).
+bit for bit in all ten cases, P = 1, 2, 3, 4, L = 2, 3, 4).
 """
 from __future__ import annotations
 

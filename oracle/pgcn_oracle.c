@@ -30,7 +30,7 @@
  * restatements of the published interfaces, not SuiteSparse -- what is pinned
  * is main.c's own control flow, operator definitions, message contents and
  * update rule, on top of the textbook meaning of mxm / eWiseAdd / eWiseMult /
- * apply / reduce).  tests/golden/make_pargcn_ref.py runs it on nine data
+ * apply / reduce).  tests/golden/make_pargcn_ref.py runs it on ten data
  * directories (P = 1, 2, 3, 4; 2, 3 and 4 layers; three of them written by the
  * reference's own preprocess + GCN-HP tools) and commits what it printed and
  * the weights it ended with; oracle_pargcn_train ends on the same weights BIT

@@ -20,6 +20,7 @@ shape of BASELINE.json configs[0] (the reference's own CPU-runnable case)."""
 import json
 import os
 import re
+import shutil
 import struct
 import subprocess
 import sys
@@ -44,6 +45,8 @@ CASES = {
     "karate_k2": {"dir": "pargcn/karate_k2", "P": 2, "seed": 7},
     "karate_k3": {"dir": "pargcn/karate_k3", "P": 3, "seed": 11},
     "gemat11p_k3": {"tar": "pargcn/gemat11p_k3.tar.gz", "P": 3, "seed": 5},
+    # layer widths that differ from layer to layer (GCN-HP only writes "f .. f"; main.c:687-714 reads any list)
+    "karate_k3_widths": {"dir": "pargcn/karate_k3", "config": [34, 12, 20, 6, 2], "P": 3, "seed": 17},
     "karate_k1_l2": {"write": {"mtx": "karate.A.mtx", "partvec": "karate.mtx.1.rp", "k": 1, "L": 2, "f": 8,
                                "value_format": "%.9g"}, "P": 1, "seed": 3},
     "gemat11p_k2_l4": {"write": {"mtx": "gemat11p.A.mtx", "partvec": "gemat11.mtx.2.rp", "k": 2, "L": 4, "f": 8,
@@ -62,6 +65,12 @@ CASES = {
 
 def materialise(case: dict, tmp: str) -> str:
     """The data directory of a case (shared with tests/test_reference_grbgcn.py)."""
+    if "dir" in case and "config" in case:                # the committed directory under another config file
+        out = os.path.join(tmp, "data")
+        shutil.copytree(os.path.join(HERE, case["dir"]), out)
+        with open(os.path.join(out, "config"), "w") as fh:
+            fh.write("%d %s \n" % (len(case["config"]) - 1, " ".join(str(x) for x in case["config"])))
+        return out
     if "dir" in case:
         return os.path.join(HERE, case["dir"])
     if "tar" in case:

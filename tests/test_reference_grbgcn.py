@@ -1,7 +1,7 @@
 """the training loop of the reference's CPU engine, pinned by that engine itself.
 
 tests/golden/pargcn_ref_*.{json,npz} hold what /root/reference/Parallel-GCN/main.c -- compiled UNMODIFIED against the
-GraphBLAS / MPI stand-ins of oracle/shim/ (`make -C oracle ref`) -- printed and the weights it ended with, on nine data
+GraphBLAS / MPI stand-ins of oracle/shim/ (`make -C oracle ref`) -- printed and the weights it ended with, on ten data
 directories in the reference's on-disk format (tests/golden/make_pargcn_ref.py).  Here: the oracle's restatement of
 that loop ends on the same weights bit for bit; the product's `pargcn.main` (numpy stand-in kernels over gloo on the
 CPU box, the HIP engine under -m gpu) prints the binary's `err:` lines and ends on its weights within fp32
@@ -33,7 +33,7 @@ CASE_NAMES = list(ref.CASES)
 # shape that running sum is itself 1.8e-5 from the exact sum (2434.70 vs 2434.7435), so anything that adds in another
 # order -- the float64 shadow, torch's pairwise sum in pargcn.py -- is held to 5e-5 on the loss; weights keep 1e-5.
 ERR_RTOL = 5e-5
-SYMMETRIC = ("karate_k2", "karate_k3", "karate_k1_l2", "cora_k1", "cora_k2", "rmat_k4_f64")          # HB/gemat11 has an unsymmetric pattern
+SYMMETRIC = ("karate_k2", "karate_k3", "karate_k1_l2", "cora_k1", "cora_k2", "rmat_k4_f64", "karate_k3_widths")          # HB/gemat11 has an unsymmetric pattern
 
 
 def _fixture(name):

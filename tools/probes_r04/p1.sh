@@ -1,6 +1,6 @@
 #!/bin/bash
 # r04 batch 1 (prepared at the end of r03, when the round's GPU budget was spent; NOT yet run):
-#   a. the nine GPU tests that hold the HIP engine to the outputs of the reference's own main.c
+#   a. the ten GPU tests that hold the HIP engine to the outputs of the reference's own main.c
 #      (tests/test_reference_grbgcn.py -- written and run on the CPU box with the numpy stand-in kernels only);
 #   b. the dense3 harness with its per-wave phase timers (PGCN_DENSE3_PROBE=3 build: where do the 7.75 us per tile go?
 #      tools/micro/mfma_rate says the MFMA dependency pattern is free and one LDS operand read per two MFMAs costs
