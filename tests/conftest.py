@@ -56,6 +56,13 @@ TRAIN_CASES = [
     ("ref_train_karateA", "karate.A.mtx", "karate.mtx.1.rp"),
     ("ref_train_gemat11pA", "gemat11p.A.mtx", "gemat11.mtx.1.rp"),
 ]
+# tests/golden/make_golden_more.py (r03): the Cora shape of BASELINE configs[0] through the reference's GPU/PGCN.py;
+# held by the CPU tests (maps, PSpMM over gloo with two and FOUR ranks, the P = 1 training run)
+SPMM_CASES_MORE = [
+    ("ref_coraA_rp2", "cora.A.mtx", "cora.A.mtx.2.rp", 2),
+    ("ref_coraA_rp4", "cora.A.mtx", "cora.A.mtx.4.rp", 4),
+]
+TRAIN_CASES_MORE = [("ref_train_coraA", "cora.A.mtx", "cora.A.mtx.1.rp")]
 
 
 def golden_inputs(n: int, f: int, seed: int):

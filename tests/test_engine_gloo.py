@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 from scipy.io import mmread
 
 import _workers
-from conftest import SPMM_CASES, TRAIN_CASES, free_port, golden, golden_inputs, gpath, pkg, read_partvec, rel_err
+from conftest import SPMM_CASES, SPMM_CASES_MORE, TRAIN_CASES, TRAIN_CASES_MORE, free_port, golden, golden_inputs, gpath, pkg, read_partvec, rel_err
 from oracle import oracle
 
 TOL = 1e-5
@@ -35,7 +35,7 @@ def _spawn(fn, P, *args, **kw):
     return sorted(res, key=lambda r: r["rank"])
 
 
-@pytest.mark.parametrize("name,mtx,pv,P", [SPMM_CASES[i] for i in (0, 2, 3, 4, 5, 7, 8)])
+@pytest.mark.parametrize("name,mtx,pv,P", [SPMM_CASES[i] for i in (0, 2, 3, 4, 5, 7, 8)] + SPMM_CASES_MORE)
 def test_pspmm_forward_backward(name, mtx, pv, P):
     arrays, meta = golden(name)
     res = _spawn(_workers.pspmm_worker, P, gpath(mtx), gpath(pv), meta["f"], meta["seed"])
@@ -60,7 +60,7 @@ def test_pspmm_forward_backward(name, mtx, pv, P):
     assert rel_err(bwd, oracle.spmm(sp.csr_matrix(A.T), G)) < TOL
 
 
-@pytest.mark.parametrize("name,mtx,pv", TRAIN_CASES)
+@pytest.mark.parametrize("name,mtx,pv", TRAIN_CASES + TRAIN_CASES_MORE)
 def test_run_matches_reference_training_p1(name, mtx, pv):
     arrays, meta = golden(name)
     res = _spawn(_workers.run_worker, 1, gpath(mtx), gpath(pv), meta["nlayers"], meta["f"], meta["seed"])

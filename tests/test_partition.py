@@ -6,7 +6,7 @@ import scipy.sparse as sp
 import torch
 from scipy.io import mmread
 
-from conftest import SPMM_CASES, golden, gpath, pkg, read_partvec
+from conftest import SPMM_CASES, SPMM_CASES_MORE, golden, gpath, pkg, read_partvec
 
 
 def _build(mtx, pv, rank, P, rounds=None):
@@ -37,7 +37,7 @@ def _dense(csr, nrows=None):
     return sp.csr_matrix((v.numpy(), (r.numpy(), c.numpy())), shape=(R, csr.ncols)).toarray()
 
 
-@pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES)
+@pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES + SPMM_CASES_MORE)
 def test_maps_and_counts_match_reference(name, mtx, pv, P):
     arrays, meta = golden(name)
     for r in range(P):
