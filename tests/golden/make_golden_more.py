@@ -7,6 +7,7 @@ with the machinery of make_golden.py (same seeds, same drivers) on the Cora shap
                        makes it reproducible), with seeded 1- / 2- / 4-way part vectors in the reference's format
   ref_coraA_rp2        maps + PSpMM forward AND backward, two ranks
   ref_coraA_rp4        maps + PSpMM forward, FOUR ranks (the first four-way case held against the reference's maps)
+  ref_gat_coraA        two dense PGAT layers of the reference (GPU/PGAT.py:138-151), f = 8: outputs and all gradients
   ref_train_coraA      the body of run() at P = 1: 2 layers, f = 16 -- losses and final weights, cross-checked against
                        the stdout of the unmodified ref.run()
 
@@ -47,6 +48,11 @@ def main():
     p.start()
     p.join()
     assert p.exitcode == 0
+    # GAT (row N3): outputs and ALL gradients of two of the reference's own dense PGAT layers (GPU/PGAT.py) on the same graph
+    import torch
+    import make_golden_gat as mgg
+    torch.set_num_threads(1)
+    mgg.operator_level(mgg.load_ref(), "ref_gat_coraA", "cora.A.mtx", 8, 2)
 
 
 if __name__ == "__main__":

@@ -115,7 +115,8 @@ def test_layers_forward_backward_any_partition(mtx, pv, P, mode, heads, f, L):
         assert r["n_send_rows"] == pairs.shape[1]
 
 
-@pytest.mark.parametrize("name,mtx", [("ref_gat_karateA", "karate.A.mtx"), ("ref_gat_gemat11pA", "gemat11p.A.mtx")])
+@pytest.mark.parametrize("name,mtx", [("ref_gat_karateA", "karate.A.mtx"), ("ref_gat_gemat11pA", "gemat11p.A.mtx"),
+                                      ("ref_gat_coraA", "cora.A.mtx")])
 def test_reference_mode_reproduces_reference_layers(name, mtx):
     """The product's host path (P = 1) in reference mode against the outputs and gradients of the
     reference's own dense PGAT layers -- same parameters, same input."""

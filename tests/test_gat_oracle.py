@@ -55,7 +55,8 @@ def chain_forward_backward(A, arrays, L, dtype):
     return outs, loss, grads
 
 
-@pytest.mark.parametrize("name,mtx", [("ref_gat_karateA", "karate.A.mtx"), ("ref_gat_gemat11pA", "gemat11p.A.mtx")])
+@pytest.mark.parametrize("name,mtx", [("ref_gat_karateA", "karate.A.mtx"), ("ref_gat_gemat11pA", "gemat11p.A.mtx"),
+                                      ("ref_gat_coraA", "cora.A.mtx")])
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 2e-5), (np.float32, 1e-4)])
 def test_sparse_restatement_matches_reference_layers(name, mtx, dtype, tol):
     arrays, meta = golden(name)
