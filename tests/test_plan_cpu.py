@@ -3,6 +3,11 @@ gather tasks and their XCD segments, fix records, strip records (layers, pad slo
 LDS-core tiles, MFMA tiles in A-operand order, the per-row slot lists of the fix-up, row maps of the halo blocks -- is
 decoded the way include/pgcn_hip.h specifies and must reproduce A . B to float64 round-off.  Host logic only: what a
 wrong offset in partition.py / kernels.py / pgcn_spmm_plan_host would otherwise show on a GPU first."""
+import os
+import re
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -267,3 +272,20 @@ def test_default_tuning_on_a_dense_graph_reaches_every_tile_path():
     for a in pt.A_halo:
         C, _ = run_plan(K.prepare(a), H[hg], C0=C, accumulate=True)
     assert np.abs(C - AH[own]).max() < TOL
+
+
+@pytest.mark.parametrize("tuning,parts1,parts3,rounds3", [
+    ("core_min_nnz=0,core_min_frac=0,strip_min_records=0,exchange_rounds=3", "sd", "sd", 3),     # strips + MFMA tiles on a shard too
+    ("strip=0,core_min_nnz=0,core_emax=500,exchange_rounds=1", "cd", "cd", 1),                   # LDS core with short pieces
+    ("tiles=0,slices=1,spmm_chunk=64,spmm_adaptive_chunk=0", "-", "-", 2),                       # gather only, unsliced, short tasks
+])
+def test_non_default_tunings_keep_the_plans_exact(tuning, parts1, parts3, rounds3):
+    """PGCN_TUNING is the one switchboard of the path (tuning.py); whatever it selects, the plans must still be the
+    product.  One interpreter per tuning (the variable is read once at import): tests/_plan_tuning_child.py."""
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_plan_tuning_child.py")
+    out = subprocess.run([sys.executable, child], env=dict(os.environ, PGCN_TUNING=tuning), capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = re.findall(r"P=(\d) parts=(\S+) rounds=(\d+) err=(\S+)", out.stdout)
+    assert [(g[0], g[1]) for g in got] == [("1", parts1), ("3", parts3)] and int(got[1][2]) == rounds3
+    assert all(float(g[3]) < TOL for g in got)
