@@ -278,16 +278,16 @@ def bench_inputs_worker(rank, P, port, kind, path, path_pv, q):
     dist.destroy_process_group()
 
 
-def pargcn_main_worker(rank, P, port, directory, seed, q):
+def pargcn_main_worker(rank, P, port, directory, seed, q, provider="oracle"):
     """pargcn.main (the `grbgcn -p DIR -c CONFIG` command line of Parallel-GCN/main.c:120-165) with world > 1
     over gloo, checker-backed kernels."""
     _init(rank, P, port)
     from conftest import pkg
-    from oracle_kernels import OracleKernels
+    from oracle_kernels import OracleKernels, PlanKernels
     os.environ["PGCN_SEED"] = str(seed)
     buf = io.StringIO()
     errs, Wn, Hout, part = pkg("pargcn").main(["-p", directory, "-c", os.path.join(directory, "config")],
-                                             kernels=OracleKernels(), out=buf)
+                                             kernels=PlanKernels() if provider == "plans" else OracleKernels(), out=buf)
     q.put({"rank": rank, "stdout": buf.getvalue(), "errs": [float(e) for e in errs],
            "W": {l: w.numpy() for l, w in Wn.items()}, "own": part.owned.numpy(), "H": Hout.numpy(),
            "n_send": part.n_send, "n_halo": part.n_halo,

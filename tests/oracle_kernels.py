@@ -59,6 +59,34 @@ class OracleKernels:
         return H
 
 
+class PlanKernels(OracleKernels):
+    """The same interface with every SpMM executed FROM ITS LAUNCH PLAN (tests/plan_interpreter.py): ``prepare`` runs the
+    host half of ``HipKernels`` (tasks, strip / core / MFMA tiles, slot lists) and ``spmm`` walks those arrays the way
+    the kernels are specified to.  Slower than OracleKernels; used where a whole run should exercise the plans."""
+    name = "plans(test-only)"
+
+    def __init__(self):
+        from plan_interpreter import HostPlanner
+        self._planner = HostPlanner()
+
+    def prepare(self, csr, pattern_only=False):
+        return self._planner.prepare(csr, pattern_only)
+
+    def spmm(self, A, B, C, accumulate=False):
+        from plan_interpreter import run_plan
+        if A.nrows == 0:
+            return C
+        if A.col.numel() == 0 and A.core is None and A.dense is None and A.strip is None:
+            if not accumulate:                       # an empty block: C = 0 (kernels._bind_spmm does the same without a launch)
+                (C[:A.nrows] if A.row_map is None else C[A.row_map.long()]).zero_()
+            return C
+        out, _ = run_plan(A, B.detach().numpy(), C0=C.detach().numpy() if accumulate else None, accumulate=accumulate)
+        rows = np.arange(A.nrows) if A.row_map is None else A.row_map.numpy().astype(np.int64)
+        assert not np.isnan(out[rows]).any(), "the plan leaves output rows unwritten"
+        C[torch.from_numpy(rows)] = torch.from_numpy(out[rows].astype(np.float32))
+        return C
+
+
 # ---- GAT path: numpy stand-ins for pgcn_gat.hip on the STORAGE order of the structure ----------
 class _CpuGat(_CpuCSR):
     def __init__(self, csr, rows_wave, rows_block):

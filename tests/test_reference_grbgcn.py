@@ -130,17 +130,19 @@ def _check_product(name, stdout, errs, W, printed, Wend, meta, tol_err, tol_w):
         assert all(a <= b for a, b in zip(stats, meta["stats"])) and stats[4:] == meta["stats"][4:]
 
 
-@pytest.mark.parametrize("name", CASE_NAMES)
-def test_product_main_over_gloo_prints_the_reference_lines(name, tmp_path):
+@pytest.mark.parametrize("name,provider", [(nm, "oracle") for nm in CASE_NAMES] +
+                         [("gemat11p_k3", "plans"), ("rmat_k4_f64", "plans"), ("karate_k3_widths", "plans")])
+def test_product_main_over_gloo_prints_the_reference_lines(name, provider, tmp_path):
     """`pargcn.main -p DIR -c DIR/config` with as many ranks as the directory has parts (gloo, numpy stand-ins of the
-    kernels), started from the reference's own weight draw (PGCN_SEED=glibc:<seed>), against the binary's output."""
+    kernels), started from the reference's own weight draw (PGCN_SEED=glibc:<seed>), against the binary's output.
+    provider "plans": every aggregation of the run is executed from its launch plan (oracle_kernels.PlanKernels)."""
     meta, printed, _, Wend = _fixture(name)
     directory, _ = _problem(name, tmp_path)
     P = meta["P"]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=_workers.pargcn_main_worker, args=(r, P, port, directory, "glibc:%d" % meta["seed"], q))
+    procs = [ctx.Process(target=_workers.pargcn_main_worker, args=(r, P, port, directory, "glibc:%d" % meta["seed"], q, provider))
              for r in range(P)]
     for p in procs:
         p.start()
