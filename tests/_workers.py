@@ -280,16 +280,18 @@ def bench_inputs_worker(rank, P, port, kind, path, path_pv, q):
 
 def pargcn_main_worker(rank, P, port, directory, seed, q, provider="oracle"):
     """pargcn.main (the `grbgcn -p DIR -c CONFIG` command line of Parallel-GCN/main.c:120-165) with world > 1
-    over gloo, checker-backed kernels."""
+    over gloo: checker-backed kernels ("oracle", "plans"), or -- provider "hip" -- the product's own choice, i.e. the
+    REAL HIP kernels on every rank, the P processes sharing the one GPU (gloo transport, host-staged)."""
     _init(rank, P, port)
     from conftest import pkg
     from oracle_kernels import OracleKernels, PlanKernels
     os.environ["PGCN_SEED"] = str(seed)
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(P), "0"
     buf = io.StringIO()
-    errs, Wn, Hout, part = pkg("pargcn").main(["-p", directory, "-c", os.path.join(directory, "config")],
-                                             kernels=PlanKernels() if provider == "plans" else OracleKernels(), out=buf)
+    kernels = None if provider == "hip" else (PlanKernels() if provider == "plans" else OracleKernels())
+    errs, Wn, Hout, part = pkg("pargcn").main(["-p", directory, "-c", os.path.join(directory, "config")], kernels=kernels, out=buf)
     q.put({"rank": rank, "stdout": buf.getvalue(), "errs": [float(e) for e in errs],
-           "W": {l: w.numpy() for l, w in Wn.items()}, "own": part.owned.numpy(), "H": Hout.numpy(),
+           "W": {l: w.cpu().numpy() for l, w in Wn.items()}, "own": part.owned.numpy(), "H": Hout.cpu().numpy(),
            "n_send": part.n_send, "n_halo": part.n_halo,
            "targets": int(torch.unique(part.send_owner).numel()), "sources": int(torch.unique(part.halo_owner).numel())})
     dist.barrier()

@@ -79,6 +79,31 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+OBSERVED_LOG = os.path.join(ROOT, "gpurun_out", "parity_observed.jsonl")
+
+
+def held_to_fixture(case: str, what: str, got, fixture, shadow64, floor: float = 1e-5, record: bool = True):
+    """north_star's bar ("within 1e-5 relative fp32") where the comparison value is itself an fp32 result of the
+    reference: both the HIP result and the reference-made fixture are measured against a float64 shadow of the same
+    arithmetic, and the HIP result may be at most ``floor`` away from the shadow -- or twice as far as the reference's
+    own fp32 result is, where that one is already beyond the floor (its running fp32 sums, Adam's division by
+    sqrt(v)).  No blanket tolerance: the observed pair goes to gpurun_out/parity_observed.jsonl (DESIGN.md section 2
+    tabulates it) and into the assertion message."""
+    e_got, e_fix = rel_err(got, shadow64), rel_err(fixture, shadow64)
+    if record:
+        try:
+            os.makedirs(os.path.dirname(OBSERVED_LOG), exist_ok=True)
+            with open(OBSERVED_LOG, "a") as fh:
+                fh.write(json.dumps({"case": case, "what": what, "err_hip": e_got, "err_fixture": e_fix,
+                                     "bound": max(floor, 2 * e_fix)}) + "\n")
+        except OSError:
+            pass
+    assert e_got <= max(floor, 2 * e_fix), \
+        "%s %s: HIP result is %.3g from the float64 shadow, the reference's own fp32 result %.3g (bound %.3g)" % (
+            case, what, e_got, e_fix, max(floor, 2 * e_fix))
+    return e_got, e_fix
+
+
 def free_port() -> int:
     """A TCP port the kernel just handed out on 127.0.0.1 (fixed port numbers collide under pytest-xdist and with
     sockets of an earlier test still in TIME_WAIT)."""

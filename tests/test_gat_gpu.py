@@ -8,7 +8,7 @@ import torch
 from scipy.io import mmread
 
 import _workers
-from conftest import free_port, golden, gpath, pkg, rel_err
+from conftest import free_port, golden, gpath, held_to_fixture, pkg, rel_err
 from oracle import oracle
 from test_engine_gloo import _spawn
 from test_gat_gloo import CASES, _expected, _losses, _pattern
@@ -175,13 +175,20 @@ def test_attention_kernels_edge_cases_and_errors(K, dev):
     assert b"pgcn_gat_edge_softmax_f32" in L.pgcn_last_error()
 
 
-@pytest.mark.parametrize("name,mtx", [("ref_gat_karateA", "karate.A.mtx"), ("ref_gat_gemat11pA", "gemat11p.A.mtx")])
+@pytest.mark.parametrize("name,mtx", [("ref_gat_karateA", "karate.A.mtx"), ("ref_gat_gemat11pA", "gemat11p.A.mtx"),
+                                      ("ref_gat_coraA", "cora.A.mtx")])
 def test_engine_reference_mode_vs_reference_layers(dev, name, mtx):
-    """The product path on the GPU (P = 1, reference mode) against the reference's own dense layers."""
+    """The product path on the GPU (P = 1, reference mode) against the reference's own dense layers (GPU/PGAT.py:138-151;
+    the Cora shape of BASELINE configs[0] included).  The reference's gradients pass through two fp32 softmaxes over
+    all n columns and are themselves up to 1e-3 from exact arithmetic, so outputs and gradients of both sides are
+    measured against the float64 run of the sparse restatement (test_gat_oracle.chain_forward_backward) and the HIP
+    result may be 1e-5 or twice the reference's own distance away (conftest.held_to_fixture)."""
+    from test_gat_oracle import chain_forward_backward, positive_pattern
     arrays, meta = golden(name)
     M = _workers._pgat_module(0, 1, "reference", 1, gpu=True)
     A = mmread(gpath(mtx))
     n, f, L = meta["n"], meta["f"], meta["layers"]
+    outs64, loss64, grads64 = chain_forward_backward(positive_pattern(A), arrays, L, np.float64)
     eng = M.get_partitiont_of_adjacency_matrix(A, [0] * n, 0)
     assert type(M._kernel_provider).__name__ == "HipKernels"
     own = eng.part.owned.numpy()
@@ -194,14 +201,14 @@ def test_engine_reference_mode_vs_reference_layers(dev, name, mtx):
     x = H
     for i, layer in enumerate(layers):
         x = layer(x)
-        assert rel_err(x.detach().cpu().numpy(), arrays["out_%d" % i][own]) < 1e-4
+        held_to_fixture(name, "PGAT layer %d output" % i, x.detach().cpu().numpy(), arrays["out_%d" % i][own], outs64[i][own])
     loss = M.local_loss(x, torch.from_numpy(own).to(dev) % f, n)
-    assert abs(float(loss.detach()) - meta["loss"]) < 1e-5 * meta["loss"]
+    assert abs(float(loss.detach()) - loss64) <= max(1e-5, 2 * abs(meta["loss"] - loss64) / abs(loss64)) * abs(loss64)
     loss.backward()
-    assert rel_err(H.grad.cpu().numpy(), arrays["dH"][own]) < 2e-3
+    held_to_fixture(name, "dH", H.grad.cpu().numpy(), arrays["dH"][own], grads64["dH"][own])
     for i, layer in enumerate(layers):
-        assert rel_err(layer.linear.weight.grad.cpu().numpy(), arrays["dW_%d" % i]) < 2e-3
-        assert rel_err(layer.attention.grad.cpu().numpy(), arrays["da_%d" % i]) < 2e-3
+        held_to_fixture(name, "dW_%d" % i, layer.linear.weight.grad.cpu().numpy(), arrays["dW_%d" % i], grads64["dW_%d" % i])
+        held_to_fixture(name, "da_%d" % i, layer.attention.grad.cpu().numpy(), arrays["da_%d" % i], grads64["da_%d" % i])
 
 
 @pytest.mark.parametrize("mtx,pv,P,mode,heads,f,L", CASES)

@@ -16,8 +16,8 @@ import scipy.sparse as sp
 import torch
 from scipy.io import mmread
 
-from conftest import (SPMM_CASES, TRAIN_CASES, free_port, golden, golden_inputs, gpath, pkg, read_partvec,
-                      rel_err)
+from conftest import (SPMM_CASES, SPMM_CASES_MORE, TRAIN_CASES, TRAIN_CASES_MORE, free_port, golden, golden_inputs, gpath,
+                      held_to_fixture, pkg, read_partvec, rel_err)
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -492,19 +492,26 @@ def _virtual_ranks_fwd_bwd(K, dev, A, part, P, Hfull, Gfull):
     return fwd, bwd, engines
 
 
-@pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES)
+@pytest.mark.parametrize("name,mtx,pv,P", SPMM_CASES + SPMM_CASES_MORE)
 def test_engine_forward_backward_vs_reference_golden(K, dev, name, mtx, pv, P):
-    """Every rank's engine on the one GPU, checked against the reference's PSpMM outputs."""
+    """Every rank's engine on the one GPU (real kernels), against the outputs of the reference's own PSpMM
+    (GPU/PGCN.py:121-134) -- the Cora shape of BASELINE configs[0] with two and four ranks included.  Both sides are
+    measured against a float64 product of the same matrices (conftest.held_to_fixture): no blanket tolerance."""
     arrays, meta = golden(name)
     A = sp.coo_matrix(mmread(gpath(mtx)))
     n, f = A.shape[0], meta["f"]
     part = torch.tensor(read_partvec(gpath(pv)))
     Hfull, Gfull = golden_inputs(n, f, meta["seed"])
     fwd, bwd, _ = _virtual_ranks_fwd_bwd(K, dev, A, part, P, Hfull, Gfull)
-    assert rel_err(fwd, arrays["fwd"]) < TOL
+    A64 = sp.csr_matrix(A).astype(np.float64)                     # (duplicates add, like the reference's uncoalesced COO)
+    ref_f, ref_b = A64 @ Hfull.astype(np.float64), A64.T.tocsr() @ Gfull.astype(np.float64)
+    held_to_fixture(name, "PSpMM.forward", fwd, arrays["fwd"], ref_f)
+    assert rel_err(fwd, arrays["fwd"]) < 2 * TOL                  # ... and to each other, both being within the floor
     assert rel_err(bwd, oracle.spmm(sp.csr_matrix(A.T).astype(np.float32), Gfull)) < TOL
     if "bwd" in arrays:
-        assert rel_err(bwd, arrays["bwd"]) < TOL
+        held_to_fixture(name, "PSpMM.backward", bwd, arrays["bwd"], ref_b)
+    else:
+        assert rel_err(bwd, ref_b) < TOL
 
 
 @pytest.mark.parametrize("P,f", [(2, 128), (3, 64)])
@@ -537,9 +544,13 @@ def test_engine_halo_dense_core(K, dev, P, f, monkeypatch):
         assert worst <= 1.0, "a row exceeds 1e-5 * sum|a||x| by a factor %.3g" % worst
 
 
-@pytest.mark.parametrize("name,mtx,pv", TRAIN_CASES)
+@pytest.mark.parametrize("name,mtx,pv", TRAIN_CASES + TRAIN_CASES_MORE)
 def test_run_matches_reference_training(dev, name, mtx, pv):
-    """The drop-in's run() on the GPU at P=1 vs losses/weights of the reference's run()."""
+    """The drop-in's run() on the GPU at P=1 vs losses/weights of the reference's run() (GPU/PGCN.py:194-226; the Cora
+    shape of BASELINE configs[0] included).  Five Adam steps divide by sqrt(v): where a gradient entry is near zero the
+    reference's own fp32 run is already far from exact arithmetic, so both runs are measured against the float64
+    shadow of the loop (oracle.pgcn_train_np) and the HIP run may be as far as the floor 1e-5 or twice the
+    reference's own distance (conftest.held_to_fixture)."""
     arrays, meta = golden(name)
     M = pkg("PGCN")
     M._kernel_provider = None
@@ -553,10 +564,18 @@ def test_run_matches_reference_training(dev, name, mtx, pv):
     with contextlib.redirect_stdout(buf):
         model = M.run(0, 1, meta["nlayers"], meta["f"], gpath(mtx), gpath(pv), "nccl")
     printed = [float(x) for x in re.findall(r"Epoch \d{5} \| Loss ([0-9.]+)", buf.getvalue())]
-    np.testing.assert_allclose(printed, arrays["losses"][1:], rtol=5e-5, atol=6e-5)
-    for i, m in enumerate(model):
-        assert rel_err(m.linear.weight.detach().cpu().numpy(), arrays["w1_%d" % i]) < 2e-4
     assert type(M._kernel_provider).__name__ == "HipKernels"
+    A = sp.csr_matrix(mmread(gpath(mtx)))
+    n, f = A.shape[0], meta["f"]
+    H0 = np.repeat(np.arange(n, dtype=np.float64)[:, None], f, axis=1)            # PGCN.py:187-189
+    losses64, W64 = oracle.pgcn_train_np(A, [0] * n, 1, w0, H0, np.arange(n) % f, epochs=5)
+    # the printed loss has four decimals ("{:.4f}", PGCN.py:224): half a unit of the last digit is the print's own error
+    e_fix = rel_err(arrays["losses"][1:], losses64[1:])
+    bound = max(1e-5, 2 * e_fix) * np.abs(losses64[1:]) + 0.5e-4
+    assert (np.abs(np.array(printed) - losses64[1:]) <= bound).all(), (printed, losses64[1:], e_fix)
+    for i, m in enumerate(model):
+        held_to_fixture(name, "run() weight %d after 5 Adam steps" % i, m.linear.weight.detach().cpu().numpy(),
+                        arrays["w1_%d" % i], W64[i])
 
 
 def test_pargcn_semantics_vs_oracle(K, dev):

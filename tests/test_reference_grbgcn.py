@@ -21,7 +21,7 @@ import scipy.sparse as sp
 import torch.multiprocessing as mp
 
 import _workers
-from conftest import GOLDEN, ROOT, free_port, pkg, rel_err
+from conftest import GOLDEN, ROOT, free_port, held_to_fixture, pkg, rel_err
 from oracle import oracle
 
 sys.path.insert(0, GOLDEN)
@@ -175,21 +175,78 @@ def test_reference_binary_reproduces_the_fixtures(tmp_path):
             assert np.array_equal(W[l], Wend[l])
 
 
+def _shadow(name, tmp_path):
+    """float64 run of the restated loop from the binary's own start: what both the binary's fp32 numbers and the HIP
+    engine's are measured against (conftest.held_to_fixture)."""
+    meta, printed, W0, Wend = _fixture(name)
+    directory, prob = _problem(name, tmp_path)
+    d, n = prob["d"], prob["d"][0]
+    A, _ = oracle.drop_undelivered(prob["A"], prob["part"], prob["conn"], meta["P"])
+    errd, Wd, _ = oracle.pargcn_train_np(A, d, W0, np.ones((n, d[1]), np.float32), prob["Y"], prob["Ymask"])
+    return meta, printed, Wend, directory, errd, Wd
+
+
+def _held_to_the_binary(name, what, got_errs, W, printed, Wend, errd, Wd):
+    """err lines: the binary prints six significant digits of an fp32 RUNNING sum (main.c:320,323) that is itself up to
+    1.8e-5 from the exact sum (Cora shape); weights: 3 plain gradient steps, the binary's are ~1e-7 from exact."""
+    held_to_fixture(name, what + " err lines", got_errs, printed, errd)
+    for l in Wend:
+        held_to_fixture(name, what + " W[%d]" % l, W[l], Wend[l], Wd[l])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASE_NAMES)
 def test_hip_engine_on_the_reference_outputs(name, tmp_path, monkeypatch):
-    """The same command line on the HIP engine (one rank, real kernels): the binary's `err:` lines and final weights."""
+    """The same command line on the HIP engine (one rank, real kernels): the binary's `err:` lines and final weights,
+    each side measured against the float64 shadow (no blanket tolerance)."""
     import torch
     assert torch.cuda.is_available()
-    meta, printed, _, Wend = _fixture(name)
-    directory, _ = _problem(name, tmp_path)
+    meta, printed, Wend, directory, errd, Wd = _shadow(name, tmp_path)
     monkeypatch.setenv("PGCN_SEED", "glibc:%d" % meta["seed"])
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     buf = io.StringIO()
     errs, Wn, _, _ = pkg("pargcn").main(["-p", directory, "-c", os.path.join(directory, "config")], out=buf)
     got = [float(x) for x in re.findall(r"^err:(\S+)$", buf.getvalue(), re.M)]
-    np.testing.assert_allclose(got, printed, rtol=ERR_RTOL)
-    np.testing.assert_allclose([float(e) for e in errs], printed, rtol=ERR_RTOL)
-    for l in Wend:
-        assert rel_err(Wn[l].cpu().numpy(), Wend[l]) < 5e-5
+    np.testing.assert_allclose(got, [float(e) for e in errs], rtol=6e-6)             # %g keeps six significant digits
+    _held_to_the_binary(name, "P=1", [float(e) for e in errs], {l: w.cpu().numpy() for l, w in Wn.items()}, printed, Wend, errd, Wd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [nm for nm in CASE_NAMES if ref.CASES[nm]["P"] > 1])
+def test_hip_engine_multi_rank_on_the_reference_outputs(name, tmp_path):
+    """As many PROCESSES as the directory has parts share the one GPU (gloo transport, host-staged; real kernels and
+    the comm-stream overlap on every rank): the halo path of pargcn.main (boundary rows out, `A_halo . halo`,
+    all-reduced losses and dW: Parallel-GCN/main.c:238-335,425) against the lines and weights of the reference binary
+    run with the same number of ranks -- and its statistics line where the pattern is symmetric."""
+    import torch
+    assert torch.cuda.is_available()
+    meta, printed, Wend, directory, errd, Wd = _shadow(name, tmp_path)
+    P = meta["P"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_workers.pargcn_main_worker, args=(r, P, port, directory, "glibc:%d" % meta["seed"], q, "hip"))
+             for r in range(P)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(P)], key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    stdout = res[0]["stdout"]
+    got = [float(x) for x in re.findall(r"^err:(\S+)$", stdout, re.M)]
+    assert len(got) == 3
+    np.testing.assert_allclose(got, res[0]["errs"], rtol=6e-6)
+    _held_to_the_binary(name, "P=%d" % P, res[0]["errs"], res[0]["W"], printed, Wend, errd, Wd)
+    lines = stdout.strip().split("\n")
+    assert lines[0] == meta["stdout"][0] and lines[1] == meta["stdout"][1]                   # config echo, main.c:699-704
+    stats = [int(x) for x in lines[-1].split()]
+    if name in SYMMETRIC:
+        assert stats == meta["stats"]
+    else:       # this engine moves the rows the entries need; the reference also ships rows nobody refers to
+        assert all(a <= b for a, b in zip(stats, meta["stats"])) and stats[4:] == meta["stats"][4:]
+    for r in res[1:]:                                                                        # every rank ends on the same weights
+        for l in Wend:
+            assert np.array_equal(r["W"][l], res[0]["W"][l])
+    assert sum(r["n_halo"] for r in res) > 0
