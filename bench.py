@@ -713,6 +713,9 @@ def main():
         if getattr(eng.A_loc, "dense", None) is not None:
             kname += " + spmm_dense_kernel<4> (fp32-MFMA tiles, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.dense.nnz / max(eng.A_loc.nnz, 1))
+        if getattr(eng.A_loc, "dense3", None) is not None:
+            kname += " + split_panels_kernel + spmm_dense3_kernel<4> (512x128 blocks on the bf16 matrix cores, three-plane split at fp32 accuracy, %.0f%% of the entries)" % (
+                100.0 * eng.A_loc.dense3.nnz / max(eng.A_loc.nnz, 1))
         kname += " + fix-up; one launch group, timed as a whole"
         roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -772,7 +775,8 @@ def main():
                    "exchange": exch.name if exch else "none",
                    "xcd_slices": eng.A_loc.nslices, "chunk": K.chunk,
                    "core_tile_fill_min": partition.CORE_TAU,
-                   "mfma_tile_fill_min": partition.DENSE_TAU if partition.DENSE_ON else None,
+                   "mfma_tile_fill_min": (partition.DENSE_TAU if partition.DENSE_ON and not partition.DENSE3_ON else None),
+                   "bf16x3_block_fill_min": partition.DENSE3_TAU if partition.DENSE3_ON else None,
                    "exchange_rounds": part.rounds, "vertex_order": part.order_info,
                    "dense_gemm": "stock rocBLAS / hipBLASLt via PyTorch, kernel per shape picked by TunableOp in set-up" if gemm_tuned
                                  else "stock rocBLAS / hipBLASLt via PyTorch (default pick)",

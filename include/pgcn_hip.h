@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PGCN_ABI_VERSION 1
+#define PGCN_ABI_VERSION 2   /* r04: + pgcn_spmm_dense_bf16x3_f32; r03 changed layouts of the GAT entry points (entry-major de / src) */
 
 #define PGCN_OK 0
 #define PGCN_EINVAL (-1)  /* bad argument (null pointer, misaligned, negative size) */
@@ -210,6 +210,25 @@ int pgcn_spmm_strip_f32(const int32_t *work, int64_t nwork, const int32_t *recs,
                         const float *B, int64_t ldb, int64_t ncols, int32_t f, float *partial_ws,
                         int64_t partial_ws_elems, int64_t nslots_total, pgcn_stream_t stream);
 
+
+/* The densest 512 x 128 BLOCKS through the bf16 matrix cores at fp32 accuracy (v_mfma_f32_32x32x16_bf16; every fp32
+ * operand is the exact sum of three bf16 numbers, the six partial products that matter are accumulated in fp32,
+ * smallest first: the error class of an fp32 dot product, deterministic).  Part of PSpMM's torch.sparse.mm
+ * (/root/reference/GPU/PGCN.py:127,132) like the other SpMM entry points.
+ *   vals3[block][w][unit = 2 ks + rb][h][lane][e] = A[64 w + 32 rb + (lane & 31)][16 ks + 8 (lane >> 5) + 4 h + e]
+ *     (65 536 fp32 per block, 16-byte aligned: the A-operand order of the instruction for wave w of 8);
+ *   work: 4 x int32 per piece {block row, first block, number of blocks, first slot}; a piece leaves a 512 x f block of
+ *     partial sums in partial_ws (slot rows of f floats) for pgcn_spmm_fixup_f32;
+ *   panel_list[npanels]: the distinct column blocks the blocks refer to (rows [128 p, 128 p + 128) of B, rows >= ncols
+ *     read as zero), blk_img[b]: position of block b's column block in panel_list.
+ * The call first splits the listed panels of B into bf16 planes in image_ws (pgcn_dense_bf16x3_image_bytes(npanels, f)
+ * bytes, 16-byte aligned; scratch, rewritten by every call), then runs the blocks.  Zeros of a block are structural:
+ * a panel holding Inf / NaN takes an exact (slow) path that multiplies only where A != 0.  Any f, ldb, alignment of B. */
+int64_t pgcn_dense_bf16x3_image_bytes(int64_t npanels, int32_t f);
+int pgcn_spmm_dense_bf16x3_f32(const int32_t *work, int64_t nwork, const int32_t *blk_img, const float *vals3,
+                               const int32_t *panel_list, int64_t npanels, const float *B, int64_t ldb, int64_t ncols,
+                               int32_t f, void *image_ws, int64_t image_ws_bytes, float *partial_ws,
+                               int64_t partial_ws_elems, int64_t nslots_total, pgcn_stream_t stream);
 
 /* The densest tiles through the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32, k-ordered
  * fmaf chains).  A tile is stored dense, pre-swizzled into the A-operand order:

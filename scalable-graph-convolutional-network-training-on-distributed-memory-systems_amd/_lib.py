@@ -62,6 +62,8 @@ SIGNATURES = {
                                                     _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _u32,
                                                     _vp]),
     "pgcn_spmm_dense_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp]),
+    "pgcn_spmm_dense_bf16x3_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "pgcn_dense_bf16x3_image_bytes": (_i64, [_i64, _i32]),
     "pgcn_spmm_fixup_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _u32, _vp]),
     "pgcn_spmm_plan_host": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp,
                                            ctypes.POINTER(_i64), ctypes.POINTER(_i64),
@@ -98,6 +100,9 @@ class PgcnError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2      # PGCN_ABI_VERSION of include/pgcn_hip.h
+
+
 def build(verbose: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     out = subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh")], capture_output=True, text=True)
@@ -121,8 +126,9 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.pgcn_abi_version() != 1:
-            raise PgcnError("libpgcn_hip.so ABI version mismatch")
+        if L.pgcn_abi_version() != ABI_VERSION:
+            raise PgcnError("libpgcn_hip.so has ABI version %d, this package binds version %d: rebuild (csrc/build.sh)"
+                            % (L.pgcn_abi_version(), ABI_VERSION))
         _LIB = L
     return _LIB
 
@@ -130,8 +136,11 @@ def lib():
 def load_variant(path: str):
     """Load ANOTHER build of the library (A/B probes: tools/ab_build.sh); typed like lib()."""
     L = ctypes.CDLL(path)
+    L.pgcn_abi_version.restype = ctypes.c_int
+    if L.pgcn_abi_version() != ABI_VERSION:       # same names, other layouts: refuse instead of computing nonsense
+        raise PgcnError("%s has ABI version %d, this package binds version %d" % (path, L.pgcn_abi_version(), ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(L, name, None)       # an older variant build may lack newer entry points
+        fn = getattr(L, name, None)       # a variant build may lack entry points (probe builds)
         if fn is not None:
             fn.restype = res
             fn.argtypes = args

@@ -51,6 +51,7 @@ class DeviceCSR:
     core: Optional["DeviceCore"] = None   # dense-tile part (LDS-tiled kernel)
     dense: Optional["DeviceDense"] = None  # densest tiles (fp32 matrix cores)
     strip: Optional["DeviceStrip"] = None  # 512 x 128 strip tiles (LDS-staged, async pipeline)
+    dense3: Optional["DeviceDense3"] = None  # densest 512 x 128 blocks (bf16 matrix cores, three planes)
     fix_all: Optional[torch.Tensor] = None    # int32 [nfix_all,4] combined fix list (core + gather slots)
     slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
     nslots_total: int = 0
@@ -79,6 +80,18 @@ class DeviceDense:
     vals: torch.Tensor
     npieces: int
     nnz: int
+
+
+@dataclass
+class DeviceDense3:
+    work: torch.Tensor
+    blk_img: torch.Tensor
+    vals3: torch.Tensor
+    panel_list: torch.Tensor
+    npieces: int
+    npanels: int
+    nnz: int
+    image: Optional[torch.Tensor] = None      # uint8 work-space of the split panels (grown on demand, per width)
 
 
 @dataclass
@@ -198,7 +211,7 @@ class HipKernels:
             d.ntasks, d.nfix, d.nslots = tasks.shape[0], fix.shape[0], nslots
             d.nslices, d.seg = csr.nslices if sc is not None else 1, seg
         d.nslots_total = d.nslots
-        if csr.core is not None or csr.dense is not None or csr.strip is not None:
+        if csr.core is not None or csr.dense is not None or csr.strip is not None or csr.dense3 is not None:
             self._attach_core(d, csr, fix if tasks is not None else None)
         return d
 
@@ -207,7 +220,7 @@ class HipKernels:
         partial sums are its core pieces (in work order), its dense pieces, then its gather-kernel slots."""
         from .partition import CORE_TR, STRIP_TR
         dev = self.device
-        hc, hd, hs = csr.core, csr.dense, csr.strip
+        hc, hd, hs, h3 = csr.core, csr.dense, csr.strip, csr.dense3
         ns_rem = d.nslots
         pieces = []                                                # (first row, rows, first slot) of every piece
         ns_core = ns_strip = 0
@@ -235,6 +248,13 @@ class HipKernels:
                                   hd.vals.to(dev).contiguous(), hd.npieces, hd.nnz)
             w64 = work.cpu().to(torch.int64)
             pieces.append(torch.stack([w64[:, 0] * CORE_TR, torch.full_like(w64[:, 0], CORE_TR), w64[:, 3]], 1))
+        if h3 is not None:
+            work = h3.work.clone()
+            work[:, 3] += ns_rem + ns_strip + ns_core + (hd.nslots if hd is not None else 0)   # ... and the bf16 blocks last
+            d.dense3 = DeviceDense3(work.to(dev).contiguous(), h3.blk_img.to(dev).contiguous(), h3.vals3.to(dev).contiguous(),
+                                    h3.panel_list.to(dev).contiguous(), h3.npieces, int(h3.panel_list.numel()), h3.nnz)
+            w64 = work.cpu().to(torch.int64)
+            pieces.append(torch.stack([w64[:, 0] * STRIP_TR, torch.full_like(w64[:, 0], STRIP_TR), w64[:, 3]], 1))
         wk = torch.cat(pieces)
         cntp = wk[:, 1]
         startp = torch.cumsum(cntp, 0) - cntp
@@ -260,7 +280,7 @@ class HipKernels:
         fix_all = torch.stack([urows, begin, counts, torch.zeros_like(urows)], 1).to(torch.int32)
         d.fix_all = fix_all.to(dev).contiguous()
         d.slot_ids = slots.to(torch.int32).to(dev).contiguous()
-        d.nslots_total = ns_rem + ns_strip + ns_core + (hd.nslots if hd is not None else 0)
+        d.nslots_total = ns_rem + ns_strip + ns_core + (hd.nslots if hd is not None else 0) + (h3.nslots if h3 is not None else 0)
         d.nnz = csr.nnz
 
     # -- kernels ----------------------------------------------------------
@@ -307,7 +327,7 @@ class HipKernels:
         lib, check, stream = self.lib, _lib.check, self._stream
         if A.nrows == 0:
             return lambda B, C: None
-        if A.nnz == 0 and A.core is None and A.dense is None and A.strip is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
+        if A.nnz == 0 and A.core is None and A.dense is None and A.strip is None and A.dense3 is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
             if accumulate:
                 return lambda B, C: None
             if A.row_map is None:
@@ -315,7 +335,7 @@ class HipKernels:
             rows = A.row_map.long()
             return lambda B, C: C.index_fill_(0, rows, 0.0)
         rowptr, col, val, rmap = A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), _ptr(A.row_map)
-        if A.tasks is None and A.row_map is None and A.core is None and A.dense is None and A.strip is None:
+        if A.tasks is None and A.row_map is None and A.core is None and A.dense is None and A.strip is None and A.dense3 is None:
             nrows = A.nrows
             def simple(B, C):
                 check(lib.pgcn_spmm_csr_f32(rowptr, col, val, nrows, B.data_ptr(), ldb, C.data_ptr(), ldc, f,
@@ -328,7 +348,7 @@ class HipKernels:
         ws, ws_n = _ptr(A.ws), (0 if A.ws is None else A.ws.numel())
         tasks, ntasks, seg, nslices = _ptr(A.tasks), A.ntasks, A.seg, A.nslices
         nslots = A.nslots
-        if A.core is None and A.dense is None and A.strip is None:
+        if A.core is None and A.dense is None and A.strip is None and A.dense3 is None:
             fix, nfix = _ptr(A.fix), A.nfix
             def planned(B, C):
                 check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, rmap,
@@ -336,7 +356,14 @@ class HipKernels:
                                                  stream()), "pgcn_spmm_csr_plan_f32")
             return planned
         # gather part (partial sums stay in the work-space) + LDS-tiled core + MFMA tiles + one combined fix-up
-        co, de, st = A.core, A.dense, A.strip
+        co, de, st, d3 = A.core, A.dense, A.strip, A.dense3
+        if d3 is not None:
+            need3 = int(lib.pgcn_dense_bf16x3_image_bytes(d3.npanels, f))
+            if d3.image is None or d3.image.numel() < need3:
+                d3.image = torch.empty(need3, dtype=torch.uint8, device=self.device)
+                A.launch_cache.clear()          # other bindings hold the old work-space pointer
+            w3, n3, bi3, v3, pl3, np3, img3, imgb3 = (d3.work.data_ptr(), d3.npieces, d3.blk_img.data_ptr(), d3.vals3.data_ptr(),
+                                                      d3.panel_list.data_ptr(), d3.npanels, d3.image.data_ptr(), d3.image.numel())
         if st is not None:
             sw, sn, srec, spairs = st.work.data_ptr(), st.npieces, st.rec.data_ptr(), st.pairs.data_ptr()
         if co is not None:
@@ -358,6 +385,9 @@ class HipKernels:
                                                  c, ldc, f, ws, ws_n, nslots, gflags, s), "pgcn_spmm_csr_plan_f32")
             if st is not None:
                 check(lib.pgcn_spmm_strip_f32(sw, sn, srec, spairs, b, ldb, ncols, f, ws, ws_n, nst, s), "pgcn_spmm_strip_f32")
+            if d3 is not None:
+                check(lib.pgcn_spmm_dense_bf16x3_f32(w3, n3, bi3, v3, pl3, np3, b, ldb, ncols, f, img3, imgb3, ws, ws_n, nst, s),
+                      "pgcn_spmm_dense_bf16x3_f32")
             if de is not None:
                 check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s), "pgcn_spmm_dense_f32")
             if co is not None:

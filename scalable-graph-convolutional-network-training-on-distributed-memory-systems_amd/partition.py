@@ -46,12 +46,14 @@ class HostCSR:
     row_flags: Optional[torch.Tensor] = None  # uint8 [nrows]: row also receives core partial sums
     dense: Optional["HostDense"] = None       # the densest tiles, stored dense for the fp32 matrix cores
     strip: Optional["HostStrip"] = None       # entries of 512 x 128 strip tiles (LDS-staged, async pipeline)
+    dense3: Optional["HostDense3"] = None     # the densest 512 x 128 blocks, stored dense for the bf16 matrix cores (three planes)
 
     @property
     def nnz(self) -> int:
         """Stored entries of the whole block (gather part + LDS core / strips + MFMA tiles)."""
         return int(self.col.numel()) + (self.core.nnz if self.core is not None else 0) + \
-            (self.dense.nnz if self.dense is not None else 0) + (self.strip.nnz if self.strip is not None else 0)
+            (self.dense.nnz if self.dense is not None else 0) + (self.strip.nnz if self.strip is not None else 0) + \
+            (self.dense3.nnz if self.dense3 is not None else 0)
 
     def to_coo(self):
         """(row, col, val) of the whole block, core included (tests / checker only)."""
@@ -69,6 +71,9 @@ class HostCSR:
         if self.strip is not None:
             sr, sc, sv = self.strip.to_coo()
             r, c, v = torch.cat([r, sr]), torch.cat([c, sc]), torch.cat([v, sv])
+        if self.dense3 is not None:
+            dr, dc, dv = self.dense3.coo
+            r, c, v = torch.cat([r, dr]), torch.cat([c, dc]), torch.cat([v, dv])
         return r, c, v
 
 
@@ -193,6 +198,119 @@ def build_dense(r64, c64, v, tkey_local, ntiles, tile_row, tile_panel, nrows, nc
     work = np.stack([ttr[kbeg][lpt], kbeg[lpt], kcnt[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
     return HostDense(nrows, ncols, torch.from_numpy(work).to(dev), tile_row, tile_panel, vals.view(ntiles, TR * TC),
                      (r64, c64, v.to(torch.float32)))
+
+
+# ---- 512 x 128 blocks on the bf16 matrix cores (pgcn_spmm_dense_bf16x3_f32) -------------------------------------
+DENSE3_ON = _T.dense_bf16x3
+DENSE3_TAU = _T.dense3_tau
+DENSE3_PIECE = _T.dense3_piece
+DENSE3_BR = 512    # rows per block (= STRIP_TR: the two tall-tile paths share the row blocking and the 512-row slot blocks)
+
+
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> the nearest bf16 number (ties to even), returned as fp32.  Inf / NaN pass through."""
+    b = x.contiguous().view(torch.int32)
+    r = (b + 0x7FFF + ((b >> 16) & 1)) & ~0xFFFF                  # (two's-complement int32 add = the usual uint32 trick)
+    r = torch.where(torch.isfinite(x), r, b & ~0xFFFF | ((b & 0xFFFF) != 0).to(torch.int32) << 16)
+    return r.view(torch.float32)
+
+
+def bf16_split3(x: torch.Tensor):
+    """x = x1 + x2 + x3, every term a bf16 number (returned as fp32): x1 = bf16(x), x2 = bf16(x - x1),
+    x3 = bf16(x - x1 - x2) -- what the kernels do to both operands of pgcn_spmm_dense_bf16x3_f32 (split_pair in
+    csrc/pgcn_spmm_dense3.hip).  Both subtractions are exact in fp32 and the last remainder has at most 8 significant
+    bits, so the sum is EXACT for |x| >= 2^-110 (below that the lowest bits of x sit under the smallest bf16
+    denormal, 2^-133, and are rounded away)."""
+    x = x.to(torch.float32)
+    x1 = bf16_round(x)
+    r = x - x1
+    x2 = bf16_round(r)
+    x3 = bf16_round(r - x2)
+    return x1, x2, x3
+
+
+def dense3_index(i, k):
+    """Position of A[i][k] (row i of 512, column k of 128) inside a block of ``HostDense3.vals3``: the A-operand order of
+    v_mfma_f32_32x32x16_bf16 for wave w = i // 64, row block rb, k step ks --
+    vals3[block][w][unit = 2 ks + rb][h][lane = 32 (k // 8 % 2) + i % 32][e] with k = 16 ks + 8 (lane >> 5) + 4 h + e."""
+    w, rb, il = i // 64, (i // 32) % 2, i % 32
+    ks, hk, h, e = k // 16, (k // 8) % 2, (k // 4) % 2, k % 4
+    return ((((w * 16 + 2 * ks + rb) * 2 + h) * 64) + hk * 32 + il) * 4 + e
+
+
+@dataclass
+class HostDense3:
+    """The densest 512 x 128 blocks, stored DENSE in fp32 in the A-operand order of the bf16 MFMA (``dense3_index``);
+    the kernel splits the values into three bf16 planes in registers and the panels of the dense operand once per
+    SpMM into a work-space (one 96 KB image per entry of ``panel_list`` and 128 features)."""
+    nrows: int
+    ncols: int
+    work: torch.Tensor        # int32 [npieces, 4] {block row, first block, number of blocks, first slot (local)}
+    blk_row: torch.Tensor     # int32 [nblocks]
+    blk_panel: torch.Tensor   # int32 [nblocks]
+    vals3: torch.Tensor       # fp32 [nblocks, 512 * 128]
+    panel_list: torch.Tensor  # int32 [npanels] the distinct panels of the blocks, ascending
+    blk_img: torch.Tensor     # int32 [nblocks] position of a block's panel in panel_list
+    coo: tuple                # (row, col, val) of the stored entries (host-side bookkeeping / checker)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.coo[0].numel())
+
+    @property
+    def npieces(self) -> int:
+        return int(self.work.shape[0])
+
+    @property
+    def nslots(self) -> int:
+        return self.npieces * DENSE3_BR
+
+
+def build_dense3(r64, c64, v, bkey_local, nblocks, blk_row, blk_panel, nrows, ncols, piece: int = None) -> HostDense3:
+    """``bkey_local`` numbers the blocks 0..nblocks-1 in (block row, panel) order."""
+    import numpy as np
+    BR, TC = DENSE3_BR, CORE_TC
+    piece = DENSE3_PIECE if piece is None else piece
+    if piece <= 0:
+        # one workgroup per CU: ~512 pieces = two rounds over the 256 CUs (longest first); a piece writes a 512-row
+        # partial block (256 KB) whatever it holds, so no confetti: between 1 and 8 blocks
+        piece = int(min(8, max(1, -(-nblocks // 512))))
+    dev = r64.device
+    vals = torch.zeros(nblocks * BR * TC, dtype=torch.float32, device=dev)
+    vals.index_add_(0, bkey_local * (BR * TC) + dense3_index(r64 % BR, c64 % TC), v.to(torch.float32))   # duplicates add
+    brw = blk_row.cpu().numpy()
+    run_start = np.r_[True, brw[1:] != brw[:-1]]
+    pos_in_run = np.arange(nblocks) - np.maximum.accumulate(np.where(run_start, np.arange(nblocks), 0))
+    newp = run_start | (pos_in_run % max(piece, 1) == 0)
+    kbeg = np.nonzero(newp)[0]
+    kcnt = np.r_[kbeg[1:], nblocks] - kbeg
+    lpt = np.argsort(-kcnt, kind="stable")
+    work = np.stack([brw[kbeg][lpt], kbeg[lpt], kcnt[lpt], np.arange(len(kbeg)) * BR], 1).astype(np.int32)
+    plist, bimg = torch.unique(blk_panel.to(torch.int64), return_inverse=True)
+    return HostDense3(nrows, ncols, torch.from_numpy(work).to(dev), blk_row, blk_panel, vals.view(nblocks, BR * TC),
+                      plist.to(torch.int32), bimg.to(torch.int32), (r64, c64, v.to(torch.float32)))
+
+
+def split_dense3(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int, tau: float = None):
+    """Separate the entries of 512 x 128 blocks at least ``tau`` full.  Returns (keep_mask or None, HostDense3 or None)."""
+    tau = DENSE3_TAU if tau is None else tau
+    if r.numel() == 0 or tau > 1.0:
+        return None, None
+    BR, TC = DENSE3_BR, CORE_TC
+    r64, c64 = r.to(torch.int64), c.to(torch.int64)
+    ncp = (ncols + TC - 1) // TC
+    bkey = (r64 // BR) * ncp + c64 // TC
+    uniq, inv, cnt = torch.unique(bkey, return_inverse=True, return_counts=True)
+    sel = cnt >= max(1, int(tau * BR * TC))
+    nb = int(sel.sum())
+    if nb == 0:
+        return None, None
+    is3 = sel[inv]
+    bmap = torch.cumsum(sel.to(torch.int64), 0) - 1
+    bk = uniq[sel]
+    h3 = build_dense3(r64[is3], c64[is3], v[is3], bmap[inv[is3]], nb, (bk // ncp).to(torch.int32), (bk % ncp).to(torch.int32),
+                      nrows, ncols)
+    return ~is3, h3
 
 
 # ---- strip tiles (pgcn_spmm_strip_f32) ---------------------------------------------------------
@@ -451,7 +569,7 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
                  compact_rows: bool = False, nslices: Optional[int] = None, core: bool = False,
                  tau: float = None, emax: int = None, ngroups: Optional[int] = None,
                  dense_tau: float = None, slice_bounds: Optional[torch.Tensor] = None,
-                 strip: Optional[bool] = None, strip_min: Optional[int] = None) -> HostCSR:
+                 strip: Optional[bool] = None, strip_min: Optional[int] = None, dense3_tau: Optional[float] = None) -> HostCSR:
     """Sort by (row, slice, col) and build CSR.  Duplicate entries are kept as
     separate stored entries (an uncoalesced COO sums them, PGCN.py:63).  With ``core``
     the entries of dense 128 x 128 tiles are split off into a HostCore (LDS-tiled kernel).
@@ -472,11 +590,20 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
         return torch.bucketize(c64, slice_bounds[1:-1], right=True)
     G = 1 if ngroups is None else (max(1, min(64, int(ngroups))) if S > 1 else 1)
     gw = max(1, -(-ncols // G))          # columns per group
-    hcore, hdense, hstrip, row_flags = None, None, None, None
+    hcore, hdense, hstrip, hdense3, row_flags = None, None, None, None, None
     if core and not compact_rows and r.numel():
         use_strip = STRIP_ON if strip is None else strip
-        keep, hcore, hdense = split_core(r, c, v, nrows, ncols, 2.0 if use_strip else tau, emax, dense_tau)
         r0, c0, v0 = r, c, v
+        # the bf16 three-plane blocks (512 x 128) replace the fp32-MFMA tiles (128 x 128) unless a caller asks for those
+        # by passing dense_tau; dense3_tau > 1 switches them off
+        use3 = (DENSE3_ON and dense_tau is None) if dense3_tau is None else dense3_tau <= 1.0
+        if use3 and ncols >= CORE_TC:
+            keep3, hdense3 = split_dense3(r, c, v, nrows, ncols, dense3_tau)
+            if keep3 is not None:
+                r, c, v = r[keep3], c[keep3], v[keep3]
+            if dense_tau is None:
+                dense_tau = 2.0
+        keep, hcore, hdense = split_core(r, c, v, nrows, ncols, 2.0 if use_strip else tau, emax, dense_tau)
         if keep is not None:
             r, c, v = r[keep], c[keep], v[keep]
         if use_strip:
@@ -491,16 +618,17 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
                     r, c, v = r[ckeep], c[ckeep], v[ckeep]
             if skeep is not None:
                 r, c, v = r[skeep], c[skeep], v[skeep]
-        tiled = sum(h.nnz for h in (hcore, hdense, hstrip) if h is not None)
-        if tiled and tau is None and strip_min is None and (tiled < CORE_MIN_NNZ or tiled < CORE_MIN_FRAC * r0.numel()):
-            hcore = hdense = hstrip = None     # a small tiled part does not pay for the extra kernel + fix-up launches
+        tiled = sum(h.nnz for h in (hcore, hdense, hstrip, hdense3) if h is not None)
+        if tiled and tau is None and strip_min is None and dense3_tau is None and \
+                (tiled < CORE_MIN_NNZ or tiled < CORE_MIN_FRAC * r0.numel()):
+            hcore = hdense = hstrip = hdense3 = None     # a small tiled part does not pay for the extra kernel + fix-up launches
             r, c, v = r0, c0, v0
-        if hcore is not None or hdense is not None or hstrip is not None:
+        if hcore is not None or hdense is not None or hstrip is not None or hdense3 is not None:
             row_flags = torch.zeros(nrows, dtype=torch.uint8, device=dev)
-            for h, tr in ((hcore, CORE_TR), (hdense, CORE_TR), (hstrip, STRIP_TR)):
+            for h, tr in ((hcore, CORE_TR), (hdense, CORE_TR), (hstrip, STRIP_TR), (hdense3, DENSE3_BR)):
                 if h is None:
                     continue
-                trs = torch.unique((h.work[:, 0] if h is hstrip else h.tile_row).to(torch.int64))
+                trs = torch.unique((h.work[:, 0] if (h is hstrip or h is hdense3) else h.tile_row).to(torch.int64))
                 rows = (trs[:, None] * tr + torch.arange(tr, device=dev)[None, :]).reshape(-1)
                 row_flags[rows[rows < nrows]] = 1
     if r.numel():
@@ -530,19 +658,19 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     else:
         G = 1
     return HostCSR(nrows, ncols, rowptr, c.to(torch.int32).contiguous(),
-                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, G, hcore, row_flags, hdense, hstrip)
+                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, G, hcore, row_flags, hdense, hstrip, hdense3)
 
 
 def csr_from_scipy(A, nslices: Optional[int] = None, core: bool = False, tau: float = None,
                    emax: int = None, ngroups: Optional[int] = None, dense_tau: float = None,
-                   strip: Optional[bool] = None, strip_min: Optional[int] = None) -> HostCSR:
+                   strip: Optional[bool] = None, strip_min: Optional[int] = None, dense3_tau: Optional[float] = None) -> HostCSR:
     """Convenience for tests / tools: a scipy sparse matrix -> HostCSR (optionally sliced)."""
     import numpy as np
     A = A.tocoo()
     return csr_from_coo(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
                         torch.from_numpy(A.data.astype(np.float32)), A.shape[0], A.shape[1],
                         nslices=nslices, core=core, tau=tau, emax=emax, ngroups=ngroups, dense_tau=dense_tau,
-                        strip=strip, strip_min=strip_min)
+                        strip=strip, strip_min=strip_min, dense3_tau=dense3_tau)
 
 
 @dataclass

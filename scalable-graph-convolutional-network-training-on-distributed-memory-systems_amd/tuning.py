@@ -35,9 +35,13 @@ class Tuning:
     core_min_nnz: int = 2000000      # a smaller tiled part does not pay for its three extra launches (r03: the 1.7 M-entry
                                      # local block of an 8-way shard runs 0.067 ms gather-only, 0.099 ms tiled)
     core_min_frac: float = 0.1
-    dense: bool = True               # fp32-MFMA tiles
+    dense: bool = True               # fp32-MFMA tiles (128 x 128; only where dense_bf16x3 is off)
     dense_tau: float = 0.30          # tiles at least this full go to the matrix cores
     dense_piece: int = 0             # tiles per MFMA piece (0 = adaptive)
+    dense_bf16x3: bool = True        # r04: 512 x 128 blocks on the bf16 matrix cores at fp32 accuracy (three-plane split, six
+                                     # products) instead of the fp32-MFMA tiles
+    dense3_tau: float = 0.16         # blocks at least this full (of 65 536) take that path
+    dense3_piece: int = 0            # blocks per piece (0 = adaptive: ~512 pieces, between 1 and 8 blocks)
     strip: bool = True               # 512 x 128 strip tiles
     strip_min: int = 512             # stored entries that make a strip tile worth staging
     strip_layer_min: int = 384       # stored entries that make one more layer (record) of a tile worth it

@@ -64,7 +64,7 @@ def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None):
         o = out_row(r)
         C[o] = (C[o] + s) if accumulate else s
 
-    tiled = d.core is not None or d.dense is not None or d.strip is not None
+    tiled = d.core is not None or d.dense is not None or d.strip is not None or getattr(d, "dense3", None) is not None
     # ---- gather part -----------------------------------------------------------------------------------------
     if d.tasks is None:                                  # one task per row, no plan (pgcn_spmm_csr_f32)
         for r in range(d.nrows):
@@ -179,6 +179,26 @@ def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None):
                 info["entries_dense"] += int((tile != 0).sum())
             assert np.isnan(ws[slot0:slot0 + TR]).all()
             ws[slot0:slot0 + TR] = acc
+    # ---- bf16 three-plane blocks (pgcn_spmm_dense_bf16x3_f32): 512 x 128, A-operand order of v_mfma_f32_32x32x16_bf16 ----
+    if getattr(d, "dense3", None) is not None:
+        BR = part.DENSE3_BR
+        d3 = d.dense3
+        work, bimg, plist, vals = _np(d3.work), _np(d3.blk_img), _np(d3.panel_list), _np(d3.vals3).astype(np.float64)
+        assert (np.diff(plist) > 0).all() and bimg.max() < plist.size
+        i, k = np.meshgrid(np.arange(BR), np.arange(128), indexing="ij")
+        idx = part.dense3_index(i, k)
+        for br, first, cnt, slot0 in work:
+            acc = np.zeros((BR, f))
+            for t in range(first, first + cnt):
+                blk = vals[t][idx]                                         # [row in block, column in panel]
+                c0 = int(plist[bimg[t]]) * 128
+                w = min(128, d.ncols - c0)
+                assert w > 0 and not blk[:, w:].any(), "values beyond the last column of the block"
+                assert not blk[max(0, d.nrows - int(br) * BR):].any(), "values beyond the last row of the block"
+                acc += blk[:, :w] @ B[c0:c0 + w]
+                info["entries_dense"] += int((blk != 0).sum())
+            assert np.isnan(ws[slot0:slot0 + BR]).all()
+            ws[slot0:slot0 + BR] = acc
     # ---- fix-up: a row's partial sums in the fixed order of its slot list ------------------------------------
     if tiled:
         fix, slots = _np(d.fix_all).astype(np.int64), _np(d.slot_ids).astype(np.int64)

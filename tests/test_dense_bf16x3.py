@@ -1,24 +1,15 @@
-"""Host side of the bf16 three-plane MFMA tiles (tools/experiments/dense3, prepared and harness-measured in r03,
-not in the library yet): the exact three-way split, the A-operand plane layout built from the product's own MFMA
-tile image, the arithmetic of the six-product scheme emulated in numpy (every partial product exact in fp32, fp32
-accumulation) against float64, and that integrate.patch -- the wiring into partition.py / kernels.py / the C ABI --
-still applies to the tree.  The kernel itself ran on the MI355X through tools/experiments/dense3/dense3_bench.cpp
-(profiles/r03_dense3_bench.txt), whose C++ layout builder follows the same formula as the test below."""
-import importlib.util
-import os
-import subprocess
-
+"""Host side of the bf16 three-plane MFMA blocks (pgcn_spmm_dense_bf16x3_f32, csrc/pgcn_spmm_dense3.hip): the exact
+three-way split the kernels apply to both operands (partition.bf16_split3 restates split_pair), the A-operand block
+layout (partition.dense3_index / HostDense3.vals3) and the arithmetic of the six-product scheme emulated in numpy
+(every partial product exact in fp32, fp32 accumulation) against float64.  The kernel itself is held to the oracle by
+tests/test_hip_gpu.py::test_spmm_bf16x3_blocks and measured by tools/micro/dense3_bench.cpp."""
 import numpy as np
 import scipy.sparse as sp
 import torch
 
 from conftest import pkg
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXP = os.path.join(ROOT, "tools", "experiments", "dense3")
-_spec = importlib.util.spec_from_file_location("dense3_planes", os.path.join(EXP, "planes.py"))
-planes_mod = importlib.util.module_from_spec(_spec)
-_spec.loader.exec_module(planes_mod)
+planes_mod = pkg("partition")
 
 
 def _is_bf16(x: np.ndarray) -> bool:
@@ -56,42 +47,43 @@ def test_split_is_exact_and_every_term_is_bf16():
     assert torch.isinf(r[0]) and r[0] > 0 and torch.isinf(r[1]) and r[1] < 0 and torch.isnan(r[2])
 
 
-def test_planes_are_the_a_operand_order_of_the_bf16_mfma():
-    """planes[t][w][ks][p][lane][j] = bf16 plane p of A[32 w + (lane & 31)][16 ks + 8 (lane >> 5) + j]."""
+def test_blocks_are_stored_in_the_a_operand_order_of_the_bf16_mfma():
+    """vals3[b][w][unit = 2 ks + rb][h][lane][e] = A[64 w + 32 rb + (lane & 31)][16 ks + 8 (lane >> 5) + 4 h + e] of block b;
+    blocks below the fill threshold and whatever the blocks do not hold stay in the other parts; the panel list is
+    the sorted set of the blocks' column blocks."""
     partition = pkg("partition")
     rng = np.random.default_rng(3)
-    n, m = 300, 384
-    D = ((rng.random((n, m)) < 0.5) * rng.standard_normal((n, m))).astype(np.float32)
-    h = partition.csr_from_scipy(sp.coo_matrix(D), nslices=1, core=True, tau=0.05, dense_tau=0.2, strip=False)
-    hd = h.dense
-    assert hd is not None
-    nt = hd.tile_row.numel()
-    planes = planes_mod.dense_planes(hd.vals)                                    # from the product's own fp32 tile image
-    assert tuple(planes.shape) == (nt, 4, 8, 3, 64, 8) and planes.dtype == torch.int16
-    pl = planes.numpy().view(np.uint16).astype(np.uint32) << 16
-    pl = pl.view(np.float32)                                                     # the planes as fp32 numbers
-    Dp = np.zeros((384, 384), np.float32); Dp[:n, :m] = D
-    i, k = np.meshgrid(np.arange(128), np.arange(128), indexing="ij")
-    w, il, ks, hk, j = i // 32, i % 32, k // 16, (k // 8) % 2, k % 8
-    for t in range(nt):
-        tr, tp = int(hd.tile_row[t]), int(hd.tile_panel[t])
-        tile = Dp[tr * 128:(tr + 1) * 128, tp * 128:(tp + 1) * 128]
-        terms = [pl[t][w, ks, p, 32 * hk + il, j] for p in range(3)]
-        np.testing.assert_array_equal(terms[0].astype(np.float64) + terms[1] + terms[2], tile.astype(np.float64))
-        x1, x2, x3 = (x.numpy() for x in planes_mod.bf16_split3(torch.from_numpy(tile.copy())))
-        np.testing.assert_array_equal(terms[0], x1)
-        np.testing.assert_array_equal(terms[1], x2)
-        np.testing.assert_array_equal(terms[2], x3)
-
-
-def test_integration_patch_applies():
-    """integrate.patch = the edits that put the kernel into the library behind tuning.dense_bf16x3 (header entry,
-    build.sh, ctypes signature, HostDense.planes, the dispatch in kernels.py): it must keep applying to the tree."""
-    if not os.path.isdir(os.path.join(ROOT, ".git")):
-        import pytest
-        pytest.skip("not a git checkout (a gpurun snapshot)")
-    out = subprocess.run(["git", "apply", "--check", os.path.join(EXP, "integrate.patch")], cwd=ROOT, capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr
+    n, m = 1100, 700
+    D = ((rng.random((n, m)) < 0.3) * rng.standard_normal((n, m))).astype(np.float32)
+    D[600:, 300:] *= rng.random((500, 400)) < 0.1
+    h = partition.csr_from_scipy(sp.coo_matrix(D), nslices=1, core=True, strip=True, strip_min=32, dense3_tau=0.2)
+    hd = h.dense3
+    assert hd is not None and h.dense is None and h.nnz == int((D != 0).sum())
+    nb = hd.vals3.shape[0]
+    assert tuple(hd.vals3.shape) == (nb, 512 * 128) and hd.vals3.dtype == torch.float32
+    Dp = np.zeros((1536, 768), np.float32); Dp[:n, :m] = D
+    i, k = np.meshgrid(np.arange(512), np.arange(128), indexing="ij")
+    idx = partition.dense3_index(i, k)
+    assert np.array_equal(np.sort(idx.ravel()), np.arange(512 * 128))                       # a permutation of the block
+    w, rb, il, ks, hk, hh, e = i // 64, (i // 32) % 2, i % 32, k // 16, (k // 8) % 2, (k // 4) % 2, k % 4
+    assert np.array_equal(idx, ((((w * 16 + 2 * ks + rb) * 2 + hh) * 64) + 32 * hk + il) * 4 + e)
+    held = np.zeros_like(Dp, dtype=bool)
+    for b in range(nb):
+        br, bp = int(hd.blk_row[b]), int(hd.blk_panel[b])
+        blk = Dp[br * 512:(br + 1) * 512, bp * 128:(bp + 1) * 128]
+        np.testing.assert_array_equal(hd.vals3[b].numpy()[idx], blk)
+        assert (blk != 0).sum() >= 0.2 * 512 * 128
+        held[br * 512:(br + 1) * 512, bp * 128:(bp + 1) * 128] = True
+        assert int(hd.panel_list[hd.blk_img[b]]) == bp
+    assert torch.equal(hd.panel_list, torch.unique(hd.blk_panel)) and nb >= 5
+    r, c, v = hd.coo
+    assert held[r.numpy(), c.numpy()].all() and r.numel() == int(((Dp != 0) & held).sum())
+    # pieces: runs of blocks of ONE block row, every block in exactly one piece, 512 slot rows per piece
+    seen = np.zeros(nb, np.int32)
+    for br, first, cnt, slot0 in hd.work.numpy():
+        assert (hd.blk_row[first:first + cnt].numpy() == br).all() and slot0 % 512 == 0
+        seen[first:first + cnt] += 1
+    assert (seen == 1).all() and hd.nslots == hd.npieces * 512
 
 
 def test_six_products_reach_fp32_accuracy():

@@ -220,6 +220,68 @@ def test_spmm_mfma_dense_tiles(K, dev, f, nslices):
     assert rel_err(got[:, 1:], ref[:, 1:]) < TOL
 
 
+@pytest.mark.parametrize("f", [4, 30, 64, 100, 128, 132, 256])
+@pytest.mark.parametrize("nslices", [1, 8])
+def test_spmm_bf16x3_blocks(K, dev, f, nslices):
+    """The densest 512 x 128 blocks go through the bf16 matrix cores with the three-plane split
+    (pgcn_spmm_dense_bf16x3_f32), the rest through strips / the gather kernel; one fix-up.  Same tolerance as every
+    other SpMM path -- and the per-row bound against float64 (the split is fp32-accurate, not bf16-accurate), bit-equal
+    repeats, accumulate, an unaligned operand, structural zeros under Inf, a partial last panel and block row."""
+    partition = pkg("partition")
+    rng = np.random.default_rng(300 + f + nslices)
+    n, m = 1300, 700                                         # 3 block rows (the last one 276 rows), 6 panels (the last one 60 columns)
+    D = (rng.random((n, m)) < 0.004).astype(np.float32)
+    D[:512, :384] = rng.random((512, 384)) < 0.45            # three full blocks in block row 0
+    D[512:1024, :128] = rng.random((512, 128)) < 0.25        # one in block row 1
+    D[1024:, 640:] = rng.random((276, 60)) < 0.9             # the partial corner block: 276 x 60 of 512 x 128 = 23 % full
+    D[5, :] = 0                                              # an empty row inside a block
+    D[:, 300] = 0                                            # a column nobody references
+    D *= (rng.standard_normal((n, m)) * np.exp(rng.standard_normal((n, 1)))).astype(np.float32)      # rows of different scale
+    A = sp.csr_matrix(D)
+    h = partition.csr_from_scipy(A, nslices=nslices, core=True, strip=True, strip_min=32, dense3_tau=0.2)
+    assert h.dense3 is not None and h.dense3.blk_row.tolist() == [0, 0, 0, 1, 2] and h.dense is None and h.nnz == A.nnz
+    d = K.prepare(h)
+    assert d.dense3 is not None and d.nslots_total >= d.nslots + h.dense3.nslots
+    B = (rng.random((m, f), dtype=np.float32) * 2 - 1) * np.exp(rng.standard_normal((m, 1))).astype(np.float32)
+    ref = oracle.spmm(A, B)
+    Bd = torch.from_numpy(B).to(dev)
+    C = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, Bd, C)
+    torch.cuda.synchronize()
+    got = C.cpu().numpy()
+    assert rel_err(got, ref) < TOL
+    ref64 = A.astype(np.float64) @ B.astype(np.float64)
+    bound = abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    worst = float((np.abs(got - ref64) / (1e-5 * bound + 1e-30)).max())
+    assert worst <= 1.0, "a row exceeds 1e-5 * sum|a||x| by a factor %.3g" % worst
+    C2 = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, Bd, C2)
+    assert torch.equal(C, C2)                                # deterministic
+    base = rng.random((n, f), dtype=np.float32)
+    C3 = torch.from_numpy(base).to(dev)
+    K.spmm(d, Bd, C3, accumulate=True)
+    assert rel_err(C3.cpu().numpy(), ref + base) < TOL
+    wide = torch.zeros((m, f + 3), device=dev)               # an odd leading dimension / unaligned base
+    wide[:, 1:f + 1] = Bd
+    C4 = torch.full((n, f), float("nan"), device=dev)
+    K.spmm(d, wide[:, 1:f + 1], C4)
+    assert rel_err(C4.cpu().numpy(), ref) < TOL
+    # Inf in a feature row no entry references: nothing leaks.  Inf in a referenced row: exactly the rows with an
+    # entry in that column see it (the exact path multiplies only where A != 0).
+    B2 = B.copy(); B2[300] = np.inf
+    C5 = torch.empty((n, f), device=dev)
+    K.spmm(d, torch.from_numpy(B2).to(dev), C5)
+    assert np.isfinite(C5.cpu().numpy()).all() and rel_err(C5.cpu().numpy(), ref) < TOL
+    B3 = B.copy(); B3[17, 0] = np.inf
+    C6 = torch.empty((n, f), device=dev)
+    K.spmm(d, torch.from_numpy(B3).to(dev), C6)
+    got = C6.cpu().numpy()
+    hit = np.asarray(A[:, 17].todense()).ravel() != 0
+    assert hit.sum() > 100                                   # column 17 crosses the blocks
+    assert np.isinf(got[hit, 0]).all() and np.isfinite(got[~hit]).all() and np.isfinite(got[:, 1:]).all()
+    assert rel_err(got[:, 1:], ref[:, 1:]) < TOL
+
+
 @pytest.mark.parametrize("f", [4, 30, 64, 128, 132, 256])
 @pytest.mark.parametrize("nslices", [1, 8])
 def test_spmm_strip_tiles(K, dev, f, nslices):

@@ -35,6 +35,7 @@ def _power_law_block(n=3000, nnz=300000, seed=4):
 VARIANTS = {
     # name: (csr_from_coo arguments, planner arguments, parts that must be present)
     "strips+mfma": (dict(nslices=8, core=True, strip=True, strip_min=64, dense_tau=0.2), {}, ("strip", "dense")),
+    "strips+bf16x3": (dict(nslices=8, core=True, strip=True, strip_min=64, dense3_tau=0.12), {}, ("strip", "dense3")),
     "strips_only": (dict(nslices=8, core=True, strip=True, strip_min=64, dense_tau=2.0), {}, ("strip",)),
     "core+mfma": (dict(nslices=8, core=True, strip=False, tau=0.05, emax=5000, dense_tau=0.3), {}, ("core", "dense")),
     "gather_sliced": (dict(nslices=8, core=False), {}, ()),
@@ -42,7 +43,7 @@ VARIANTS = {
     "gather_unsliced_long_rows": (dict(nslices=1, core=False), dict(chunk=128, adaptive_chunk=False), ()),
     "gather_column_groups": (dict(nslices=8, core=False, ngroups=4), {}, ()),
     "range_slices": (dict(core=True, strip=True, strip_min=64, slice_bounds=[0, 40, 100, 250, 600, 1100, 1700, 2400, 3000]), {},
-                     ("strip", "dense")),
+                     ("strip", "dense3")),
 }
 
 
@@ -52,7 +53,7 @@ def test_launch_group_plan_reproduces_the_product(name):
     kw, pk, parts = VARIANTS[name]
     n, r, c, val, A = _power_law_block()
     h = partition.csr_from_coo(r, c, val, n, n, **kw)
-    for p in ("strip", "core", "dense"):
+    for p in ("strip", "core", "dense", "dense3"):
         assert (getattr(h, p) is not None) == (p in parts), "variant %s: part %s" % (name, p)
     assert h.nnz == A.nnz
     d = HostPlanner(**pk).prepare(h)
@@ -260,14 +261,14 @@ def test_default_tuning_on_a_dense_graph_reaches_every_tile_path():
     pt = partition.build_partition(row, col, val, n, torch.zeros(n, dtype=torch.int64), 0, 1)
     own = pt.owned.numpy()
     for blk, ref in ((pt.A_loc, AH), (pt.A_loc_T, ATH)):
-        assert blk.strip is not None and blk.dense is not None and blk.col.numel() > 0 and blk.nnz == A.nnz
-        assert blk.strip.nnz > 0.3 * A.nnz and blk.dense.nnz > 0.2 * A.nnz
+        assert blk.strip is not None and blk.dense3 is not None and blk.dense is None and blk.col.numel() > 0 and blk.nnz == A.nnz
+        assert blk.strip.nnz > 0.2 * A.nnz and blk.dense3.nnz > 0.2 * A.nnz
         C, info = run_plan(K.prepare(blk), H[own])
         assert np.abs(C - ref[own]).max() < TOL
     pt = partition.build_partition(row, col, val, n, synth.random_partvec(n, 4, seed=0), 1, 4)
     own, hg = pt.owned.numpy(), pt.halo_global.numpy()
-    assert pt.A_loc.strip is None and pt.A_loc.core is None and pt.A_loc.dense is None          # a small block: gather only
-    assert any(a.core is not None or a.dense is not None or a.strip is not None for a in pt.A_halo)
+    assert pt.A_loc.strip is None and pt.A_loc.core is None and pt.A_loc.dense is None and pt.A_loc.dense3 is None          # a small block: gather only
+    assert any(a.core is not None or a.dense3 is not None or a.strip is not None for a in pt.A_halo)
     C, _ = run_plan(K.prepare(pt.A_loc), H[own])
     for a in pt.A_halo:
         C, _ = run_plan(K.prepare(a), H[hg], C0=C, accumulate=True)
@@ -275,8 +276,9 @@ def test_default_tuning_on_a_dense_graph_reaches_every_tile_path():
 
 
 @pytest.mark.parametrize("tuning,parts1,parts3,rounds3", [
-    ("core_min_nnz=0,core_min_frac=0,strip_min_records=0,exchange_rounds=3", "sd", "sd", 3),     # strips + MFMA tiles on a shard too
-    ("strip=0,core_min_nnz=0,core_emax=500,exchange_rounds=1", "cd", "cd", 1),                   # LDS core with short pieces
+    ("core_min_nnz=0,core_min_frac=0,strip_min_records=0,exchange_rounds=3", "s3", "s3", 3),     # strips + bf16 blocks on a shard too
+    ("dense_bf16x3=0,core_min_nnz=0,core_min_frac=0,strip_min_records=0", "sd", "sd", 2),        # the fp32-MFMA tiles instead
+    ("strip=0,dense_bf16x3=0,core_min_nnz=0,core_emax=500,exchange_rounds=1", "cd", "cd", 1),    # LDS core with short pieces
     ("tiles=0,slices=1,spmm_chunk=64,spmm_adaptive_chunk=0", "-", "-", 2),                       # gather only, unsliced, short tasks
 ])
 def test_non_default_tunings_keep_the_plans_exact(tuning, parts1, parts3, rounds3):
