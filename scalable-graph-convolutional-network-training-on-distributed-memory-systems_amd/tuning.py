@@ -40,7 +40,8 @@ class Tuning:
     dense_piece: int = 0             # tiles per MFMA piece (0 = adaptive)
     dense_bf16x3: bool = True        # r04: 512 x 128 blocks on the bf16 matrix cores at fp32 accuracy (three-plane split, six
                                      # products) instead of the fp32-MFMA tiles
-    dense3_tau: float = 0.16         # blocks at least this full (of 65 536) take that path
+    dense3_tau: float = 0.20         # blocks at least this full (of 65 536) take that path (r04 sweep on the benchmark graph,
+                                     # SpMM launch group: off 1.742 ms, 0.12 1.724, 0.16 1.728, 0.20 1.685, 0.26 1.796)
     dense3_piece: int = 0            # blocks per piece (0 = adaptive: ~512 pieces, between 1 and 8 blocks)
     strip: bool = True               # 512 x 128 strip tiles
     strip_min: int = 512             # stored entries that make a strip tile worth staging
