@@ -479,6 +479,49 @@ def pgcn_train_np(A: sp.spmatrix, part: Sequence[int], P: int, weights: List[np.
     return np.array(losses), Ws
 
 
+def pgcn_epochs_f32(csr, csr_t, weights: List[np.ndarray], H0: np.ndarray, labels: np.ndarray, epochs: int,
+                    lr: float = 1e-3):
+    """The epoch of GPU/PGCN.py:run() 212-220 at P = 1 in fp32 on the host cores, for bench.py's `cpu_baseline` leg:
+    per layer  AH = A.H (OpenMP CSR SpMM of pgcn_oracle.c), Z = AH.W^T, H = relu(Z)  (PGCN.forward :144-148);
+    log_softmax + nll_loss (:213-214); the backward pass with A^T (PSpMM.backward :130-134), the three GEMMs of every
+    layer and torch.optim.Adam's defaults (:200).  The same arithmetic as pgcn_train_np (the float64 shadow the GPU
+    tests use), organised for speed: BLAS GEMMs (numpy), in-place element-wise passes.  ``csr`` / ``csr_t``:
+    (rowptr int64, col int32, val fp32) of A and A^T.  Returns (losses, seconds per epoch)."""
+    import time
+    n, f = H0.shape
+    Ws = [np.array(w, dtype=np.float32) for w in weights]
+    opt = _Adam(Ws, lr)
+    H0 = np.ascontiguousarray(H0, dtype=np.float32)
+    rows = np.arange(n)
+    losses, secs = [], []
+    for _ in range(epochs):
+        t0 = time.time()
+        acts, agg = [H0], []
+        for W in Ws:
+            AH = spmm_csr(*csr, acts[-1])
+            agg.append(AH)
+            Z = AH @ W.T
+            np.maximum(Z, 0, out=Z)
+            acts.append(Z)                                   # relu(Z); Z > 0 <=> relu(Z) > 0 for the backward mask
+        logits = acts[-1]
+        m = logits.max(axis=1, keepdims=True)
+        z = logits - m
+        np.exp(z, out=z)
+        ssum = z.sum(axis=1, keepdims=True)
+        losses.append(float((np.log(ssum[:, 0]) + m[:, 0] - logits[rows, labels]).mean()))
+        g = z / ssum                                         # softmax
+        g[rows, labels] -= 1
+        g *= np.float32(1.0 / n)
+        grads = [None] * len(Ws)
+        for l in range(len(Ws) - 1, -1, -1):
+            g *= acts[l + 1] > 0
+            grads[l] = g.T @ agg[l]
+            g = spmm_csr(*csr_t, g @ Ws[l])
+        opt.step(grads)
+        secs.append(time.time() - t0)
+    return losses, secs
+
+
 # ---------------------------------------------------------------------------------------------
 # GAT path (GPU/PGAT.py) -- numpy restatement, vectorised per row segment (no C code: the dense
 # reference is a few matmuls; this sparse restatement is pinned to it by tests/golden/ref_gat_*).

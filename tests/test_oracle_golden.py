@@ -125,3 +125,20 @@ def test_pargcn_c_vs_float64_shadow():
     assert st1.sum() == 0
     assert st3[:, 0].sum() == rows * (16 + 16 + 2 + 16) * 3
     assert st3[:, 1].sum() == 6 * 4 * 3
+
+
+def test_fast_fp32_epoch_is_the_float64_shadow():
+    """oracle.pgcn_epochs_f32 (bench.py's cpu_baseline leg: the GPU line's own epoch on the host cores, fp32, OpenMP SpMM +
+    BLAS GEMMs) against pgcn_train_np, the float64 shadow the GPU tests hold run() to."""
+    import scipy.sparse as sp
+    from scipy.io import mmread
+    from conftest import gpath, rel_err
+    A = sp.csr_matrix(mmread(gpath("cora.A.mtx"))).astype(np.float32)
+    n, f = A.shape[0], 16
+    rng = np.random.default_rng(0)
+    w0 = [(rng.random((f, f), dtype=np.float32) - 0.5) * 0.5 for _ in range(3)]
+    H0 = np.repeat(np.arange(n, dtype=np.float32)[:, None], f, axis=1) / n
+    lab = np.arange(n) % f
+    l64, _ = oracle.pgcn_train_np(A, [0] * n, 1, w0, H0, lab, epochs=4)
+    l32, secs = oracle.pgcn_epochs_f32(oracle._csr_arrays(A), oracle._csr_arrays(sp.csr_matrix(A.T)), w0, H0, lab, 4)
+    assert len(secs) == 4 and rel_err(l32, l64) < 1e-6
