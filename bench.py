@@ -316,9 +316,12 @@ def acquire_partition(args, rank, world, dev, stage, with_transpose=True):
         n = int(sh["n"])
         if args.partvec in ("random", "block"):
             cand = "%s.%d.bp" % (args.shards, parts)          # tools/make_shards.py writes the block vector it used
-            if not os.path.exists(cand):
+            if os.path.exists(cand):
+                args.partvec = cand
+            elif os.path.exists(args.shards + ".degree.npy"):
+                args.partvec = "block"                        # --only-rank shards: contiguous blocks, computed (no 111 M-id text file)
+            else:
                 sys.exit("--shards needs the part vector the shards were cut with (--partvec FILE or %s)" % cand)
-            args.partvec = cand
         partvec, pname = read_partvec_arg(args, n, parts, synth, partition)
         if sh["nparts"] != parts or sh["rank"] != prank:
             sys.exit("%s was written for rank %d of %d, this is rank %d of %d" % (path, sh["rank"], sh["nparts"], prank, parts))
@@ -331,7 +334,19 @@ def acquire_partition(args, rank, world, dev, stage, with_transpose=True):
         if world > 1:
             part = partition.build_partition_local(row, col, val, n, partvec, prank, parts, with_transpose=with_transpose)
         elif parts > 1:
-            sys.exit("--emulate-rank with --shards needs the other ranks' degrees: use a synthetic workload or --mtx")
+            # one process stands in for rank prank: what the two collectives of build_partition_local would have brought comes
+            # from the side files of tools/make_shards.py --only-rank (global degree vector; symmetric pattern)
+            dfile = args.shards + ".degree.npy"
+            if not os.path.exists(dfile):
+                sys.exit("--emulate-rank with --shards needs %s (tools/make_shards.py --only-rank)" % dfile)
+            deg = torch.from_numpy(np.load(dfile).astype(np.int64)).to(dev)
+            meta = {}
+            if os.path.exists(args.shards + ".meta.json"):
+                with open(args.shards + ".meta.json") as fh:
+                    meta = json.load(fh)
+            part = partition.build_partition_local(row, col, val, n, partvec, prank, parts, with_transpose=with_transpose,
+                                                   emulate={"gdeg": 2 * deg, "nnz_global": meta.get("nnz_global", int(row.numel()))})
+            del deg
         else:
             part = partition.build_partition(row, col, val, n, partvec, 0, 1, with_transpose=with_transpose)
         info = {"n": n, "nnz": int(part.nnz_global), "partition": pname, "data": "synthetic (shards)" if not args.real else "real",
@@ -403,11 +418,75 @@ def pmc_traffic_for(args, world, f, block="loc"):
     return None, note
 
 
-def graph_replay(model, make_model, H, labels, n, P, steps, dev, eager_ms):
-    """Capture ONE training step (forward, loss, backward, Adam) in a HIP graph and time `steps` replays.  The C-ABI
-    library never allocates or synchronises and the engine orders its streams with events only, so the whole step --
-    ~80 launches on a whole graph, ~150 on a shard with its halo groups -- is capturable; a replay has no host-side
-    enqueue cost.  Eager timing stays the headline `value` (it carries the live per-kernel events)."""
+def multirank_selftest(rank, world, dev, kernels, exch, n=8192, nnz=400000, f=32):
+    """First-contact check of an N-rank job, BEFORE anything is timed: a small synthetic graph (same seed on every rank)
+    is cut with a random part vector, every rank runs the aggregation forward and backward through its real engine and
+    the real boundary exchange (two rounds, non-empty segments to every peer), and rank 0 compares the gathered rows
+    with the SAME kernels run on the whole graph as one rank (no exchange): what differs is exactly the multi-rank
+    path -- packed rows, slab order, halo products, the reverse exchange with accumulation.  Every wait has a
+    deadline (engine._wait_or_die).  Returns a record for the JSON line; raises on a mismatch (every rank)."""
+    synth, partition, engine = pkg("synth"), pkg("partition"), pkg("engine")
+    cpu = dev.type != "cuda"
+    n, row, col, val = synth.make_graph(n, nnz, seed=11, device="cpu")
+    pv = synth.random_partvec(n, world, seed=5)
+    part = partition.build_partition(row, col, val, n, pv, rank, world)
+    eng = engine.AggregationEngine(part, kernels, dev, exch)
+    g = torch.Generator()
+    g.manual_seed(77)
+    Hfull = torch.rand(n, f, generator=g) * 2 - 1
+    Gfull = torch.rand(n, f, generator=g) * 2 - 1
+    own = part.owned
+    fwd = eng.forward(Hfull[own].to(dev))
+    bwd = eng.backward(Gfull[own].to(dev))
+    if not cpu:
+        engine._wait_or_die(dev, "the %d-rank forward / backward aggregation of the self-test" % world)
+    mine = {"own": own.numpy(), "fwd": fwd.cpu().numpy(), "bwd": bwd.cpu().numpy()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    rec = {"ranks": world, "n": n, "nnz": int(row.numel()), "f": f, "rounds": eng.rounds, "exchange": getattr(exch, "name", "?"),
+           "exchanger_selftest": getattr(exch, "selftest", None), "boundary_rows_this_rank": int(part.n_send)}
+    verdict = [1.0, 0.0, 0.0]
+    if rank == 0:
+        one = partition.build_partition(row, col, val, n, torch.zeros(n, dtype=torch.int64), 0, 1)
+        e1 = engine.AggregationEngine(one, kernels, dev, None)
+        o1 = one.owned
+        ref_f = np.zeros((n, f), np.float32)
+        ref_b = np.zeros((n, f), np.float32)
+        ref_f[o1.numpy()] = e1.forward(Hfull[o1].to(dev)).cpu().numpy()
+        ref_b[o1.numpy()] = e1.backward(Gfull[o1].to(dev)).cpu().numpy()
+        got_f, got_b = np.full((n, f), np.nan, np.float32), np.full((n, f), np.nan, np.float32)
+        for r in everyone:
+            got_f[r["own"]], got_b[r["own"]] = r["fwd"], r["bwd"]
+        ef = float(np.abs(got_f - ref_f).max() / max(np.abs(ref_f).max(), 1e-30))
+        eb = float(np.abs(got_b - ref_b).max() / max(np.abs(ref_b).max(), 1e-30))
+        verdict = [1.0 if (ef < 1e-5 and eb < 1e-5) else 0.0, ef, eb]        # (NaN = a row nobody delivered: fails)
+    box = [verdict]
+    dist.broadcast_object_list(box, src=0)
+    rec["forward_rel_err_vs_one_rank"], rec["backward_rel_err_vs_one_rank"] = box[0][1], box[0][2]
+    if box[0][0] != 1.0:
+        raise RuntimeError("multi-rank self-test FAILED: %s" % json.dumps(rec))
+    return rec
+
+
+def graph_replay(model, make_model, H, labels, n, P, steps, dev, eager_ms, world=1):
+    """Capture ONE training step (forward, loss, backward, gradient all-reduce, Adam) in a HIP graph and time `steps`
+    replays.  The C-ABI library never allocates or synchronises and the engine orders its streams with events only, so
+    the whole step -- ~80 launches on a whole graph, ~150 on a shard with its halo groups, the RCCL calls of the
+    exchange and of average_gradients included (RCCL records grouped send / recv and all-reduce into a capturing
+    stream) -- is capturable; a replay has no host-side enqueue cost.  Eager timing stays the headline `value` (it
+    carries the live per-kernel events).  N > 1: every rank must have captured, or nobody replays; the replays are
+    waited for with a deadline."""
+    engine = pkg("engine")
+
+    voted = [False]
+
+    def all_agree(ok):
+        voted[0] = True
+        if world == 1:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], device=dev)
+        P._all_reduce(t, dist.ReduceOp.MIN)
+        return float(t) == 1.0
     try:
         # fresh leaves: the AccumulateGrad nodes of the eager run's parameters are bound to the default stream, which
         # must not be touched during a capture
@@ -427,23 +506,40 @@ def graph_replay(model, make_model, H, labels, n, P, steps, dev, eager_ms):
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g):
-            loss = P.local_loss(model(H), labels, n)
-            loss.backward()
-            opt.step()
+        err = None
+        try:
+            with torch.cuda.graph(g):
+                loss = P.local_loss(model(H), labels, n)
+                loss.backward()
+                P.average_gradients(model)
+                opt.step()
+        except Exception as e:
+            err = repr(e)[:300]
+        if not all_agree(err is None):
+            return {"captured": False, "error": err or "another rank could not capture"}
         torch.cuda.synchronize(dev)
         for _ in range(2):
             g.replay()
-        torch.cuda.synchronize(dev)
+        engine._wait_or_die(dev, "the first replays of the captured %d-rank training step" % world)
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             g.replay()
         t_host = time.perf_counter() - t0
         torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
         t_all = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([t_all], dtype=torch.float64, device=dev)
+            P._all_reduce(t, dist.ReduceOp.MAX)
+            t_all = float(t)
         return {"captured": True, "ms_per_step": 1e3 * t_all / steps, "host_enqueue_ms_per_step": 1e3 * t_host / steps,
-                "eager_ms_per_step": eager_ms, "loss": float(loss)}
+                "eager_ms_per_step": eager_ms, "loss": float(loss), "ranks": world}
     except Exception as e:                                 # a capture problem must not cost the eager line
+        if not voted[0]:                                   # (the others wait in the vote)
+            all_agree(False)
         return {"captured": False, "error": repr(e)[:300]}
 
 
@@ -634,9 +730,11 @@ def main():
                          "rows; the part vector is --partvec FILE or PREFIX.<N>.bp")
     ap.add_argument("--mtx", default=None, help="a MatrixMarket adjacency file (like PGCN.py -a) instead of the synthetic graph")
     ap.add_argument("--real", action="store_true", help="label the --shards / --mtx input as real data in the JSON line")
+    ap.add_argument("--no-selftest", action="store_true",
+                    help="N > 1: skip the small-graph check of the multi-rank path that runs before the timed region")
     ap.add_argument("--graph", action="store_true",
-                    help="after the timed (eager) region: capture ONE training step in a HIP graph and time its replays "
-                         "(reported as `graph_replay`; one process only -- an RCCL capture cannot be exercised on one GPU)")
+                    help="after the timed (eager) region: capture ONE training step in a HIP graph -- the RCCL calls of an "
+                         "N > 1 run included -- and time its replays (reported as `graph_replay`; all ranks or none)")
     ap.add_argument("--emulate-rank", default=None, metavar="r/P",
                     help="one GPU runs rank r of a P-rank job with a no-op exchange (per-rank compute of 2/4/8 GPUs)")
     args = ap.parse_args()
@@ -698,6 +796,10 @@ def main():
     if args.emulate_rank and part.size > 1:          # the slabs a real exchange would fill: resident random rows
         eng._slab("halo", eng.n_halo, f).uniform_()
         eng._slab("send", eng.n_send, f).uniform_()
+    selftest = None
+    if world > 1 and not args.no_selftest:        # first contact: the multi-rank path on a small graph, before anything is timed
+        selftest = multirank_selftest(rank, world, dev, K, exch)
+        stage("multi-rank self-test passed")
     P._engine_current = eng           # gradient all-reduce rides the exchange's communicator and stream
     gemm_tuned = P.tune_dense_gemms(part.n_local, f, dev)      # library GEMM choice made in set-up, not in a timed step
     torch.cuda.synchronize()
@@ -776,7 +878,7 @@ def main():
             kname += " + spmm_dense_kernel<4> (fp32-MFMA tiles, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.dense.nnz / max(eng.A_loc.nnz, 1))
         if getattr(eng.A_loc, "dense3", None) is not None:
-            kname += " + split_panels_kernel + spmm_dense3_kernel<4> (512x128 blocks on the bf16 matrix cores, three-plane split at fp32 accuracy, %.0f%% of the entries)" % (
+            kname += " + spmm_split_panels_kernel + spmm_dense3_kernel<4> (512x128 blocks on the bf16 matrix cores, three-plane split at fp32 accuracy, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.dense3.nnz / max(eng.A_loc.nnz, 1))
         kname += " + fix-up; one launch group, timed as a whole"
         roofline = {"bound": "hbm", "kernel": kname,
@@ -848,13 +950,14 @@ def main():
     }
     if halo_groups is not None:
         out["halo_groups"] = halo_groups
-    if args.graph and world == 1:
+    if args.graph:
         out["graph_replay"] = graph_replay(model, lambda: nn.Sequential(*[P.PGCN(eng, f, f) for _ in range(L)]).to(dev),
-                                           H, labels, n, P, args.steps, dev, ms_per_step)
+                                           H, labels, n, P, args.steps, dev, ms_per_step, world)
     if world > 1:
         vol = torch.tensor([eng.stats["send_volume"]], dtype=torch.float64, device=dev)
         P._all_reduce(vol)
         out["exchange_rows_total"] = float(vol)
+        out["selftest"] = selftest
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not emul:
         cb = cpu_baseline(part, f, L, args.cpu_budget)
         out["cpu_baseline"] = cb

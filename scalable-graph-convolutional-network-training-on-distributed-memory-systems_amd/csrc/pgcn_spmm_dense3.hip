@@ -17,7 +17,7 @@
 // by every tile that shares the panel.  And what the first r04 version taught (panels split once per SpMM, 128-row
 // tiles, two workgroups per CU: 7.7 us per tile): the kernel is then bound by the L2 <-> fabric traffic -- 96 KB of
 // planes + 64 KB of A per 128 x 128 tile at the ~21 GB/s a CU gets when all 256 pull (5.4 TB/s in total).  So:
-//   * split_panels_kernel splits the panels that dense blocks refer to ONCE per SpMM (~490 of 1 821 panels on the
+//   * spmm_split_panels_kernel splits the panels that dense blocks refer to ONCE per SpMM (~490 of 1 821 panels on the
 //     benchmark graph: 31 MB read, 47 MB written) into the exact LDS image of the block kernel, in a work-space:
 //         image[panel][feature block] = [quarter q (32 k)][plane p][k group kg (8 k)][column n (128)] x 16 B
 //     (8 bf16: k = 32 q + 8 kg + j), i.e. a lane's B operand of v_mfma_f32_32x32x16_bf16 is one 16-byte slot and
@@ -110,7 +110,7 @@ __device__ __forceinline__ f32x16 mma(const u32x4 &a, const u32x4 &b, const f32x
 
 // ---- the panel split ------------------------------------------------------------------------------------------
 // grid (panels in the list, feature blocks of 128); thread t: column n = t & 127, k groups 8 (t >> 7) .. + 8
-__global__ __launch_bounds__(kSplitThreads) void split_panels_kernel(const int32_t *__restrict__ panel_list, const float *__restrict__ B,
+__global__ __launch_bounds__(kSplitThreads) void spmm_split_panels_kernel(const int32_t *__restrict__ panel_list, const float *__restrict__ B,
                                                                   int64_t ldb, int64_t ncols, int32_t f, u32x4 *__restrict__ image) {
     const int64_t r0 = (int64_t)panel_list[blockIdx.x] * kT;
     const int fcol0 = blockIdx.y * kT;
@@ -463,7 +463,7 @@ extern "C" int pgcn_spmm_dense_bf16x3_f32(const int32_t *work, int64_t nwork, co
     }
     hipStream_t s = (hipStream_t)stream;
     const unsigned nfb = (unsigned)((f + kT - 1) / kT);
-    hipLaunchKernelGGL(split_panels_kernel, dim3((unsigned)npanels, nfb), dim3(kSplitThreads), 0, s, panel_list, B, ldb, ncols, f,
+    hipLaunchKernelGGL(spmm_split_panels_kernel, dim3((unsigned)npanels, nfb), dim3(kSplitThreads), 0, s, panel_list, B, ldb, ncols, f,
                        reinterpret_cast<u32x4 *>(image_ws));
     PGCN_HIP_CHECK(hipGetLastError());
     const int4 *w4 = reinterpret_cast<const int4 *>(work);

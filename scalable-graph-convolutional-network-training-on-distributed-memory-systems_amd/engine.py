@@ -114,41 +114,93 @@ class RcclExchanger:
             self.comm = None
 
 
+SELFTEST_TIMEOUT_S = float(os.environ.get("PGCN_SELFTEST_TIMEOUT", "90"))
+
+
+def _wait_or_die(device: torch.device, what: str, timeout_s: float = None) -> None:
+    """Wait for everything queued on ``device`` with a deadline: a collective whose peers never arrive (a mismatched
+    send / receive pair, a dead link) spins on the GPU for ever -- the process then says what it was doing and
+    exits with status 3 instead of hanging the launcher until its own limit."""
+    import sys
+    import time
+    timeout_s = SELFTEST_TIMEOUT_S if timeout_s is None else timeout_s
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    t0 = time.time()
+    while not ev.query():
+        if time.time() - t0 > timeout_s:
+            sys.stderr.write("pgcn: %s did not complete within %.0f s on %s -- the collective hangs (peer never arrived); "
+                             "PGCN_EXCHANGE=torch selects torch.distributed's all_to_all_single instead of the C-ABI "
+                             "communicator\n" % (what, timeout_s, device))
+            sys.stderr.flush()
+            os._exit(3)
+        time.sleep(0.002)
+
+
+def exchange_selftest(ex, rank: int, size: int, device: torch.device, group=None, f: int = 4, rows: int = 3):
+    """One all-to-all-v with NON-EMPTY, unequal segments (1 + (p + q) % rows rows between ranks p and q) through ``ex``,
+    checked against what every peer must have sent: value = 1000 * sender + position in the sender's slab.  Device
+    exchangers are waited for with a deadline.  Returns True / False (this rank's view)."""
+    send_off, recv_off = [0], [0]
+    for q in range(size):
+        send_off.append(send_off[-1] + (0 if q == rank else 1 + (rank + q) % rows))
+        recv_off.append(recv_off[-1] + (0 if q == rank else 1 + (rank + q) % rows))
+    send = (torch.arange(send_off[-1] * f, device=device, dtype=torch.float32) + 1000 * rank).view(-1, f)
+    got = torch.full((max(recv_off[-1], 1), f), -1.0, device=device)
+    ex.alltoallv(send, send_off, got, recv_off, f)
+    if torch.device(device).type == "cuda":
+        _wait_or_die(device, "the exchanger self-test (%s, %d ranks)" % (ex.name, size))
+    want = torch.full_like(got, -1.0)
+    for q in range(size):
+        if q == rank:
+            continue
+        # what q holds for me: its segment for target `rank` starts after its segments for targets < rank
+        qoff = sum(0 if t == q else 1 + (q + t) % rows for t in range(rank))
+        nrow = 1 + (rank + q) % rows
+        seg = (torch.arange(qoff * f, (qoff + nrow) * f, device=device, dtype=torch.float32) + 1000 * q).view(-1, f)
+        want[recv_off[q]:recv_off[q + 1]] = seg
+    return bool(torch.equal(got[:recv_off[-1]], want[:recv_off[-1]]))
+
+
 def make_exchanger(rank: int, size: int, device: torch.device, impl: str = "auto", group=None):
     """Pick the boundary-row transport.  'rccl' = libpgcn_hip.so's own communicator (C ABI),
     'torch' = torch.distributed all_to_all_single (RCCL under backend nccl, gloo otherwise).
-    'auto' uses the C-ABI communicator on GPUs under nccl after a self-test against
-    torch.distributed (both are RCCL: this is a choice of API, not a CPU fallback)."""
+    'auto' (or $PGCN_EXCHANGE) uses the C-ABI communicator on GPUs under nccl after a self-test with non-empty
+    segments (both are RCCL: this is a choice of API, not a CPU fallback).  Whatever is chosen has passed
+    ``exchange_selftest`` on every rank before it is returned; ``.selftest`` records what happened."""
     device = torch.device(device)
     backend = dist.get_backend(group)
-    if impl == "torch" or device.type != "cuda" or backend != "nccl":
-        return TorchDistExchanger(rank, size, group)
-    ex, good = None, 0.0
-    try:
-        ex = RcclExchanger(rank, size, device, group)
-        f = 4
-        send_off, recv_off = [0], [0]
-        for q in range(size):
-            send_off.append(send_off[-1] + (0 if q == rank else 1 + (rank + q) % 3))
-            recv_off.append(recv_off[-1] + (0 if q == rank else 1 + (rank + q) % 3))
-        send = (torch.arange(send_off[-1] * f, device=device, dtype=torch.float32) + 1000 * rank).view(-1, f)
-        got = torch.full((max(recv_off[-1], 1), f), -1.0, device=device)
-        ref = torch.full((max(recv_off[-1], 1), f), -2.0, device=device)
-        ex.alltoallv(send, send_off, got, recv_off, f)
-        TorchDistExchanger(rank, size, group).alltoallv(send, send_off, ref, recv_off, f)
-        torch.cuda.synchronize(device)
-        good = 1.0 if torch.equal(got[:recv_off[-1]], ref[:recv_off[-1]]) else 0.0
-    except _lib.PgcnError:
-        good = 0.0
-    ok = torch.tensor([good], device=device)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # every rank takes the same decision
-    if float(ok) == 1.0:
-        return ex
-    if ex is not None:
-        ex.close()
-    if impl == "rccl":
-        raise _lib.PgcnError("C-ABI RCCL exchanger failed its self-test")
-    return TorchDistExchanger(rank, size, group)
+    if impl == "auto":
+        impl = os.environ.get("PGCN_EXCHANGE", "auto")
+
+    def agreed(flag: float) -> bool:            # every rank takes the same decision
+        ok = torch.tensor([flag], device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        return float(ok) == 1.0
+
+    record = {}
+    if not (impl == "torch" or device.type != "cuda" or backend != "nccl"):
+        ex, good = None, 0.0
+        try:
+            ex = RcclExchanger(rank, size, device, group)
+            good = 1.0 if exchange_selftest(ex, rank, size, device, group) else 0.0
+        except _lib.PgcnError as e:
+            record["rccl-capi_error"] = str(e)[:200]
+        record["rccl-capi"] = bool(good)
+        if agreed(good):
+            ex.selftest = record
+            return ex
+        if ex is not None:
+            ex.close()
+        if impl == "rccl":
+            raise _lib.PgcnError("C-ABI RCCL exchanger failed its self-test: %r" % (record,))
+    ex = TorchDistExchanger(rank, size, group)
+    good = 1.0 if (size == 1 or exchange_selftest(ex, rank, size, device, group)) else 0.0
+    record["torch.distributed"] = bool(good)
+    if not agreed(good):
+        raise _lib.PgcnError("no boundary-row transport passed its self-test on every rank: %r" % (record,))
+    ex.selftest = record
+    return ex
 
 
 # --------------------------------------------------------------------------

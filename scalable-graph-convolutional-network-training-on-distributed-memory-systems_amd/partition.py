@@ -823,13 +823,18 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
 def build_partition_local(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: int,
                           partvec: torch.Tensor, rank: int, size: int, group=None,
                           with_transpose: bool = True, rounds: Optional[int] = None,
-                          degree_sort: Optional[bool] = None) -> Partition:
+                          degree_sort: Optional[bool] = None, emulate: Optional[dict] = None) -> Partition:
     """The same Partition from rank ``rank``'s OWN ROWS only (global coordinates, e.g.
     ``ingest.load_partition``): no rank ever holds the whole matrix.  Two small collectives over
     ``torch.distributed`` replace the global scan: an all-reduce of the n-vector of degrees (for
     the common degree ranking) and an all-to-all-v of id lists (every rank tells the owners which
     of their rows it needs -- the reference derives this from the global matrix, PGCN.py:44-47).
-    Field for field identical to ``build_partition`` on the global COO (tests/test_partition.py)."""
+    Field for field identical to ``build_partition`` on the global COO (tests/test_partition.py).
+
+    ``emulate`` (one process stands in for rank ``rank`` of ``size``, bench.py --emulate-rank with --shards): the two
+    collectives are replaced by what the caller knows -- ``emulate["gdeg"]``, the global n-vector of (row count + column
+    count) degrees, and ``emulate["nnz_global"]``; the rows the peers need from this rank are derived from this
+    rank's own entries, which is exact for a SYMMETRIC pattern (peer q holds (c, r) for every (r, c) held here)."""
     import torch.distributed as dist
     dev = row.device
     row = row.to(torch.int64)
@@ -838,6 +843,20 @@ def build_partition_local(row: torch.Tensor, col: torch.Tensor, val: torch.Tenso
     if row.numel() and not bool((part[row] == rank).all()):
         raise ValueError("build_partition_local takes the rows owned by this rank only")
 
+    if emulate is not None:
+        part_ = _check_partvec(partvec, n, size, dev)
+        row64, col64 = row.to(torch.int64), col.to(torch.int64)
+        if row64.numel() and not bool((part_[row64] == rank).all()):
+            raise ValueError("build_partition_local takes the rows owned by this rank only")
+        gdeg = torch.as_tensor(emulate["gdeg"]).to(device=dev, dtype=torch.int64)
+        if not (DEGREE_SORT if degree_sort is None else degree_sort) or n <= 1:
+            gdeg = None
+        gorder, grank = _degree_order(gdeg, n, dev)
+        pcol = part_[col64]
+        away = pcol != rank
+        suniq = torch.unique(pcol[away] * n + grank[row64[away]])            # (requesting rank, degree rank of MY row)
+        return _finish_partition(row64, col64, val, n, part_, rank, size, gorder, grank, suniq,
+                                 int(emulate.get("nnz_global", row64.numel())), with_transpose, rounds)
     gloo = size > 1 and dist.get_backend(group) == "gloo"
 
     def to_wire(t):            # gloo moves host tensors; nccl (= RCCL) device tensors

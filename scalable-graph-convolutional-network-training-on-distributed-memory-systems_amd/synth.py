@@ -251,6 +251,32 @@ def rmat_shard_keys(n: int, pairs: int, rank: int, partvec: torch.Tensor, seed: 
     return keys
 
 
+def rmat_all_keys(n: int, pairs: int, seed: int = 0, device="cpu", chunk: int = 1 << 24) -> torch.Tensor:
+    """The GLOBAL pattern of the stream ``rmat_shard_keys`` walks (sorted unique keys ``row * n + col``, both directions
+    of every pair, all self loops): the union of the ranks' key sets, whatever the part vector.  For tools that stand in
+    for a whole job on one big device (tools/make_shards.py --only-rank: the global degree vector of a papers100M-scale
+    graph is 13 GB of keys on a 288 GB GPU); the ranks of a real job never call this."""
+    device = torch.device(device)
+    gen = PortableRng(seed, device)
+    scale = max(1, math.ceil(math.log2(max(n, 2))))
+    perm = gen.randperm(n)
+    own = torch.arange(n, dtype=torch.int64, device=device)
+    parts = [own * n + own]
+    done = 0
+    while done < pairs:
+        m = min(chunk, pairs - done)
+        r, c = _rmat_pairs(m, scale, gen, device)
+        r, c = perm[r % n], perm[c % n]
+        ok = r != c
+        r, c = r[ok], c[ok]
+        parts.append(r * n + c)
+        parts.append(c * n + r)
+        done += m
+        if len(parts) > 64:                                       # (bounded list: fold now and then)
+            parts = [torch.unique(torch.cat(parts))]
+    return torch.unique(torch.cat(parts))
+
+
 def shard_normalize(n: int, keys: torch.Tensor, degree: torch.Tensor):
     """(row, col, val) of a rank's entries, val = d_r^-1/2 d_c^-1/2 with the GLOBAL degree vector (row counts of
     A + I, summed over the ranks: one all-reduce of an n-vector), like preprocess/GrB-GNN-IDG.py:45-68."""

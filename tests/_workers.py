@@ -296,3 +296,32 @@ def pargcn_main_worker(rank, P, port, directory, seed, q, provider="oracle"):
            "targets": int(torch.unique(part.send_owner).numel()), "sources": int(torch.unique(part.halo_owner).numel())})
     dist.barrier()
     dist.destroy_process_group()
+
+
+def bench_selftest_worker(rank, P, port, break_it, q):
+    """bench.multirank_selftest over gloo with the checker-backed kernels: the first-contact check of an N-rank job
+    (P ranks through the real engine + exchange against the same kernels on one rank).  ``break_it``: an exchanger that
+    delivers a wrong row -- the check must notice."""
+    _init(rank, P, port)
+    import importlib
+    from conftest import pkg, ROOT
+    from oracle_kernels import OracleKernels
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    engine = pkg("engine")
+    ex = engine.make_exchanger(rank, P, torch.device("cpu"))
+    if break_it:
+        real = ex.alltoallv
+
+        def bad(send, send_off, recv, recv_off, f):
+            real(send, send_off, recv, recv_off, f)
+            if rank == 1 and recv.shape[0] > 2:
+                recv[2] += 1.0                      # one received row is off
+        ex.alltoallv = bad
+    try:
+        rec = bench.multirank_selftest(rank, P, torch.device("cpu"), OracleKernels(), ex, n=3000, nnz=60000, f=8)
+        q.put({"rank": rank, "ok": True, "rec": rec})
+    except RuntimeError as e:
+        q.put({"rank": rank, "ok": False, "msg": str(e)[:300]})
+    dist.barrier()
+    dist.destroy_process_group()

@@ -129,3 +129,19 @@ def test_new_flags_parse_and_fail_loudly_without_gpu(tmp_path):
                           "--mtx", str(tmp_path / "y.mtx"), "--real", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 1 and "needs an MI355X" in out.stderr and "unrecognized" not in out.stderr
+
+
+@pytest.mark.parametrize("P,break_it", [(3, False), (2, True)])
+def test_multirank_selftest_over_gloo(P, break_it):
+    """bench.py's first-contact check of an N-rank job (runs before the timed region of every N > 1 run): P ranks through
+    the real engine and exchange against the same kernels on one rank; a wrong received row fails it on EVERY rank."""
+    from test_engine_gloo import _spawn
+    res = _spawn(_workers.bench_selftest_worker, P, break_it)
+    if break_it:
+        assert all(not r["ok"] and "FAILED" in r["msg"] for r in res)
+        return
+    assert all(r["ok"] for r in res)
+    rec = res[0]["rec"]
+    assert rec["ranks"] == P and rec["rounds"] == 2 and rec["exchanger_selftest"] == {"torch.distributed": True}
+    assert rec["forward_rel_err_vs_one_rank"] < 1e-5 and rec["backward_rel_err_vs_one_rank"] < 1e-5
+    assert all(r["rec"]["boundary_rows_this_rank"] > 0 for r in res)

@@ -8,12 +8,15 @@ backward against a float64 shadow with a PER-ROW bound:
 instead of a bound relative to the largest output anywhere (a wrong low-degree row cannot hide behind a hub row).
 Reference semantics: Parallel-GCN/main.c:238-299 (forward: local product + one accumulate per source),
 :343-404 (backward), accumulate-on-receive.  A sample of the rows is also checked against the C oracle."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
 import torch
 
-from conftest import pkg
+from conftest import ROOT, pkg
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -299,3 +302,21 @@ def test_papers_shape_graph_partition_shards_f64(K, dev):
         assert p.n_halo > 0
         del p
         torch.cuda.empty_cache()
+
+
+def test_one_rank_of_the_papers_shape_from_its_shard(tmp_path):
+    """BASELINE config 4 on ONE rank, the path that ran at full size in r04 (profiles/r04_papers_full_rank_0_8_check.json: n =
+    111 059 956, 1.71 G entries, rank 0 of 8: 213 M entries, int64 row pointers, 64-bit gather offsets, 56.7 GB of HBM),
+    here at 1/50 scale: tools/make_shards.py --only-rank on the GPU, then tools/shard_rank_check.py -- the rank's forward
+    aggregation from its binary CSR shard against float64 over the shard's own entries, per-row bound 1e-5 sum |a||x|."""
+    import json
+    import subprocess
+    prefix = str(tmp_path / "papers")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_shards.py"), "--workload", "papers", "--ranks", "8", "--only-rank", "0",
+                    "--device", "cuda", "--scale", "0.02", "--out", prefix], check=True, capture_output=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_rank_check.py"), "--shards", prefix, "--rank", "0", "--ranks", "8",
+                          "--features", "64"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["passed"] and rec["worst_row_error_over_bound_1e-5"] <= 1.0 and rec["rowptr_dtype"] == "torch.int64"
+    assert rec["n"] == 2221199 and rec["nnz_local"] > 4_000_000 and rec["n_halo"] > 500_000 and rec["rows_checked"] > 4000

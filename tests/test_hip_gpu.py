@@ -731,6 +731,42 @@ def test_rccl_single_rank_comm(dev):
     _lib.check(L.pgcn_comm_destroy(comm), "comm_destroy")
 
 
+def test_rccl_calls_are_capturable_in_a_hip_graph(dev):
+    """bench.py --graph captures a whole N-rank training step, the RCCL calls of the boundary exchange and of
+    average_gradients included.  What one GPU can show of that: the library's all-reduce and (peer-less) all-to-all-v
+    on a ONE-rank communicator record into a capturing stream without error and replay (Parallel-GCN/main.c:321,425
+    MPI_Allreduce; GPU/PGCN.py:99-115 send / recv)."""
+    _lib = pkg("_lib")
+    L = _lib.lib()
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(L.pgcn_comm_unique_id(uid), "unique_id")
+    comm = ctypes.c_void_p()
+    _lib.check(L.pgcn_comm_init(ctypes.byref(comm), uid, 1, 0), "comm_init")
+    buf = torch.arange(4096, dtype=torch.float32, device=dev)
+    out = torch.zeros_like(buf)
+    off = (ctypes.c_int64 * 2)(0, 0)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):                       # one eager call first: lazy initialisation must not happen inside a capture
+        _lib.check(L.pgcn_allreduce_sum_f32(comm, buf.data_ptr(), buf.numel(), side.cuda_stream), "allreduce (eager)")
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s = torch.cuda.current_stream(dev).cuda_stream
+        buf.mul_(2.0)
+        _lib.check(L.pgcn_allreduce_sum_f32(comm, buf.data_ptr(), buf.numel(), s), "allreduce (captured)")
+        _lib.check(L.pgcn_exchange_alltoallv_f32(comm, None, off, None, off, 128, s), "alltoallv (captured)")
+        out.copy_(buf)
+    torch.cuda.synchronize(dev)
+    want = torch.arange(4096, dtype=torch.float32)
+    for k in range(1, 4):
+        g.replay()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out.cpu(), want * 2.0 ** k)      # a one-rank sum is the identity; the replays really ran
+    _lib.check(L.pgcn_comm_destroy(comm), "comm_destroy")
+
+
 @pytest.mark.parametrize("mtx,pv,P,L,f", [("karate.A.mtx", "karate.mtx.3.hp", 3, 3, 16),
                                           ("gemat11p.A.mtx", "gemat11.mtx.2.rp", 2, 3, 32)])
 def test_run_multi_rank_on_one_gpu(dev, mtx, pv, P, L, f):

@@ -8,6 +8,8 @@ import scipy.sparse as sp
 from scipy.io import mmread as sp_mmread
 from scipy.io import mmwrite
 
+import torch
+
 from conftest import gpath, pkg
 
 
@@ -213,3 +215,40 @@ def test_plan_host_keeps_64_bit_entry_offsets():
         cover[k - base:k - base + ln] += 1
     assert (cover == 1).all()                                        # every stored entry in exactly one task
     assert int(tasks[:, 2].max()) <= 1024 and nslots == 3 + 3 and fix.shape[0] == 2      # the two long rows are split in 3
+
+
+def test_one_rank_shard_with_degree_file_rebuilds_the_ranks_partition(tmp_path):
+    """tools/make_shards.py --only-rank (BASELINE config 4 at full size on ONE rank: bench.py --emulate-rank r/P --shards):
+    the global key set equals the union of the rank-local generators', and the partition built from the rank's shard +
+    the degree side file (build_partition_local(emulate=...): no collectives, the peers' needs derived from the
+    symmetric pattern) is the partition the global build gives that rank."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    synth, partition, ingest = pkg("synth"), pkg("partition"), pkg("ingest")
+    prefix = str(tmp_path / "mid")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_shards.py"), "--workload", "mid", "--ranks", "4", "--only-rank", "1",
+                    "--scale", "0.25", "--out", prefix], check=True, capture_output=True)
+    meta = json.load(open(prefix + ".meta.json"))
+    n, P, r = meta["n"], 4, 1
+    pv = synth.block_partvec(n, P)
+    allk = synth.rmat_all_keys(n, meta["pairs"], seed=0)
+    assert allk.numel() == meta["nnz_global"]
+    for q in range(P):
+        assert torch.equal(synth.rmat_shard_keys(n, meta["pairs"], q, pv, seed=0), allk[pv[allk // n] == q])
+    deg = torch.from_numpy(np.load(prefix + ".degree.npy").astype(np.int64))
+    assert torch.equal(deg, torch.bincount(allk // n, minlength=n))
+    sh = ingest.read_shard(ingest.shard_path(prefix, r))
+    rr, cc, vv = ingest.shard_coo(sh)
+    e = partition.build_partition_local(torch.from_numpy(rr), torch.from_numpy(cc), torch.from_numpy(vv), n, pv, r, P,
+                                        emulate={"gdeg": 2 * deg, "nnz_global": meta["nnz_global"]})
+    row, col, val = synth.shard_normalize(n, allk, deg)
+    g = partition.build_partition(row, col, val, n, pv, r, P)
+    for name in ("owned", "send_idx", "send_owner", "halo_owner", "halo_global", "send_global"):
+        assert torch.equal(getattr(g, name), getattr(e, name)), name
+    assert g.round_send_off == e.round_send_off and g.round_recv_off == e.round_recv_off and g.nnz_global == e.nnz_global
+    for a, b in ((g.A_loc, e.A_loc), (g.A_halo[0], e.A_halo[0]), (g.A_halo[1], e.A_halo[1]), (g.A_loc_T, e.A_loc_T), (g.A_halo_T[0], e.A_halo_T[0])):
+        ra, ca, va = partition.full_csr(a)
+        rb, cb, vb = partition.full_csr(b)
+        assert torch.equal(ra, rb) and torch.equal(ca, cb) and torch.equal(va, vb)

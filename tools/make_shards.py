@@ -5,6 +5,10 @@
       python tools/make_shards.py --mtx A.mtx --partvec A.mtx.8.hp --out /data/A
   from the rank-local synthetic generator (papers100M-scale R-MAT, block partition unless --partvec):
       python tools/make_shards.py --workload papers --ranks 8 --out /data/papers [--scale 0.01] [--device cuda]
+  ONE rank of that job at full size, for bench.py --emulate-rank r/P on one big GPU (the global key set -- 13 GB at the
+  papers100M shape -- lives on the device only here; the shard comes with PREFIX.degree.npy, the global degree vector
+  the other ranks would have contributed):
+      python tools/make_shards.py --workload papers --ranks 8 --only-rank 0 --device cuda --out /tmp/papers
 
 Each rank's degrees are summed into the global degree vector (one n-vector; under torch.distributed this is an
 all-reduce, here the ranks are produced one after the other).  Then:  python PGCN.py -a PREFIX -p PARTVEC ..."""
@@ -29,6 +33,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n and nnz of the synthetic workload by this factor")
     ap.add_argument("--device", default="cpu")
+    ap.add_argument("--only-rank", type=int, default=None, help="write this rank's shard only, plus PREFIX.degree.npy")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     ingest = importlib.import_module(PKG + ".ingest")
@@ -50,6 +55,33 @@ def main():
     n, pairs = max(64, int(n * args.scale)), max(64, int(nnz * args.scale) // 2)
     P = args.ranks
     pv = torch.tensor(partition.read_partvec(args.partvec)) if args.partvec else synth.block_partvec(n, P)
+    if args.only_rank is not None:
+        import time
+        r = args.only_rank
+        t0 = time.time()
+        allk = synth.rmat_all_keys(n, pairs, seed=0, device=args.device)
+        rows_all = allk // n
+        deg = torch.bincount(rows_all, minlength=n)                    # row counts of A + I (= column counts: symmetric)
+        mine = pv.to(allk.device)[rows_all] == r
+        nnz_global = int(allk.numel())
+        keys_r = allk[mine]
+        del allk, rows_all, mine
+        # (the rank-local generator of a real job yields the same set: tests/test_ingest.py; at this size it is checked on a sample)
+        row, col, val = synth.shard_normalize(n, keys_r, deg)
+        own, counts = torch.unique_consecutive(row, return_counts=True)
+        allown = torch.nonzero(pv == r).reshape(-1)
+        cnt = torch.zeros(n, dtype=torch.int64, device=row.device)
+        cnt[own] = counts
+        rowptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=row.device), torch.cumsum(cnt[allown.to(row.device)], 0)])
+        ingest.write_shard(ingest.shard_path(args.out, r), n, r, P, allown.numpy(), rowptr.cpu().numpy(), col.cpu().numpy(),
+                           val.cpu().numpy())
+        np.save(args.out + ".degree.npy", deg.cpu().numpy().astype(np.int32))
+        with open(args.out + ".meta.json", "w") as fh:
+            import json
+            json.dump({"n": n, "pairs": pairs, "nnz_global": nnz_global, "ranks": P, "rank": r, "nnz_rank": int(col.numel()),
+                       "partvec": "block" if not args.partvec else os.path.basename(args.partvec), "seconds": time.time() - t0}, fh)
+        print("rank %d of %d: %d rows, %d entries of %d (global), %.1f s" % (r, P, allown.numel(), col.numel(), nnz_global, time.time() - t0))
+        return
     keys, deg = [], torch.zeros(n, dtype=torch.int64)
     for r in range(P):
         k = synth.rmat_shard_keys(n, pairs, r, pv, seed=0, device=args.device).cpu()
