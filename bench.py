@@ -31,6 +31,8 @@ Extra objects in the JSON line:
   cpu_baseline the CPU oracle (GraphBLAS-free restatement of Parallel-GCN's SpMM and training loop, OpenMP)
                timed on this host on a bounded sample: rank 0, N = 1 only.
 """
+import time as _time
+PROCESS_T0 = _time.time()          # (before the heavy imports: a cold box pages torch in for a long time)
 import argparse
 import ctypes
 import importlib
@@ -748,7 +750,12 @@ def main():
         faulthandler.dump_traceback_later(wd, exit=True)
     t_start = time.time()
 
+    stages = []                                   # (name, seconds since start): the set-up breakdown of the JSON line
+
     def stage(msg):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        stages.append((msg, round(time.time() - t_start, 3)))
         if wd > 0:
             print("[bench rank %d +%.1fs] %s" % (rank, time.time() - t_start, msg), file=sys.stderr, flush=True)
     if world != args.gpus:
@@ -801,10 +808,11 @@ def main():
         selftest = multirank_selftest(rank, world, dev, K, exch)
         stage("multi-rank self-test passed")
     P._engine_current = eng           # gradient all-reduce rides the exchange's communicator and stream
+    stage("engine ready (kernel structures uploaded)")
     gemm_tuned = P.tune_dense_gemms(part.n_local, f, dev)      # library GEMM choice made in set-up, not in a timed step
     torch.cuda.synchronize()
     setup_s = time.time() - t0
-    stage("engine ready")
+    stage("GEMM choice made")
 
     # ---- model: L x PGCN(f, f), PGCN.py:194-200 ----------------------------------
     P.device, P.myrank, P.world_size = dev, rank, world
@@ -947,6 +955,7 @@ def main():
                    "strip_tiles": {"min_entries": partition.STRIP_MIN, "layer_min": partition.STRIP_LAYER_MIN}
                    if partition.STRIP_ON else None},
         "roofline": roofline, "ms_per_epoch": ms_per_step, "loss": loss_val, "setup_s": setup_s,
+        "setup_stages_s": {"process_start_to_main": round(t_start - PROCESS_T0, 3), **{k: v for k, v in stages}},
     }
     if halo_groups is not None:
         out["halo_groups"] = halo_groups

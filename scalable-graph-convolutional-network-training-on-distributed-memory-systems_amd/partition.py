@@ -272,9 +272,10 @@ def build_dense3(r64, c64, v, bkey_local, nblocks, blk_row, blk_panel, nrows, nc
     BR, TC = DENSE3_BR, CORE_TC
     piece = DENSE3_PIECE if piece is None else piece
     if piece <= 0:
-        # one workgroup per CU: ~512 pieces = two rounds over the 256 CUs (longest first); a piece writes a 512-row
-        # partial block (256 KB) whatever it holds, so no confetti: between 1 and 8 blocks
-        piece = int(min(8, max(1, -(-nblocks // 512))))
+        # one workgroup per CU: ~256 pieces = one round over the 256 CUs (longest first); a piece writes a 512-row
+        # partial block (256 KB) whatever it holds, so no confetti: between 1 and 8 blocks (r04, 1 880 blocks: 2 / 4 / 8
+        # blocks per piece -> launch group 1.747 / 1.663 / 1.642 ms)
+        piece = int(min(8, max(1, -(-nblocks // 256))))
     dev = r64.device
     vals = torch.zeros(nblocks * BR * TC, dtype=torch.float32, device=dev)
     vals.index_add_(0, bkey_local * (BR * TC) + dense3_index(r64 % BR, c64 % TC), v.to(torch.float32))   # duplicates add
@@ -428,10 +429,12 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     if nrec == 0:
         return None, None
     if pieces is None:
-        # one piece writes 512 partial rows (256 KB ~ six records of LDS time): a piece wants >= ~40 records, and the
-        # number of pieces a multiple of the 256 one-workgroup CUs.  Measured r02 (82 k records: 1 024 pieces best of
-        # 512..1 536) and r03 (shards of 8.6 k / 14.9 k records: 256 best of 128 / 256 / 512)
-        pieces = min(STRIP_PIECES, max(256, 256 * int(round(nrec / 64.0 / 256.0))))
+        # one piece writes 512 partial rows (256 KB ~ six records of LDS time, written once and read again by the fix-up,
+        # which is bandwidth-bound): a piece wants >= ~100 records, and the number of pieces a multiple of the 256
+        # one-workgroup CUs.  Measured r02 (82 k records: 1 024 pieces best of 512..1 536), r03 (shards of 8.6 k / 14.9 k
+        # records: 256 best of 128 / 256 / 512) and r04 (60 k records once the bf16 blocks took the dense part: launch
+        # group 1.663 / 1.643 / 1.633 ms with 1 024 / 768 / 512 pieces, fix-up 159 / 155 / 136 us)
+        pieces = min(STRIP_PIECES, max(256, 256 * int(round(nrec / 128.0 / 256.0))))
     in_s = lsel[linv] & ~deep
     rmap = torch.cumsum(lsel.to(torch.int64), 0) - 1
     e_rec = rmap[linv[in_s]]                                     # record of every strip entry (tile major, layer minor)
