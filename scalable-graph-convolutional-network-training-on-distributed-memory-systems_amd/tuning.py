@@ -44,8 +44,10 @@ class Tuning:
                                      # SpMM launch group: off 1.742 ms, 0.12 1.724, 0.16 1.728, 0.20 1.685, 0.26 1.796)
     dense3_piece: int = 0            # blocks per piece (0 = adaptive: ~512 pieces, between 1 and 8 blocks)
     strip: bool = True               # 512 x 128 strip tiles
-    strip_min: int = 512             # stored entries that make a strip tile worth staging
-    strip_layer_min: int = 384       # stored entries that make one more layer (record) of a tile worth it
+    strip_min: int = 256             # stored entries that make a strip tile worth staging ...
+    strip_layer_min: int = 192       # ... and one more layer (record) of a tile worth it (r02: 512 / 384; r04 re-sweep with the bf16
+                                     # blocks in -- a flat optimum, the gather part and the strips trade time about 1 : 1:
+                                     # 384 / 256 / 192 / 128 at strip_min 512 -> 1.645 / 1.652 / 1.648 / 1.666 ms; 192 with strip_min 256 -> 1.622)
     strip_min_records: int = 4096    # blocks with fewer records keep the 128 x 128 LDS core instead (r03: shards of an
                                      # 8-way run: 1.1 k records lose, 4.9 k break even, 8.6 k and 14.9 k win 9-15 %)
     strip_pieces: int = 1024         # upper bound of the strip work pieces (records / 64, in multiples of 256 CUs)
