@@ -249,10 +249,14 @@ class GatEngine(BoundaryExchange):
         if st.fused:
             # one gather pass: dZc = A_alpha^T . dOut and ds2 = the row sums of the edge gradient, which is not stored:
             # ds1 = its column sums = <dOut_i, V_i> - t_i C_i from the forward pass's second accumulator
-            if not self.k.spmm_heads_grad(self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, st.Zc, t, dZc, None, K, d):
-                raise RuntimeError("pgcn_spmm_heads_grad_f32 refused a shape pgcn_spmm_heads_forward2_f32 took")
-            ds1 = (dOut.view(n_p, K, d) * st.V[:, :F].view(n_p, K, d)).sum(-1) - t * st.V[:, F:F + K]
-            return self._finish_backward(st, dOut, dZc, ds1)
+            if self.k.spmm_heads_grad(self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, st.Zc, t, dZc, None, K, d):
+                ds1 = (dOut.view(n_p, K, d) * st.V[:, :F].view(n_p, K, d)).sum(-1) - t * st.V[:, F:F + K]
+                return self._finish_backward(st, dOut, dZc, ds1)
+            # the fused kernel refused operands its forward twin took (an alignment / stride of dOut or the work-space that
+            # `covers` does not model): the unfused passes need the alpha planes the fused forward never wrote -- build them now
+            self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,
+                                    self.planes(st), st.beta, st.rowstat)
+            st.fused = False
         if self.fused_grad:
             # one gather pass: dZc = A_alpha^T . dOut, de (entry-major, TRANSPOSED storage order) and ds2 = its row sums
             de_t = self._scratch.get(("de_t", K))

@@ -416,15 +416,19 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     run_first = idx[newrun][torch.cumsum(newrun.to(torch.int64), 0) - 1]     # first position of every entry's run
     layer = (idx - run_first) // SB
     slot = (idx - run_first) % SB
-    # tiles worth staging, then their layers worth a record
-    ut, tinv, tcnt = torch.unique(tk_s, return_inverse=True, return_counts=True)
     # a row holds at most 128 DISTINCT columns per panel = 64 layers; duplicate coordinates (an uncoalesced COO keeps
-    # them as separate entries, PGCN.py:63) can exceed that: whatever lies beyond layer 63 stays in the gather part
+    # them as separate entries, PGCN.py:63) can exceed that: whatever lies beyond layer 63 stays in the gather part and
+    # counts for nothing below (neither for its tile nor for layer 63)
     deep = layer >= 64
+    shallow = ~deep
+    # tiles worth staging, then their layers worth a record
+    ut, tcnt = torch.unique(tk_s[shallow], return_counts=True)
     lkey = tk_s * 64 + torch.clamp(layer, max=63)
-    ul, linv, lcnt = torch.unique(lkey, return_inverse=True, return_counts=True)
+    ul, lcnt = torch.unique(lkey[shallow], return_counts=True)
+    linv = torch.searchsorted(ul, lkey).clamp_(max=max(int(ul.numel()) - 1, 0))      # (deep entries: any index, masked below)
     lsel = (lcnt >= max(1, layer_min)) & (tcnt[torch.searchsorted(ut, ul // 64)] >= max(1, min_entries))
-    # layers of a tile shrink monotonically, so the kept layers of a tile are a prefix 0..L-1
+    # layers of a tile shrink monotonically (layer l holds the rows with more than 2 l entries), so the kept layers of a
+    # tile are a prefix 0..L-1
     nrec = int(lsel.sum())
     if nrec == 0:
         return None, None

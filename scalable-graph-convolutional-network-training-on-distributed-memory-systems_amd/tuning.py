@@ -94,9 +94,22 @@ def _parse(spec: str, base: Tuning) -> Tuning:
     return out
 
 
+# what else the package reads from the environment: transports, ingest path, seeds, a cache path, a deadline -- no kernel shape
+_OTHER_SWITCHES = {"PGCN_TUNING", "PGCN_EXCHANGE", "PGCN_OVERLAP", "PGCN_INGEST", "PGCN_BACKEND", "PGCN_SEED", "PGCN_DATA_DIR",
+                   "PGCN_TUNABLEOP_CACHE", "PGCN_SELFTEST_TIMEOUT", "PGCN_BENCH_BACKEND", "PGCN_BENCH_WATCHDOG", "PGCN_EXTRA_FLAGS",
+                   "PGCN_STRIP_PROBE"}
+
+
 def load(env=None) -> Tuning:
-    """The defaults overridden by PGCN_TUNING (read from ``env``, default os.environ)."""
+    """The defaults overridden by PGCN_TUNING (read from ``env``, default os.environ).  The per-knob variables of rounds
+    1-2 (PGCN_STRIP_PIECES, PGCN_EXCHANGE_ROUNDS, ...) are no longer read: setting one is an error, so that an old probe
+    script cannot silently measure the defaults under a label that claims otherwise."""
     env = os.environ if env is None else env
+    fields = {f.name.upper() for f in dataclasses.fields(Tuning)}
+    stale = sorted(k for k in env if k.startswith("PGCN_") and k not in _OTHER_SWITCHES
+                   and (k[5:] in fields or k in ("PGCN_SPMM_FPASS64", "PGCN_ORDER_HUBS", "PGCN_SPMM_PERSIST")))
+    if stale:
+        raise ValueError("%s: no longer read -- use PGCN_TUNING=\"%s=...\" (tuning.py)" % (", ".join(stale), stale[0][5:].lower()))
     return _parse(env.get("PGCN_TUNING", ""), Tuning())
 
 

@@ -208,3 +208,33 @@ def test_four_ranks_random_partition(tmp_path):
     for i in range(L):
         assert rel_err(sum(r["dW"][i] for r in res), dW[i]) < 2e-4
         assert rel_err(sum(r["da"][i] for r in res), da[i]) < 2e-4
+
+
+@pytest.mark.parametrize("mode", ["standard", "reference"])
+def test_backward_survives_a_refusal_of_the_fused_gradient_kernel(mode):
+    """After a fused forward there are no alpha planes.  When pgcn_spmm_heads_grad_f32 then refuses its operands (an
+    alignment or stride its forward twin did not care about), GatEngine.backward rebuilds the planes and takes the
+    unfused passes -- same gradients."""
+    gat, partition, synth = pkg("gat"), pkg("partition"), pkg("synth")
+    from oracle_kernels import OracleKernels
+    n, row, col, val = synth.make_graph(400, 6000, seed=2)
+    part = partition.build_partition(row, col, val, n, torch.zeros(n, dtype=torch.int64), 0, 1)
+    heads, d = 2, 32
+    g = torch.Generator().manual_seed(5)
+    Z, s1, s2 = torch.rand(n, heads * d, generator=g) - 0.5, torch.rand(n, heads, generator=g) - 0.5, torch.rand(n, heads, generator=g) - 0.5
+    dOut = torch.rand(n, heads * d, generator=g) - 0.5
+    res = []
+    for refuse in (False, True):
+        K = OracleKernels()
+        eng = gat.GatEngine(part, K, torch.device("cpu"), None, mode=mode)
+        st = eng.new_layer_state(heads, d)
+        eng.forward(st, Z, s1, s2)
+        assert st.fused and st.alpha is None
+        if refuse:
+            real = K.spmm_heads_grad
+            K.spmm_heads_grad = lambda *a, **k: False
+        out = eng.backward(st, dOut)
+        assert (st.alpha is not None) == refuse and st.fused != refuse
+        res.append([t.clone() for t in out])
+    for a, b in zip(*res):
+        assert rel_err(b.numpy(), a.numpy()) < 1e-5

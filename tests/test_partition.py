@@ -137,7 +137,7 @@ def test_dense_core_split_roundtrip():
     rank = torch.empty(n, dtype=torch.int64)
     rank[torch.argsort(-deg, stable=True)] = torch.arange(n)
     r, c = rank[row], rank[col]
-    h = partition.csr_from_coo(r, c, val, n, n, nslices=8, core=True, tau=0.05, emax=5000, strip=False)
+    h = partition.csr_from_coo(r, c, val, n, n, nslices=8, core=True, tau=0.05, emax=5000, strip=False, dense3_tau=2.0)
     assert h.core is not None and h.core.nnz > 0.2 * r.numel() and h.core.npieces > h.core.tile_row.unique().numel()
     assert h.nnz == r.numel()
     A = sp.csr_matrix((val.numpy(), (r.numpy(), c.numpy())), shape=(n, n))

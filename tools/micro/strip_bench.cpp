@@ -12,8 +12,12 @@
 #include <vector>
 #include <random>
 
+static const int32_t PADOFF = 128 * 512;      // PGCN_STRIP pad slot: byte offset of the all-zero LDS row (partition.STRIP_PAD_OFF)
+
+#ifdef WITH_HALF   // tools/experiments/pgcn_spmm_strip_half.hip (r02), not part of libpgcn_hip.so: link it in to use mode 3
 extern "C" int pgcn_spmm_strip_half_f32(const int32_t *, int64_t, const int32_t *, const int32_t *, const float *, int64_t, int64_t,
                                         int32_t, float *, int64_t, int64_t, void *);
+#endif
 #ifdef WITH_NEXT
 extern "C" int pgcn_spmm_strip3_f32(const int32_t *, int64_t, const int32_t *, const int32_t *, const float *, int64_t, int64_t,
                                     int32_t, float *, int64_t, int64_t, void *);
@@ -97,8 +101,10 @@ int main(int argc, char **argv) {
         for (int it = 0; it < reps + 1; ++it) {
             CHECK(hipEventRecord(e0));
             int rc;
+#ifdef WITH_HALF
             if (which == 3) rc = pgcn_spmm_strip_half_f32(dwork, npieces, drecs, dpn, dB, f, n, f, dws_x, nslots * f, nslots, nullptr);
             else
+#endif
 #ifdef WITH_NEXT
             if (which == 2) rc = pgcn_spmm_strip3_f32(dwork, npieces, drecs, dpx, dB, f, n, f, dws_x, nslots * f, nslots, nullptr);
             else
@@ -114,7 +120,9 @@ int main(int argc, char **argv) {
                (long long)nrec, sum / reps, best, clk);
     };
     timeit("strip", 1);
+#ifdef WITH_HALF
     timeit("strip half", 3);
+#endif
     if (!(getenv("PGCN_STRIP_PROBE") && atoi(getenv("PGCN_STRIP_PROBE")))) {
         std::vector<float> ha((size_t)nslots * f), hb((size_t)nslots * f);
         CHECK(hipMemcpy(ha.data(), dws_n, ha.size() * 4, hipMemcpyDeviceToHost));
