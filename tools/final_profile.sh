@@ -1,9 +1,10 @@
 #!/bin/bash
 # Round evidence in one gpurun call: GPU tests, smoke, default bench, rocprofv3 kernel stats of the bench command, PMC
 # traffic passes per launch group (tools/group_probe.py: the block exactly as bench.py builds it), the other workloads
-# (products, SBM, mid, GAT) and the shard shapes (--emulate-rank).  usage: bash tools/final_profile.sh r03 [hp-partvec workload]
+# (products, SBM, mid, GAT), the shard shapes (--emulate-rank) and one rank of the papers100M shape from its shard.
+# usage: bash tools/final_profile.sh r04 [hp-partvec workload]
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-tag=${1:-r03}
+tag=${1:-r04}
 HP=${2:-tests/golden/partvec/products4-sbm.A.mtx.8.hp.gz}; W3=${3:-products4}
 out=gpurun_out/final_$tag; rm -rf $out; mkdir -p $out
 timeout 2400 python -m pytest tests -m gpu -q > $out/pytest_gpu_full.txt 2>&1; grep -E "passed|failed|error" $out/pytest_gpu_full.txt | tail -3 | tee $out/pytest_gpu.txt
@@ -23,6 +24,10 @@ pmc reddit_r8h0 reddit rmat 0/8 128 random halo0 --emulate-rank 0/8 --block halo
 pmc reddit_r8l  reddit rmat 0/8 128 random loc --emulate-rank 0/8 --block loc
 pmc products    products rmat 1 128 random loc --workload products
 pmc reddit_sbm  reddit sbm 1 128 random loc --generator sbm
+# BASELINE config 4 on one rank at full size: shard + degree vector made here (6 s on the GPU), then its local block / first halo group
+python tools/make_shards.py --workload papers --ranks 8 --only-rank 0 --device cuda --out /tmp/papers > $out/papers_make_shards.txt 2>&1
+pmc papers_r8l  papers rmat 0/8 64 block loc   --workload papers --shards /tmp/papers --emulate-rank 0/8 --features 64 --block loc
+pmc papers_r8h0 papers rmat 0/8 64 block halo0 --workload papers --shards /tmp/papers --emulate-rank 0/8 --features 64 --block halo0
 cp $out/pmc_traffic.json profiles/pmc_traffic.json      # (bench.py reads it from there for the lines below)
 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1200 $out/bench.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/prof_stdout.log 2> $out/prof_stderr.log
@@ -33,6 +38,9 @@ python bench.py --workload mid --steps 10 --warmup 2 > $out/bench_mid.json 2>/de
 python bench.py --workload reddit-gat --steps 5 --warmup 2 > $out/bench_gat.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_gat -o gat -- python bench.py --workload reddit-gat --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/prof_gat_stdout.log 2> $out/prof_gat_stderr.log
 rm -f $out/prof_gat/*kernel_trace.csv $out/prof_gat/*/*kernel_trace.csv
+python bench.py --workload papers --emulate-rank 0/8 --shards /tmp/papers --partvec block --features 64 --layers 2 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_papers_full_rank_0_8.json 2>/dev/null
+python tools/shard_rank_check.py --shards /tmp/papers --rank 0 --ranks 8 --features 64 > $out/papers_full_rank_0_8_check.json 2>/dev/null
+timeout 120 tools/micro/dense3_bench.bin 1982 0.39 490 > $out/dense3_bench.txt 2>&1
 for rp in 0/8 3/8 7/8 0/4 0/2; do t=$(echo $rp | tr '/' '_')
   python bench.py --emulate-rank $rp --graph --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rank_$t.json 2>/dev/null
 done
