@@ -204,6 +204,7 @@ def build_dense(r64, c64, v, tkey_local, ntiles, tile_row, tile_panel, nrows, nc
 DENSE3_ON = _T.dense_bf16x3
 DENSE3_TAU = _T.dense3_tau
 DENSE3_PIECE = _T.dense3_piece
+DENSE3_MIN_BLOCKS = _T.dense3_min_blocks
 DENSE3_BR = 512    # rows per block (= STRIP_TR: the two tall-tile paths share the row blocking and the 512-row slot blocks)
 
 
@@ -293,7 +294,9 @@ def build_dense3(r64, c64, v, bkey_local, nblocks, blk_row, blk_panel, nrows, nc
 
 
 def split_dense3(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int, tau: float = None):
-    """Separate the entries of 512 x 128 blocks at least ``tau`` full.  Returns (keep_mask or None, HostDense3 or None)."""
+    """Separate the entries of 512 x 128 blocks at least ``tau`` full.  Returns (keep_mask or None, HostDense3 or None).
+    With the default ``tau`` a matrix with fewer than DENSE3_MIN_BLOCKS such blocks keeps them for the other paths."""
+    min_blocks = DENSE3_MIN_BLOCKS if tau is None else 0
     tau = DENSE3_TAU if tau is None else tau
     if r.numel() == 0 or tau > 1.0:
         return None, None
@@ -304,7 +307,7 @@ def split_dense3(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     uniq, inv, cnt = torch.unique(bkey, return_inverse=True, return_counts=True)
     sel = cnt >= max(1, int(tau * BR * TC))
     nb = int(sel.sum())
-    if nb == 0:
+    if nb == 0 or nb < min_blocks:
         return None, None
     is3 = sel[inv]
     bmap = torch.cumsum(sel.to(torch.int64), 0) - 1
@@ -399,8 +402,11 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
     Returns (keep_mask or None, HostStrip or None); ``keep_mask`` marks what stays in the gather part."""
     import numpy as np
     TR, TC, NG, RW, SB = STRIP_TR, CORE_TC, STRIP_NG, STRIP_RW, STRIP_B
-    min_entries = STRIP_MIN if min_entries is None else min_entries
-    layer_min = min(STRIP_LAYER_MIN, max(1, min_entries)) if layer_min is None else layer_min
+    big = r64.numel() >= _T.strip_big_nnz                 # (whole graphs: sparser tiles and layers pay, tuning.py)
+    if layer_min is None:
+        lm = _T.strip_layer_min_big if (big and min_entries is None) else STRIP_LAYER_MIN
+    min_entries = (_T.strip_min_big if big else STRIP_MIN) if min_entries is None else min_entries
+    layer_min = min(lm, max(1, min_entries)) if layer_min is None else layer_min
     dev = r64.device
     if r64.numel() == 0 or ncols < TC:       # (a panel is a window of 128 operand rows)
         return None, None

@@ -42,12 +42,17 @@ class Tuning:
                                      # products) instead of the fp32-MFMA tiles
     dense3_tau: float = 0.20         # blocks at least this full (of 65 536) take that path (r04 sweep on the benchmark graph,
                                      # SpMM launch group: off 1.742 ms, 0.12 1.724, 0.16 1.728, 0.20 1.685, 0.26 1.796)
-    dense3_piece: int = 0            # blocks per piece (0 = adaptive: ~512 pieces, between 1 and 8 blocks)
+    dense3_piece: int = 0            # blocks per piece (0 = adaptive: one round of 256 pieces, between 1 and 8 blocks)
+    dense3_min_blocks: int = 400     # matrices with fewer such blocks leave their entries to the strips / the LDS core (a shard of an
+                                     # 8-way run: two more launches and 512-row partial blocks for a few dozen blocks: rank 0 of 8,
+                                     # epoch 3.33 ms with them, 3.20 without)
     strip: bool = True               # 512 x 128 strip tiles
-    strip_min: int = 256             # stored entries that make a strip tile worth staging ...
-    strip_layer_min: int = 192       # ... and one more layer (record) of a tile worth it (r02: 512 / 384; r04 re-sweep with the bf16
-                                     # blocks in -- a flat optimum, the gather part and the strips trade time about 1 : 1:
-                                     # 384 / 256 / 192 / 128 at strip_min 512 -> 1.645 / 1.652 / 1.648 / 1.666 ms; 192 with strip_min 256 -> 1.622)
+    strip_min: int = 512             # stored entries that make a strip tile worth staging ...
+    strip_layer_min: int = 384       # ... and one more layer (record) of a tile worth it (r02 sweep)
+    strip_big_nnz: int = 50000000    # matrices with at least this many entries (whole graphs: the gather part is bound by fabric
+    strip_min_big: int = 256         # reads there, 250 B per entry against 44 B in the strips) take sparser tiles and layers: r04
+    strip_layer_min_big: int = 192   # re-sweep on the benchmark graph, a flat optimum -- 512/384 1.645 ms, 256/192 1.622 ms; an 8-way
+                                     # shard prefers the r02 values (halo group 0.265 vs 0.298 ms)
     strip_min_records: int = 4096    # blocks with fewer records keep the 128 x 128 LDS core instead (r03: shards of an
                                      # 8-way run: 1.1 k records lose, 4.9 k break even, 8.6 k and 14.9 k win 9-15 %)
     strip_pieces: int = 1024         # upper bound of the strip work pieces (records / 64, in multiples of 256 CUs)

@@ -136,7 +136,7 @@ def test_spmm_dense_core_lds_kernel(K, dev, f, nslices):
     assert h.core is not None and h.core.nnz > 0.2 * A.nnz and h.ngroups == (3 if nslices > 1 else 1)
     d = K.prepare(h)
     assert d.core is not None
-    assert d.nslots_total == d.nslots + h.core.nslots + (h.dense.nslots if h.dense is not None else 0)
+    assert d.nslots_total == d.nslots + h.core.nslots + sum(x.nslots for x in (h.dense, h.dense3) if x is not None)
     rng = np.random.default_rng(f)
     B = rng.random((n, f), dtype=np.float32) * 2 - 1
     ref = oracle.spmm(A, B)

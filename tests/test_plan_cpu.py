@@ -42,7 +42,7 @@ VARIANTS = {
     "gather_sliced_short_tasks": (dict(nslices=8, core=False), dict(chunk=64, small_row=16, adaptive_chunk=False), ()),
     "gather_unsliced_long_rows": (dict(nslices=1, core=False), dict(chunk=128, adaptive_chunk=False), ()),
     "gather_column_groups": (dict(nslices=8, core=False, ngroups=4), {}, ()),
-    "range_slices": (dict(core=True, strip=True, strip_min=64, slice_bounds=[0, 40, 100, 250, 600, 1100, 1700, 2400, 3000]), {},
+    "range_slices": (dict(core=True, strip=True, strip_min=64, dense3_tau=0.15, slice_bounds=[0, 40, 100, 250, 600, 1100, 1700, 2400, 3000]), {},
                      ("strip", "dense3")),
 }
 
@@ -247,12 +247,14 @@ def test_attention_structures_of_a_rank():
     assert np.array_equal(br.numpy(), fc.numpy()[perm]) and np.array_equal(bc.numpy(), fr.numpy()[perm])
 
 
-def test_default_tuning_on_a_dense_graph_reaches_every_tile_path():
+def test_default_tuning_on_a_dense_graph_reaches_every_tile_path(monkeypatch):
     """The Reddit shape at 1/8 of its vertices with its average degree (492 stored entries per row) under the SHIPPED
-    tuning, through build_partition as bench.py calls it: one rank gets strip tiles + MFMA tiles (and the same for the
-    pre-built transpose), a rank of four gets a gather-only local block and a halo block with LDS-core + MFMA tiles.
+    tuning (except that this small matrix may keep its 150 bf16 blocks: the shipped minimum is 400), through
+    build_partition as bench.py calls it: one rank gets strip tiles + bf16 blocks (and the same for the pre-built
+    transpose), a rank of four gets a gather-only local block and a tiled halo block.
     Forward through the plans = (A . H)[owned rows], transposed block = A^T . H."""
     partition, synth = pkg("partition"), pkg("synth")
+    monkeypatch.setattr(partition, "DENSE3_MIN_BLOCKS", 0)
     n, row, col, val = synth.make_graph(29120, 14326986, seed=0)
     A = sp.csr_matrix((val.numpy().astype(np.float64), (row.numpy(), col.numpy())), shape=(n, n))
     H = np.random.default_rng(0).standard_normal((n, 2))
@@ -276,7 +278,7 @@ def test_default_tuning_on_a_dense_graph_reaches_every_tile_path():
 
 
 @pytest.mark.parametrize("tuning,parts1,parts3,rounds3", [
-    ("core_min_nnz=0,core_min_frac=0,strip_min_records=0,exchange_rounds=3", "s3", "s3", 3),     # strips + bf16 blocks on a shard too
+    ("core_min_nnz=0,core_min_frac=0,strip_min_records=0,dense3_min_blocks=0,exchange_rounds=3", "s3", "s3", 3),   # strips + bf16 blocks on a shard too
     ("dense_bf16x3=0,core_min_nnz=0,core_min_frac=0,strip_min_records=0", "sd", "sd", 2),        # the fp32-MFMA tiles instead
     ("strip=0,dense_bf16x3=0,core_min_nnz=0,core_emax=500,exchange_rounds=1", "cd", "cd", 1),    # LDS core with short pieces
     ("tiles=0,slices=1,spmm_chunk=64,spmm_adaptive_chunk=0", "-", "-", 2),                       # gather only, unsliced, short tasks

@@ -25,7 +25,7 @@ def main():
     per, cur = {}, None
     only = sys.argv[10] if len(sys.argv) > 10 else None     # keep ONE kernel: a substring of its name incl. template arguments
     for ln in txt:
-        m = re.search(r"counter_collection\.csv \| .*::(\w+)<", ln)
+        m = re.search(r"counter_collection\.csv \| .*::(\w+)[<(]", ln)
         if m:
             if only is not None and only not in ln:
                 cur = None
@@ -37,7 +37,7 @@ def main():
             cur[m.group(1)] = float(m.group(3))
         if "kernel_trace.csv" in ln:
             cur = None
-            m = re.search(r"::(\w+)<.*mean=([\d.]+) us", ln)
+            m = re.search(r"::(\w+)[<(].*mean=([\d.]+) us", ln)
             if m and (only is None or only in ln):
                 per.setdefault(m.group(1), {}).setdefault("mean_us", float(m.group(2)))
     read = sum(2 * 1024 * v.get("FETCH_SIZE", 0) for v in per.values())
