@@ -888,7 +888,10 @@ def main():
         if getattr(eng.A_loc, "dense3", None) is not None:
             kname += " + spmm_split_panels_kernel + spmm_dense3_kernel<4> (512x128 blocks on the bf16 matrix cores, three-plane split at fp32 accuracy, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.dense3.nnz / max(eng.A_loc.nnz, 1))
-        kname += " + fix-up; one launch group, timed as a whole"
+        if partition._T.lanes and eng.A_loc.nnz >= partition._T.lanes_min_nnz and "/" in partition._T.lanes:
+            kname += " + fix-up; one launch group on two streams (lanes %s), timed as a whole" % partition._T.lanes
+        else:
+            kname += " + fix-up; one launch group, timed as a whole"
         roofline = {"bound": "hbm", "kernel": kname,
                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
@@ -903,14 +906,15 @@ def main():
         try:
             K.spmm = timer._spmm
             real_lib, K.lib = K.lib, SplitTimer(K.lib)
+            K.single_lane = True                # (the split is of the kernels one after the other, whatever tuning.lanes says)
             eng.A_loc.launch_cache.clear()
             Csplit = torch.empty((part.n_local, f), device=dev)
             with torch.no_grad():
                 for _ in range(5):
                     K.spmm(eng.A_loc, H.detach(), Csplit)
             torch.cuda.synchronize()
-            roofline["split_us"] = K.lib.summary_us()
-            K.lib = real_lib
+            roofline["split_us"] = K.lib.summary_us()         # the kernels one after the other on one stream (lanes off)
+            K.lib, K.single_lane = real_lib, False
             eng.A_loc.launch_cache.clear()
         except Exception as e:
             roofline["split_us"] = {"error": repr(e)}
@@ -955,7 +959,10 @@ def main():
                    "strip_tiles": {"min_entries": partition.STRIP_MIN, "layer_min": partition.STRIP_LAYER_MIN,
                                    "whole_graphs_from_nnz": partition._T.strip_big_nnz, "min_entries_big": partition._T.strip_min_big,
                                    "layer_min_big": partition._T.strip_layer_min_big}
-                   if partition.STRIP_ON else None},
+                   if partition.STRIP_ON else None,
+                   "launch_lanes": ({"lanes": partition._T.lanes, "from_nnz": partition._T.lanes_min_nnz,
+                                     "on_for_this_block": bool(partition._T.lanes and eng.A_loc.nnz >= partition._T.lanes_min_nnz)}
+                                    if hasattr(partition._T, "lanes") else None)},
         "roofline": roofline, "ms_per_epoch": ms_per_step, "loss": loss_val, "setup_s": setup_s,
         "setup_stages_s": {"process_start_to_main": round(t_start - PROCESS_T0, 3), **{k: v for k, v in stages}},
     }

@@ -177,6 +177,8 @@ class HipKernels:
         # "auto": 64 where the operand panel (>= 96 MB) is several times the aggregate L2 and the gather part holds
         # >= 8 M entries -- whole graphs; a rank's shard of an 8-way run loses 15 % with them: tools/rank_probe.py, r02)
         self.fpass = _T.fpass
+        self.sides = []                   # extra streams of tuning.lanes, made on first use
+        self.single_lane = False          # bench.py's per-kernel split: everything on the current stream
         if self.fpass == "64":
             self.base_flags |= _lib.SPMM_FPASS64
         self.chunk = chunk
@@ -378,21 +380,49 @@ class HipKernels:
         fixp, nfa, slots = A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr()
         gflags, fflags = flags | _lib.SPMM_NO_FIXUP, flags & _lib.SPMM_ACCUMULATE
 
-        def hybrid(B, C):
-            b, c, s = B.data_ptr(), C.data_ptr(), stream()
-            if ntasks:
+        # launch lanes (tuning.lanes): "strip/gather+dense3" = the strips on a second stream, the gather part and then the bf16 blocks
+        # on the current one ("/" separates lanes, launched in the order written; the LAST lane is the current stream).  The producers
+        # only write their own partial rows; the fix-up waits for every lane.  Fork and join are events: legal inside a HIP-graph capture.
+        present = [n for n, on in (("gather", ntasks), ("strip", st is not None), ("dense3", d3 is not None)) if on]
+        spec = "gather+strip+dense3" if (self.single_lane or not _T.lanes or A.nnz < _T.lanes_min_nnz) else _T.lanes
+        lanes = [[x for x in lane.split("+") if x] for lane in spec.split("/")]
+        if sorted(x for lane in lanes for x in lane) != ["dense3", "gather", "strip"]:
+            raise _lib.PgcnError("tuning.lanes must name gather, strip and dense3 once each (lanes by /, order by +), got %r" % spec)
+        lanes = [[x for x in lane if x in present] for lane in lanes]
+        lanes = [lane for lane in lanes[:-1] if lane] + [lanes[-1]]
+        while len(self.sides) < len(lanes) - 1:
+            self.sides.append(torch.cuda.Stream(self.device))
+        sides = self.sides
+        dev, nside = self.device, len(lanes) - 1
+
+        def launch(name, b, c, s):
+            if name == "gather":
                 check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, None, 0, rmap, b, ldb,
                                                  c, ldc, f, ws, ws_n, nslots, gflags, s), "pgcn_spmm_csr_plan_f32")
-            if st is not None:
+            elif name == "strip":
                 check(lib.pgcn_spmm_strip_f32(sw, sn, srec, spairs, b, ldb, ncols, f, ws, ws_n, nst, s), "pgcn_spmm_strip_f32")
-            if d3 is not None:
+            else:
                 check(lib.pgcn_spmm_dense_bf16x3_f32(w3, n3, bi3, v3, pl3, np3, b, ldb, ncols, f, img3, imgb3, ws, ws_n, nst, s),
                       "pgcn_spmm_dense_bf16x3_f32")
+
+        def hybrid(B, C):
+            b, c, s = B.data_ptr(), C.data_ptr(), stream()
+            if nside:
+                cur = torch.cuda.current_stream(dev)
+                for i in range(nside):
+                    sides[i].wait_stream(cur)
+                    o = sides[i].cuda_stream
+                    for name in lanes[i]:
+                        launch(name, b, c, o)
+            for name in lanes[-1]:
+                launch(name, b, c, s)
             if de is not None:
                 check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s), "pgcn_spmm_dense_f32")
             if co is not None:
                 check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, s),
                       "pgcn_spmm_core_f32")
+            for i in range(nside):
+                cur.wait_stream(sides[i])
             check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, c, ldc, f, fflags, s), "pgcn_spmm_fixup_f32")
         return hybrid
 

@@ -49,14 +49,19 @@ class Tuning:
     strip: bool = True               # 512 x 128 strip tiles
     strip_min: int = 512             # stored entries that make a strip tile worth staging ...
     strip_layer_min: int = 384       # ... and one more layer (record) of a tile worth it (r02 sweep)
-    strip_big_nnz: int = 50000000    # matrices with at least this many entries (whole graphs: the gather part is bound by fabric
+    strip_big_nnz: int = 20000000    # matrices with at least this many entries (whole graphs, halves: the gather part is bound by fabric
     strip_min_big: int = 256         # reads there, 250 B per entry against 44 B in the strips) take sparser tiles and layers: r04
     strip_layer_min_big: int = 192   # re-sweep on the benchmark graph, a flat optimum -- 512/384 1.645 ms, 256/192 1.622 ms; an 8-way
-                                     # shard prefers the r02 values (halo group 0.265 vs 0.298 ms)
+                                     # shard prefers the r02 values (halo group 0.265 vs 0.298 ms); the 28 M-entry blocks of a 2-way run the
+                                     # sparse ones (epoch 7.56 vs 7.96 ms)
     strip_min_records: int = 4096    # blocks with fewer records keep the 128 x 128 LDS core instead (r03: shards of an
                                      # 8-way run: 1.1 k records lose, 4.9 k break even, 8.6 k and 14.9 k win 9-15 %)
     strip_pieces: int = 1024         # upper bound of the strip work pieces (records / 64, in multiples of 256 CUs)
     strip_stage_cost: float = 1.0    # staging a panel ~ this many records of work (piece balancing)
+    lanes: str = "strip/gather+dense3"  # launch lanes of the producers of one product: the LDS-bound strips on a second stream beside the gather
+                                     # part and the bf16 blocks (r04, Reddit shape: one stream 1.610 ms, this 1.545; strips + dense3 beside the
+                                     # gather 1.572, three streams 1.57-1.58; lanes confined to disjoint CU ranges 2.9-5.8 ms: profiles/r04_lanes.txt)
+    lanes_min_nnz: int = 20000000    # smaller matrices keep one stream
     # ---- vertex order ---------------------------------------------------------------------------------------
     degree_sort: bool = True
     order: str = "auto"              # degree | community | auto (label propagation, kept when it finds structure)

@@ -282,6 +282,54 @@ def test_spmm_bf16x3_blocks(K, dev, f, nslices):
     assert rel_err(got[:, 1:], ref[:, 1:]) < TOL
 
 
+@pytest.mark.parametrize("lanes", ["strip/gather+dense3", "strip/dense3/gather", "dense3+strip/gather", "gather+strip+dense3"])
+def test_spmm_launch_lanes_bit_identical(K, dev, lanes, monkeypatch):
+    """tuning.lanes: the producers of one product on two or three streams write the same partial rows and the fix-up adds
+    them in the same order -- the result equals the one-stream result bit for bit, launched eagerly, back to back on the
+    same work-space, and as a replayed HIP graph (fork and join are events inside the capture)."""
+    partition, tuning = pkg("partition"), pkg("tuning")
+    rng = np.random.default_rng(77)
+    n, m, f = 2100, 900, 128
+    D = (rng.random((n, m)) < 0.02).astype(np.float32)
+    D[:1024, :256] = rng.random((1024, 256)) < 0.5           # bf16 blocks
+    D[:1536, 256:640] = rng.random((1536, 384)) < 0.08       # strip tiles
+    D *= rng.standard_normal((n, m)).astype(np.float32)
+    A = sp.csr_matrix(D)
+    h = partition.csr_from_scipy(A, nslices=8, core=True, strip=True, strip_min=32, dense3_tau=0.2)
+    assert h.dense3 is not None and h.strip is not None and h.nnz == A.nnz
+    d = K.prepare(h)
+    assert d.ntasks > 0
+    Bd = torch.from_numpy(rng.standard_normal((m, f)).astype(np.float32)).to(dev)
+    B2 = torch.from_numpy(rng.standard_normal((m, f)).astype(np.float32)).to(dev)
+    K.single_lane = True
+    try:
+        want, want2 = torch.empty((n, f), device=dev), torch.empty((n, f), device=dev)
+        K.spmm(d, Bd, want); K.spmm(d, B2, want2)
+    finally:
+        K.single_lane = False
+    assert rel_err(want.cpu().numpy(), oracle.spmm(A, Bd.cpu().numpy())) < TOL
+    monkeypatch.setattr(tuning.T, "lanes", lanes)
+    monkeypatch.setattr(tuning.T, "lanes_min_nnz", 0)
+    d.launch_cache.clear()
+    nside = lanes.count("/")
+    got, got2 = torch.full((n, f), float("nan"), device=dev), torch.full((n, f), float("nan"), device=dev)
+    for _ in range(3):                                       # back to back: the second product re-uses the first one's work-space
+        K.spmm(d, Bd, got); K.spmm(d, B2, got2)
+    torch.cuda.synchronize()
+    assert len(K.sides) >= nside
+    assert torch.equal(got, want) and torch.equal(got2, want2)
+    g = torch.cuda.CUDAGraph()
+    cg, cg2 = torch.zeros((n, f), device=dev), torch.zeros((n, f), device=dev)
+    with torch.cuda.graph(g):
+        K.spmm(d, Bd, cg); K.spmm(d, B2, cg2)
+    for _ in range(2):
+        cg.fill_(float("nan")); cg2.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cg, want) and torch.equal(cg2, want2)
+    d.launch_cache.clear()
+
+
 @pytest.mark.parametrize("f", [4, 30, 64, 128, 132, 256])
 @pytest.mark.parametrize("nslices", [1, 8])
 def test_spmm_strip_tiles(K, dev, f, nslices):
