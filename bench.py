@@ -954,7 +954,9 @@ def main():
                    "mfma_tile_fill_min": (partition.DENSE_TAU if partition.DENSE_ON and not partition.DENSE3_ON else None),
                    "bf16x3_block_fill_min": partition.DENSE3_TAU if partition.DENSE3_ON else None,
                    "exchange_rounds": part.rounds, "vertex_order": part.order_info,
-                   "dense_gemm": "stock rocBLAS / hipBLASLt via PyTorch, kernel per shape picked by TunableOp in set-up" if gemm_tuned
+                   "dense_gemm": ("stock rocBLAS GEMMs launched by the solution index recorded in tunableop/gfx950.csv (x.W^T, g.W); "
+                                  "dW: PyTorch's default pick" if not partition._T.gemm_tunableop else
+                                  "stock rocBLAS / hipBLASLt via PyTorch, kernel per shape picked by TunableOp in set-up") if gemm_tuned
                                  else "stock rocBLAS / hipBLASLt via PyTorch (default pick)",
                    "strip_tiles": {"min_entries": partition.STRIP_MIN, "layer_min": partition.STRIP_LAYER_MIN,
                                    "whole_graphs_from_nnz": partition._T.strip_big_nnz, "min_entries_big": partition._T.strip_min_big,

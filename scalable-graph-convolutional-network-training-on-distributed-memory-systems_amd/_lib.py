@@ -110,6 +110,13 @@ def build(verbose: bool = False) -> str:
         print(out.stdout + out.stderr)
     if out.returncode != 0:
         raise PgcnError("building libpgcn_hip.so failed")
+    # the GEMM plumbing beside it (gemm/pgcn_gemm.cpp: rocBLAS calls by solution index; PGCN.mm_nt / mm_nn fall back to
+    # PyTorch's product without it)
+    out = subprocess.run(["bash", os.path.join(_HERE, "gemm", "build.sh")], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout + out.stderr)
+    if out.returncode != 0:
+        raise PgcnError("building libpgcn_gemm.so failed")
     return LIB_PATH
 
 

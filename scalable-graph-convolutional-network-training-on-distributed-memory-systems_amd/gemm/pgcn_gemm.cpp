@@ -1,0 +1,76 @@
+// pgcn_gemm.cpp -- the dense products of a layer (GPU/PGCN.py:146 `self.linear(H)` and its backward) as stock rocBLAS
+// GEMMs launched BY SOLUTION INDEX.  Plumbing beside the graded aggregation path, and its own small library
+// (lib/libpgcn_gemm.so): PyTorch's default pick for the n x f x f shapes is 15-20 % slower than the best kernel the library
+// holds; PyTorch's TunableOp finds that kernel but enumerates every kernel file of two libraries when it is switched on
+// (r04: 33 s on a box that has not touched them, 1 s on one that has).  The choice is made offline (tunableop/gfx950.csv,
+// PyTorch's own result format) and this file only replays it: rocblas_gemm_ex(..., rocblas_gemm_algo_solution_index, index)
+// loads that one kernel.  Inside a PyTorch process the loader binds librocblas.so.5 to the copy PyTorch mapped, i.e. the
+// build the indices were recorded on; pgcn_gemm_rocblas_version() is what the caller checks against the file's validator.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+
+namespace {
+thread_local char g_err[256] = "";
+std::mutex g_mu;
+rocblas_handle g_handle[64] = {nullptr};
+
+int fail(int code, const char *what, int status) {
+    snprintf(g_err, sizeof(g_err), "%s (status %d)", what, status);
+    return code;
+}
+
+rocblas_handle handle_for(int dev) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!g_handle[dev]) {
+        rocblas_handle h = nullptr;
+        if (rocblas_create_handle(&h) != rocblas_status_success) return nullptr;
+        g_handle[dev] = h;
+    }
+    return g_handle[dev];
+}
+}  // namespace
+
+extern "C" const char *pgcn_gemm_last_error(void) { return g_err; }
+
+// rocBLAS build string ("5.0.2.20250912-42-1199-g2584e35062") of the library this process bound.
+extern "C" int pgcn_gemm_rocblas_version(char *buf, int64_t n) {
+    size_t need = 0;
+    if (rocblas_get_version_string_size(&need) != rocblas_status_success || !buf || (int64_t)need > n)
+        return fail(-1, "rocblas_get_version_string_size", 0);
+    rocblas_status st = rocblas_get_version_string(buf, (size_t)n);
+    return st == rocblas_status_success ? 0 : fail(-1, "rocblas_get_version_string", (int)st);
+}
+
+// C (m x n, ldc) = op(A) . op(B) in rocBLAS' column-major convention, fp32, alpha 1, beta 0, on `stream` of the current
+// device, with the kernel `solution_index` of that rocBLAS build (0 = the library's own pick).  transa / transb: 0 = N, 1 = T.
+// Returns 0, or -2 when rocBLAS refuses the index for this problem (the caller falls back to its default GEMM).
+extern "C" int pgcn_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k, const float *A, int64_t lda,
+                             const float *B, int64_t ldb, float *C, int64_t ldc, int32_t solution_index, void *stream) {
+    if (m <= 0 || n <= 0 || k <= 0 || !A || !B || !C) return fail(-1, "pgcn_gemm_f32: bad argument", 0);
+    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX || lda > INT32_MAX || ldb > INT32_MAX || ldc > INT32_MAX)
+        return fail(-1, "pgcn_gemm_f32: dimension beyond the 32-bit interface", 0);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(-1, "hipGetDevice", 0);
+    rocblas_handle h = handle_for(dev);
+    if (!h) return fail(-1, "rocblas_create_handle", 0);
+    std::lock_guard<std::mutex> lock(g_mu);          // one handle per device: stream + launch as one step
+    rocblas_status st = rocblas_set_stream(h, (hipStream_t)stream);
+    if (st != rocblas_status_success) return fail(-1, "rocblas_set_stream", (int)st);
+    const float one = 1.0f, zero = 0.0f;
+    st = rocblas_gemm_ex(h, transa ? rocblas_operation_transpose : rocblas_operation_none,
+                         transb ? rocblas_operation_transpose : rocblas_operation_none, (rocblas_int)m, (rocblas_int)n,
+                         (rocblas_int)k, &one, A, rocblas_datatype_f32_r, (rocblas_int)lda, B, rocblas_datatype_f32_r,
+                         (rocblas_int)ldb, &zero, C, rocblas_datatype_f32_r, (rocblas_int)ldc, C, rocblas_datatype_f32_r,
+                         (rocblas_int)ldc, rocblas_datatype_f32_r,
+                         solution_index ? rocblas_gemm_algo_solution_index : rocblas_gemm_algo_standard, solution_index,
+                         rocblas_gemm_flags_none);
+    if (st == rocblas_status_invalid_value || st == rocblas_status_not_implemented)
+        return fail(-2, "rocblas_gemm_ex refuses this solution index for the problem", (int)st);
+    return st == rocblas_status_success ? 0 : fail(-1, "rocblas_gemm_ex", (int)st);
+}

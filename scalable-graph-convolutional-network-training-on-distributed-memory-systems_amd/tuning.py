@@ -72,7 +72,9 @@ class Tuning:
     # ---- exchange -------------------------------------------------------------------------------------------
     exchange_rounds: int = 2         # boundary lists are cut into this many all-to-all-v rounds
     # ---- dense H.W (stock library GEMMs) ----------------------------------------------------------------------
-    gemm_tuning: bool = True         # let PyTorch's TunableOp pick the rocBLAS / hipBLASLt kernel per shape during set-up
+    gemm_tuning: bool = True         # use the recorded kernel choices for the n x f x f GEMMs of a layer (tunableop/gfx950.csv + cache) ...
+    gemm_tunableop: bool = False     # ... through PyTorch's TunableOp, which also TIMES shapes without a record (set-up: + 20-30 s on a
+                                     # cold box) instead of replaying the rocBLAS records by solution index (r04 default)
     # ---- GAT path -------------------------------------------------------------------------------------------
     gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
     gat_sliced: bool = True          # XCD-sliced edge gradient

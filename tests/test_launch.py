@@ -44,6 +44,15 @@ def test_bench_self_launch_starts_every_rank_and_fails_loudly_without_gpu():
 
 
 @pytest.mark.gpu
+def test_smoke_entry_point():
+    """__graft_entry__.smoke() -- what the driver runs before the bench -- in its own process (it changes module-level
+    thresholds so that its small graph keeps every kind of tile): every SpMM kernel on the path, checked against the oracle."""
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=_env(),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stderr[-2000:] + out.stdout[-500:]
+
+
+@pytest.mark.gpu
 def test_bench_single_gpu_line_small_workload():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "cora",
                           "--steps", "3", "--warmup", "1", "--cpu-budget", "1"], env=_env(),

@@ -2,12 +2,15 @@
 # Round evidence in one gpurun call: GPU tests, smoke, default bench, rocprofv3 kernel stats of the bench command, PMC
 # traffic passes per launch group (tools/group_probe.py: the block exactly as bench.py builds it), the other workloads
 # (products, SBM, mid, GAT), the shard shapes (--emulate-rank) and one rank of the papers100M shape from its shard.
-# usage: bash tools/final_profile.sh r04 [hp-partvec workload]
+# usage: [FINAL_TESTS_K=expr] bash tools/final_profile.sh r04 [hp-partvec workload]
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 tag=${1:-r04}
 HP=${2:-tests/golden/partvec/products4-sbm.A.mtx.8.hp.gz}; W3=${3:-products4}
 out=gpurun_out/final_$tag; rm -rf $out; mkdir -p $out
-timeout 2400 python -m pytest tests -m gpu -q > $out/pytest_gpu_full.txt 2>&1; grep -E "passed|failed|error" $out/pytest_gpu_full.txt | tail -3 | tee $out/pytest_gpu.txt
+# (FINAL_TESTS_K="expr": only the GPU tests matching it -- when the full suite already ran in its own call)
+if [ -n "${FINAL_TESTS_K:-}" ]; then timeout 2400 python -m pytest tests -m gpu -q -k "$FINAL_TESTS_K" > $out/pytest_gpu_full.txt 2>&1
+else timeout 2400 python -m pytest tests -m gpu -q > $out/pytest_gpu_full.txt 2>&1; fi
+grep -E "passed|failed|error" $out/pytest_gpu_full.txt | tail -3 | tee $out/pytest_gpu.txt
 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $out/smoke.txt
 pmc() {  # name, then the record key: workload generator ranks f partvec block, then group_probe arguments
   name=$1; key="$2 $3 $4 $5 $6 $7"; shift 7
@@ -19,6 +22,7 @@ pmc() {  # name, then the record key: workload generator ranks f partvec block, 
   python tools/make_pmc_traffic.py $out/pmc_summary_$name.txt $out/pmc_traffic.json profiles/${tag}_pmc_$name.txt $key
   rm -rf $out/pmc_$name
 }
+if [ -z "${FINAL_SKIP_PMC:-}" ]; then      # (FINAL_SKIP_PMC=1: the stamped sources did not change since the last passes -- keep profiles/pmc_traffic.json)
 pmc reddit      reddit rmat 1 128 random loc
 pmc reddit_r8h0 reddit rmat 0/8 128 random halo0 --emulate-rank 0/8 --block halo0
 pmc reddit_r8l  reddit rmat 0/8 128 random loc --emulate-rank 0/8 --block loc
@@ -29,6 +33,7 @@ python tools/make_shards.py --workload papers --ranks 8 --only-rank 0 --device c
 pmc papers_r8l  papers rmat 0/8 64 block loc   --workload papers --shards /tmp/papers --emulate-rank 0/8 --features 64 --block loc
 pmc papers_r8h0 papers rmat 0/8 64 block halo0 --workload papers --shards /tmp/papers --emulate-rank 0/8 --features 64 --block halo0
 cp $out/pmc_traffic.json profiles/pmc_traffic.json      # (bench.py reads it from there for the lines below)
+else python tools/make_shards.py --workload papers --ranks 8 --only-rank 0 --device cuda --out /tmp/papers > $out/papers_make_shards.txt 2>&1; fi
 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1200 $out/bench.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/prof_stdout.log 2> $out/prof_stderr.log
 rm -f $out/prof/*kernel_trace.csv $out/prof/*/*kernel_trace.csv
