@@ -254,8 +254,9 @@ def _gemm_direct_call(trans, w, x, m, n, k):
     """out (n x m, row-major) = the recorded rocBLAS kernel for key (trans, m, n, k, ...) on `w` (A operand) and `x` (B), or
     None when there is no record / the operands do not fit it / rocBLAS refuses."""
     table = _gemm_direct_table()
-    if not table or not (x.is_cuda and x.dtype is torch.float32 and w.dtype is torch.float32 and x.dim() == 2 and w.dim() == 2
-                         and x.stride(1) == 1 and w.stride(1) == 1):
+    if not table or not (x.is_cuda and w.device == x.device and x.dtype is torch.float32 and w.dtype is torch.float32
+                         and x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+                         and x.device.index == torch.cuda.current_device()):       # (the library launches on the CURRENT device)
         return None
     key = (trans, m, n, k, w.stride(0), x.stride(0), m)
     idx = table.get(key)
