@@ -22,6 +22,27 @@ int pgcn_gemm_rocblas_version(char *buf, int64_t n);
 int pgcn_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k, const float *A, int64_t lda,
                   const float *B, int64_t ldb, float *C, int64_t ldc, int32_t solution_index, void *stream);
 
+/* ---- the same products as the package's own matrix-core kernels (source: <package>/gemm/pgcn_dense.hip) -----------------------
+ * v_mfma_f32_32x32x16_bf16 on a three-plane bf16 split of both operands (six partial products, fp32 accumulation: the error
+ * class of an fp32 dot product), one persistent workgroup per CU with the split weight matrix in LDS, fused with the
+ * element-wise passes either side.  Replaces `F.relu(self.linear(AH))` (GPU/PGCN.py:146-147) and the autograd of those two
+ * lines.  Row-major operands, fp32, leading dimensions in elements; widths (fin, fout) up to 128; the streamed operands
+ * (X; G, Y, Gm) need 16-byte aligned bases, leading dimensions that are multiples of 4 and a width that is a multiple of 4.
+ * Return 0; -2 for operands outside that (nothing was launched: the caller runs the library product); -1 for errors
+ * (pgcn_dense_last_error()).  Binding: <package>/PGCN.py (linear_relu_fused, linear_relu_grad_input_fused), selected by
+ * tuning.dense_fused. */
+const char *pgcn_dense_last_error(void);
+
+/* Y (n x fout, ldy) = relu ? max(X . W^T, 0) : X . W^T;   X: n x fin (ldx);  W: fout x fin (ldw), nn.Linear's weight */
+int pgcn_linear_relu_f32(const float *X, int64_t ldx, int64_t n, int32_t fin, const float *W, int64_t ldw, int32_t fout,
+                         float *Y, int64_t ldy, int32_t relu, void *stream);
+
+/* Gm = G where Y > 0, else 0 (n x fout, ldgm; written when Gm != NULL -- the operand of the weight gradient; Gm == G is
+ * allowed);  dX (n x fin, lddx) = Gm . W.   G, Y: n x fout (ldg, ldy);  W: fout x fin (ldw) */
+int pgcn_linear_relu_grad_input_f32(const float *G, int64_t ldg, const float *Y, int64_t ldy, float *Gm, int64_t ldgm,
+                                    int64_t n, int32_t fout, const float *W, int64_t ldw, int32_t fin, float *dX,
+                                    int64_t lddx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

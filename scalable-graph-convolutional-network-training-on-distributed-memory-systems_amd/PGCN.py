@@ -283,6 +283,97 @@ def mm_nn(g, weight):
     return out if out is not None else g @ weight
 
 
+# ---- relu(x . W^T) and its input gradient as the package's own matrix-core kernels (gemm/pgcn_dense.hip) ---------------------
+_dense = {"lib": None}
+
+
+def bind_dense_library(path):
+    """ctypes handle of a library that exports the entry points of include/pgcn_gemm.h's second half (lib/libpgcn_gemm.so;
+    the tests also bind the host emulation build of gemm/pgcn_dense.hip)."""
+    import ctypes
+    L = ctypes.CDLL(path)
+    i32, i64, ptr = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    L.pgcn_linear_relu_f32.restype = ctypes.c_int
+    L.pgcn_linear_relu_f32.argtypes = [ptr, i64, i64, i32, ptr, i64, i32, ptr, i64, i32, ptr]
+    L.pgcn_linear_relu_grad_input_f32.restype = ctypes.c_int
+    L.pgcn_linear_relu_grad_input_f32.argtypes = [ptr, i64, ptr, i64, ptr, i64, i64, i32, ptr, i64, i32, ptr, i64, ptr]
+    L.pgcn_dense_last_error.restype = ctypes.c_char_p
+    return L
+
+
+def _dense_lib():
+    """lib/libpgcn_gemm.so; raises when the library or the entry points are missing (tuning.dense_fused asked for them:
+    no silent detour)."""
+    if _dense["lib"] is None:
+        if not os.path.exists(GEMM_LIB_PATH):
+            raise RuntimeError("tuning.dense_fused: %s is missing (run __graft_entry__.build())" % GEMM_LIB_PATH)
+        _dense["lib"] = bind_dense_library(GEMM_LIB_PATH)
+    return _dense["lib"]
+
+
+def _dense_operand_ok(*ts):
+    return all(t.is_cuda and t.dtype is torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.device == ts[0].device
+               for t in ts) and ts[0].device.index == torch.cuda.current_device()
+
+
+def _dense_stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def linear_relu_call(L, x, weight, relu, stream):
+    """[relu](x . weight^T) through pgcn_linear_relu_f32 of `L` on `stream`, or None when the entry point does not take the
+    operands (-2).  x: n x fin, weight: fout x fin, unit inner strides."""
+    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1] or x.stride(1) != 1 or weight.stride(1) != 1:
+        return None
+    y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
+    rc = L.pgcn_linear_relu_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], weight.data_ptr(), weight.stride(0),
+                                weight.shape[0], y.data_ptr(), y.stride(0), 1 if relu else 0, stream)
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError("pgcn_linear_relu_f32: %s" % L.pgcn_dense_last_error().decode())
+    return y
+
+
+def linear_relu_grad_input_call(L, g, y, weight, stream):
+    """(g (.) [y > 0], that . weight) through pgcn_linear_relu_grad_input_f32 of `L`, or None (-2).  g, y: n x fout,
+    weight: fout x fin."""
+    if g.dim() != 2 or g.shape != y.shape or weight.dim() != 2 or g.shape[1] != weight.shape[0] or \
+            g.stride(1) != 1 or y.stride(1) != 1 or weight.stride(1) != 1:
+        return None
+    gm = torch.empty_like(g, memory_format=torch.contiguous_format)
+    gx = torch.empty((g.shape[0], weight.shape[1]), dtype=torch.float32, device=g.device)
+    rc = L.pgcn_linear_relu_grad_input_f32(g.data_ptr(), g.stride(0), y.data_ptr(), y.stride(0), gm.data_ptr(), gm.stride(0),
+                                           g.shape[0], g.shape[1], weight.data_ptr(), weight.stride(0), weight.shape[1],
+                                           gx.data_ptr(), gx.stride(0), stream)
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError("pgcn_linear_relu_grad_input_f32: %s" % L.pgcn_dense_last_error().decode())
+    return gm, gx
+
+
+def linear_relu_fused(x, weight, relu=True):
+    """[relu](x . weight^T) (PGCN.py:146-147) by the package's matrix-core kernel on the current stream, or None when it
+    does not take the operands (widths above 128, rows that are not 16-byte pieces, CPU tensors): the caller runs the
+    library product."""
+    if not _dense_operand_ok(x, weight):
+        return None
+    return linear_relu_call(_dense_lib(), x, weight, relu, _dense_stream(x))
+
+
+def linear_relu_grad_input_fused(g, y, weight):
+    """(g (.) [y > 0], that . weight): the ReLU mask and the input gradient of relu(x . weight^T) in one pass, or None."""
+    if not _dense_operand_ok(g, y, weight):
+        return None
+    return linear_relu_grad_input_call(_dense_lib(), g, y, weight, _dense_stream(g))
+
+
+def _dense_fused_level():
+    from .tuning import T as _T
+    return int(_T.dense_fused)
+
+
 class _LinearNoBias(torch.autograd.Function):
     """y = x . W^T  (nn.Linear without bias, PGCN.py:139,146) with a split-K weight gradient.
 
@@ -326,17 +417,25 @@ class _LinearReluNoBias(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight):
-        y = mm_nt(x, weight).clamp_min_(0.0)
+        y = linear_relu_fused(x, weight) if _dense_fused_level() >= 1 else None       # (None: not CUDA / not its shapes)
+        if y is None:
+            y = mm_nt(x, weight).clamp_min_(0.0)
         ctx.save_for_backward(x, weight, y)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
         gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = mm_nn(g, weight)
+        both = None
+        if ctx.needs_input_grad[0] and _dense_fused_level() >= 2:
+            both = linear_relu_grad_input_fused(g.contiguous(), y, weight)       # the mask and g . W in one pass
+        if both is not None:
+            g, gx = both
+        else:
+            g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
+            if ctx.needs_input_grad[0]:
+                gx = mm_nn(g, weight)
         if ctx.needs_input_grad[1]:
             gw = _LinearNoBias.weight_grad(g, x)
         return gx, gw

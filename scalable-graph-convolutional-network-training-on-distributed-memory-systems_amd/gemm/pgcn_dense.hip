@@ -1,0 +1,654 @@
+// pgcn_dense.hip -- the dense products of a layer on the bf16 matrix cores at fp32 accuracy, fused with what surrounds them:
+//     forward    Y  = relu(X . W^T)                  (/root/reference/GPU/PGCN.py:146-147  `F.relu(self.linear(AH))`)
+//     backward   Gm = G (.) [Y > 0],  dX = Gm . W    (autograd of the same two lines; dW = Gm^T . X stays a library GEMM)
+// north_star reserves MFMA for exactly this contraction; rounds 1-4 ran it as stock rocBLAS kernels (64 us per product at
+// n = 232 965, f = 128: profiles/r04_gemm_pick.txt) plus a ReLU pass (35 us) and a mask pass (50 us).  An n x K x N product with
+// K, N <= 128 moves 2 x n x 512 B and needs 2 n K N flops: HBM-bound (30 us at 8 TB/s for the benchmark layer) as long as the
+// matrix pipes stay under that, which the fp32 MFMA does not (49 us at its peak) and six bf16 MFMAs do (18 us).
+//
+// Arithmetic: the three-plane bf16 split of csrc/pgcn_spmm_dense3.hip (x = x1 + x2 + x3 exactly, six partial products smallest
+// first, fp32 accumulation inside the MFMA): error class of an fp32 dot product, deterministic, no dependence on the grid.
+// Not bit-identical to a library GEMM (neither are two library kernels to each other); tests hold it to 1e-6 of sum |x||w|.
+//
+// Layout.  ONE persistent workgroup per CU, 8 waves.  W is split ONCE per workgroup into the B-operand image in LDS
+//     image[plane p][k step ks][column block nb][lane] x 16 B   (8 bf16: Bm[16 ks + 8 (lane >> 5) + j][32 nb + (lane & 31)])
+// = 96 KB for 128 x 128, a lane's operand of v_mfma_f32_32x32x16_bf16 is one slot, a wave reads 1 KB contiguous (no bank
+// conflicts).  Bm = W^T (forward: Bm[k][o] = W[o][k]) or W (backward: Bm[o][k] = W[o][k]).  A wave owns 32-row tiles of X
+// (tile t = 8 workgroup + wave, stride 8 workgroups): its lane (lo, hi) reads the A operands straight from global memory --
+// row lo, columns 16 ks + 8 hi .. + 8 as two 16-byte loads per k step (the whole 32 x 128 tile is 16 loads in flight per
+// lane; every byte of X is read once, a 128-byte line is touched by four loads issued back to back) --, splits them in
+// registers and runs nb x 6 MFMAs per k step against the image.  The forward keeps the next tile's loads in flight under the
+// second half of the MFMAs of the current one (the other wave of the SIMD covers the rest); the backward loads G and Y, keeps G (.) [Y > 0] and
+// writes it out as Gm for the weight gradient.  C leaves as 16 x nb dword stores per lane, two full 128-byte lines per store.
+//
+// The index arithmetic lives in functions that a host build of this same file runs lane by lane with an emulated MFMA
+// (tests/test_dense_fused.py, -DPGCN_DENSE_HOST_EMU with clang++): image slots, operand lanes and the accumulator layout
+// are checked on the CPU against numpy; the MFMA operand layout itself is the one pgcn_spmm_dense3.hip runs on hardware.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#ifdef PGCN_DENSE_HOST_EMU
+#define PG_HD inline
+#else
+#include <hip/hip_runtime.h>
+#define PG_HD __device__ __forceinline__
+#endif
+
+namespace pgcn_dense {
+
+// Measurement builds (tools/micro/build_dense_fused_bench.sh compiles this file again with -DPGCN_DENSE_PREFETCH=0 / 2 and other
+// entry-point names): where the forward kernel issues the next tile's loads.  The library is built with 1.
+#ifndef PGCN_DENSE_PREFETCH
+#define PGCN_DENSE_PREFETCH 1
+#endif
+constexpr int kPrefetch = PGCN_DENSE_PREFETCH;
+// ... and whether the masked (backward) kernel streams its operand by half tiles (1) or loads a whole tile, then multiplies (0)
+#ifndef PGCN_DENSE_MASK_PIPE
+#define PGCN_DENSE_MASK_PIPE 1
+#endif
+constexpr bool kMaskPipe = PGCN_DENSE_MASK_PIPE != 0;
+// ... and (1) the B operands of step t + 1 read from LDS under the MFMAs of step t, tiles in two register sets that swap roles
+// (no copy, so no wait for the tile's stores), or (0) the first version: LDS reads, wait, MFMAs, per step; cur = nxt per tile
+#ifndef PGCN_DENSE_PIPE
+#define PGCN_DENSE_PIPE 1
+#endif
+constexpr bool kPipe = PGCN_DENSE_PIPE != 0;
+constexpr int kRows = 32;                 // rows of a wave's tile = M of the MFMA
+constexpr int kMaxF = 128;                // K and N of a product
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kSlotsPerPlane = 8 * 4 * 64;                 // (k step, column block, lane)
+constexpr int kPlaneBytes = kSlotsPerPlane * 16;           // 32 KB
+constexpr int kImageBytes = 3 * kPlaneBytes;               // 96 KB
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+// float -> bf16 bits, round to nearest even (finite inputs; NaN stays NaN, inf stays inf)
+PG_HD uint32_t bf16_bits(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+PG_HD float bf16_as_f32(uint32_t b) {
+    const uint32_t u = b << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+// x, y -> their three bf16 planes, packed {x in bits 0-15, y in bits 16-31}
+#ifndef PGCN_DENSE_HOST_EMU
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+PG_HD uint32_t pack_bf16(float x, float y) {       // the hardware's conversion (RNE): {bf16(x) in bits 0-15, bf16(y) in bits 16-31}
+    const f32x2 v = {x, y};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+PG_HD void split_pair(float x, float y, uint32_t &u1, uint32_t &u2, uint32_t &u3) {
+    u1 = pack_bf16(x, y);
+    const float rx = x - __builtin_bit_cast(float, u1 << 16), ry = y - __builtin_bit_cast(float, u1 & 0xffff0000u);   // exact
+    u2 = pack_bf16(rx, ry);
+    u3 = pack_bf16(rx - __builtin_bit_cast(float, u2 << 16), ry - __builtin_bit_cast(float, u2 & 0xffff0000u));
+}
+#else
+PG_HD void split_pair(float x, float y, uint32_t &u1, uint32_t &u2, uint32_t &u3) {
+    const uint32_t x1 = bf16_bits(x), y1 = bf16_bits(y);
+    const float rx = x - bf16_as_f32(x1), ry = y - bf16_as_f32(y1);           // exact
+    const uint32_t x2 = bf16_bits(rx), y2 = bf16_bits(ry);
+    const uint32_t x3 = bf16_bits(rx - bf16_as_f32(x2)), y3 = bf16_bits(ry - bf16_as_f32(y2));   // exact, and bf16 numbers
+    u1 = x1 | (y1 << 16); u2 = x2 | (y2 << 16); u3 = x3 | (y3 << 16);
+}
+#endif
+// the eight values of one lane and k step -> the lane's A (or B) operand of each plane
+PG_HD void split8(const f32x4 &lo4, const f32x4 &hi4, u32x4 (&p)[3]) {
+    uint32_t a, b, c;
+    split_pair(lo4.x, lo4.y, a, b, c); p[0].x = a; p[1].x = b; p[2].x = c;
+    split_pair(lo4.z, lo4.w, a, b, c); p[0].y = a; p[1].y = b; p[2].y = c;
+    split_pair(hi4.x, hi4.y, a, b, c); p[0].z = a; p[1].z = b; p[2].z = c;
+    split_pair(hi4.z, hi4.w, a, b, c); p[0].w = a; p[1].w = b; p[2].w = c;
+}
+
+// the six partial products that matter, smallest first: (plane of A, plane of B)
+#define PGCN_DENSE_PRODUCTS constexpr int kPA[6] = {2, 0, 1, 1, 0, 0}, kPB[6] = {0, 2, 1, 0, 1, 0}
+
+// byte offset of a lane's B operand in the image
+PG_HD int image_offset(int plane, int ks, int nb, int lane) { return plane * kPlaneBytes + ((ks * 4 + nb) * 64 + lane) * 16; }
+
+// Slot s (0 .. kSlotsPerPlane) of the image, all three planes: the eight values Bm[16 ks + 8 hi + j][32 nb + lo].
+// transposed = 1: Bm = W^T (W is N x K, row-major, ldw); 0: Bm = W (W is K x N).  Outside K x N: zeros.
+// In two steps, so that a thread's loads of all its slots are in flight together (branch-free: clamped addresses, the value
+// dropped afterwards -- the first version loaded element by element under a branch: 32 dependent L2 round trips per
+// workgroup before the first tile, ~20 us of an 88 us launch).
+PG_HD void slot_load(const float *__restrict__ W, int64_t ldw, int transposed, int K, int N, int s, float (&v)[8]) {
+    const int lane = s & 63, nb = (s >> 6) & 3, ks = s >> 8;
+    const int col = 32 * nb + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+    const int colc = col < N ? col : N - 1;
+    const int64_t sk = transposed ? 1 : ldw, sc = transposed ? ldw : 1;      // (one address, one load: no branch on the mode)
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j, kc = k < K ? k : K - 1;
+        x[j] = W[kc * sk + colc * sc];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (k0 + j < K && col < N) ? x[j] : 0.f;
+}
+PG_HD void slot_store(char *image, int s, const float (&v)[8]) {
+    const int lane = s & 63, nb = (s >> 6) & 3, ks = s >> 8;
+    u32x4 p[3];
+    const f32x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
+    split8(lo4, hi4, p);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(image + image_offset(pl, ks, nb, lane)) = p[pl];
+}
+
+// A lane's 16-byte pieces of a tile: piece (ks, h) = A[row0 + lo][16 ks + 8 hi + 4 h .. + 4]; zeros outside n x K (K % 4 == 0).
+struct Piece {
+    int64_t off;      // element offset from the matrix base (valid only when ok)
+    bool ok;
+};
+PG_HD Piece piece_of(int64_t row0, int64_t n, int K, int64_t ld, int lane, int ks, int h) {
+    const int64_t row = row0 + (lane & 31);
+    const int k = 16 * ks + 8 * (lane >> 5) + 4 * h;
+    Piece p;
+    p.ok = row < n && k < K;
+    p.off = row * ld + k;
+    return p;
+}
+// threshold_backward(g, y, 0): the gradient where y > 0 (NaN in y keeps it, like ATen's `y <= 0 ? 0 : g`)
+PG_HD f32x4 mask4(const f32x4 &g, const f32x4 &y) {
+    f32x4 r;
+    r.x = y.x <= 0.f ? 0.f : g.x; r.y = y.y <= 0.f ? 0.f : g.y; r.z = y.z <= 0.f ? 0.f : g.z; r.w = y.w <= 0.f ? 0.f : g.w;
+    return r;
+}
+PG_HD float relu1(float x) { return x < 0.f ? 0.f : x; }                      // clamp_min(0): NaN stays NaN
+
+// accumulator register r of lane (lo, hi), column block nb -> element (row0 + (r & 3) + 8 (r >> 2) + 4 hi, 32 nb + lo) of C
+PG_HD void store_c(const f32x16 *acc, int nblk, float *C, int64_t ldc, int64_t row0, int64_t n, int N, int lane, int relu) {
+    const int hi = lane >> 5, lo = lane & 31;
+#pragma unroll
+    for (int nb = 0; nb < nblk; ++nb) {
+        const int col = 32 * nb + lo;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row < n) C[row * ldc + col] = relu ? relu1(acc[nb][r]) : acc[nb][r];
+        }
+    }
+}
+
+// ---- argument checks and the error string (both builds) ---------------------------------------------------------------------
+thread_local char g_err[256] = "";
+int fail(int code, const char *what) {
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+
+int check(const void *A, int64_t lda, int64_t n, int K, int N, const void *W, int64_t ldw, int wrows, int wcols, const void *C,
+          int64_t ldc) {
+    if (n < 0 || K <= 0 || N <= 0 || !W || (n > 0 && (!A || !C))) return fail(-1, "pgcn_dense: bad argument");
+    if (K > kMaxF || N > kMaxF) return fail(-2, "pgcn_dense: widths above 128 are left to the library GEMM");
+    if (K % 4 || lda % 4 || (uintptr_t)A % 16) return fail(-2, "pgcn_dense: rows of the left operand must be 16-byte pieces");
+    if (lda < K || ldc < N || ldw < wcols || wrows <= 0) return fail(-1, "pgcn_dense: leading dimension below the width");
+    if (n > ((int64_t)1 << 40)) return fail(-1, "pgcn_dense: n out of range");
+    return 0;
+}
+
+
+#ifndef PGCN_DENSE_HOST_EMU
+// ---- device ---------------------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+template <int NKS>
+struct TileA {
+    f32x4 v[NKS][2];
+};
+
+template <int NKS>
+PG_HD void load_tile(TileA<NKS> &t, const float *__restrict__ A, int64_t lda, int64_t row0, int64_t n, int K, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const Piece p = piece_of(row0, n, K, lda, lane, ks, h);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            t.v[ks][h] = p.ok ? *reinterpret_cast<const f32x4 *>(A + p.off) : z;
+        }
+}
+// G (.) [Y > 0], written out as Gm (when asked for) on the way
+template <int NKS>
+PG_HD void load_tile_masked(TileA<NKS> &t, const float *__restrict__ G, int64_t ldg, const float *__restrict__ Y, int64_t ldy,
+                            float *__restrict__ Gm, int64_t ldgm, int64_t row0, int64_t n, int K, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const Piece pg = piece_of(row0, n, K, ldg, lane, ks, h);
+            const Piece py = piece_of(row0, n, K, ldy, lane, ks, h);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            t.v[ks][h] = pg.ok ? *reinterpret_cast<const f32x4 *>(G + pg.off) : z;
+            const f32x4 y = py.ok ? *reinterpret_cast<const f32x4 *>(Y + py.off) : z;
+            t.v[ks][h] = mask4(t.v[ks][h], y);
+        }
+    if (Gm) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const Piece pm = piece_of(row0, n, K, ldgm, lane, ks, h);
+                if (pm.ok) *reinterpret_cast<f32x4 *>(Gm + pm.off) = t.v[ks][h];
+            }
+    }
+}
+
+PG_HD void read_b(u32x4 (&b)[3], const char *image, int ks, int nb, int lane) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(image + image_offset(pl, ks, nb, lane));
+}
+// CNT k steps (ks0 ..) x NBLK column blocks as one sequence of steps t = i NBLK + nb; the operands of step t + 1 are requested
+// before the six MFMAs of step t (LDS returns in order: the wait before a step leaves the newest three reads outstanding)
+template <int NBLK, int CNT>
+PG_HD void product_steps(const f32x4 (&v)[CNT][2], const char *image, int lane, int ks0, f32x16 (&acc)[NBLK]) {
+    constexpr int T = CNT * NBLK;
+    u32x4 b[2][3], a[3];
+    read_b(b[0], image, ks0, 0, lane);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        PGCN_DENSE_PRODUCTS;
+        const int i = t / NBLK, nb = t % NBLK;
+        if (t + 1 < T) read_b(b[(t + 1) & 1], image, ks0 + (t + 1) / NBLK, (t + 1) % NBLK, lane);
+        if (nb == 0) split8(v[i][0], v[i][1], a);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kPA[j]]),
+                                                               __builtin_bit_cast(bf16x8, b[t & 1][kPB[j]]), acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// k steps [KS0, KS1) of a tile's product
+template <int NKS, int NBLK, int KS0, int KS1>
+PG_HD void tile_product(const TileA<NKS> &t, const char *image, int lane, f32x16 (&acc)[NBLK]) {
+    if constexpr (kPipe) {
+        f32x4 v[KS1 - KS0][2];
+#pragma unroll
+        for (int i = 0; i < KS1 - KS0; ++i) { v[i][0] = t.v[KS0 + i][0]; v[i][1] = t.v[KS0 + i][1]; }
+        product_steps<NBLK, KS1 - KS0>(v, image, lane, KS0, acc);
+        return;
+    }
+#pragma unroll
+    for (int ks = KS0; ks < KS1; ++ks) {
+        u32x4 a[3];
+        split8(t.v[ks][0], t.v[ks][1], a);
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            PGCN_DENSE_PRODUCTS;
+            u32x4 b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(image + image_offset(pl, ks, nb, lane));
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kPA[i]]),
+                                                                   __builtin_bit_cast(bf16x8, b[kPB[i]]), acc[nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);     // (left alone the scheduler hoists every split and LDS read of the tile: spills)
+        }
+    }
+}
+template <int NBLK>
+PG_HD void zero_acc(f32x16 (&acc)[NBLK]) {
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+}
+
+// ---- the masked operand as a stream of HALF tiles (k steps [KS0, KS0 + CNT) of a tile) ---------------------------------------
+// G and Y of a half are 2 x CNT x 2 loads of 16 bytes; while one half is multiplied the next one (the second half of the tile,
+// or the first half of the wave's next tile) is in flight: 32 + 64 + 64 registers instead of the 128 + 64 a whole tile of
+// G and Y would hold beside the accumulators.
+template <int CNT>
+struct HalfRaw {
+    f32x4 g[CNT][2], y[CNT][2];
+};
+template <int CNT>
+PG_HD void load_half(HalfRaw<CNT> &r, const float *__restrict__ G, int64_t ldg, const float *__restrict__ Y, int64_t ldy,
+                     int64_t row0, int64_t n, int K, int lane, int ks0) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const Piece pg = piece_of(row0, n, K, ldg, lane, ks0 + i, h);
+            const Piece py = piece_of(row0, n, K, ldy, lane, ks0 + i, h);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            r.g[i][h] = pg.ok ? *reinterpret_cast<const f32x4 *>(G + pg.off) : z;
+            r.y[i][h] = py.ok ? *reinterpret_cast<const f32x4 *>(Y + py.off) : z;
+        }
+}
+template <int CNT>
+PG_HD void mask_half(f32x4 (&v)[CNT][2], const HalfRaw<CNT> &r, float *__restrict__ Gm, int64_t ldgm, int64_t row0, int64_t n, int K,
+                     int lane, int ks0) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v[i][h] = mask4(r.g[i][h], r.y[i][h]);
+            if (Gm) {
+                const Piece pm = piece_of(row0, n, K, ldgm, lane, ks0 + i, h);
+                if (pm.ok) *reinterpret_cast<f32x4 *>(Gm + pm.off) = v[i][h];
+            }
+        }
+}
+template <int NBLK, int CNT>
+PG_HD void half_product(const f32x4 (&v)[CNT][2], const char *image, int lane, int ks0, f32x16 (&acc)[NBLK]) {
+    if constexpr (kPipe) {
+        product_steps<NBLK, CNT>(v, image, lane, ks0, acc);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        u32x4 a[3];
+        split8(v[i][0], v[i][1], a);
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            PGCN_DENSE_PRODUCTS;
+            u32x4 b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(image + image_offset(pl, ks0 + i, nb, lane));
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kPA[j]]),
+                                                                   __builtin_bit_cast(bf16x8, b[kPB[j]]), acc[nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// C (n x N) = op(A) (n x K) . Bm (K x N); MASK: op(A) = A (.) [Y > 0] (and Gm = op(A) when Gm != nullptr); relu: C = relu(C).
+template <int NKS, int NBLK, bool MASK>
+__global__ __launch_bounds__(kThreads, 2) void dense_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ Y,
+                                                            int64_t ldy, float *__restrict__ Gm, int64_t ldgm, int64_t n, int K,
+                                                            int N, const float *__restrict__ W, int64_t ldw, int transposed,
+                                                            float *__restrict__ C, int64_t ldc, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char image[];
+    {
+        constexpr int kMine = kSlotsPerPlane / kThreads;      // slots s = thread + 512 q: k step (thread >> 8) + 2 q, column block per wave
+        float v[kMine][8];
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) {
+            const int s = (int)threadIdx.x + q * kThreads;
+            if ((s >> 8) < NKS && ((s >> 6) & 3) < NBLK) slot_load(W, ldw, transposed, K, N, s, v[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) {
+            const int s = (int)threadIdx.x + q * kThreads;
+            if ((s >> 8) < NKS && ((s >> 6) & 3) < NBLK) slot_store(image, s, v[q]);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const int64_t stride = (int64_t)gridDim.x * kWaves;
+    int64_t tile = (int64_t)blockIdx.x * kWaves + w;
+    f32x16 acc[NBLK];
+    if constexpr (MASK && kMaskPipe) {
+        constexpr int H = NKS / 2;
+        HalfRaw<H> raw;
+        f32x4 v[H][2];
+        if (tile < ntiles) load_half<H>(raw, A, lda, Y, ldy, tile * kRows, n, K, lane, 0);
+        while (tile < ntiles) {
+            const int64_t tn = tile + stride, row0 = tile * kRows;
+            zero_acc(acc);
+            mask_half<H>(v, raw, Gm, ldgm, row0, n, K, lane, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_half<H>(raw, A, lda, Y, ldy, row0, n, K, lane, H);                          // under the first half's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            half_product<NBLK, H>(v, image, lane, 0, acc);
+            mask_half<H>(v, raw, Gm, ldgm, row0, n, K, lane, H);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tn < ntiles) load_half<H>(raw, A, lda, Y, ldy, tn * kRows, n, K, lane, 0);    // under the second half's and the stores
+            __builtin_amdgcn_sched_barrier(0);
+            half_product<NBLK, H>(v, image, lane, H, acc);
+            store_c(acc, NBLK, C, ldc, row0, n, N, lane, relu);
+            tile = tn;
+        }
+    } else if constexpr (MASK) {
+        for (; tile < ntiles; tile += stride) {
+            TileA<NKS> cur;
+            load_tile_masked<NKS>(cur, A, lda, Y, ldy, Gm, ldgm, tile * kRows, n, K, lane);
+            zero_acc(acc);
+            tile_product<NKS, NBLK, 0, NKS>(cur, image, lane, acc);
+            store_c(acc, NBLK, C, ldc, tile * kRows, n, N, lane, relu);
+        }
+    } else if constexpr (kPipe) {
+        // two register sets that swap roles: `from` is multiplied while `into` receives the wave's next tile
+        TileA<NKS> t0, t1;
+        auto one_tile = [&](const TileA<NKS> &from, TileA<NKS> &into) {
+            const int64_t tn = tile + stride;
+            zero_acc(acc);
+            if constexpr (kPrefetch == 2) {
+                if (tn < ntiles) load_tile<NKS>(into, A, lda, tn * kRows, n, K, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tile_product<NKS, NBLK, 0, NKS / 2>(from, image, lane, acc);
+            if constexpr (kPrefetch == 1) {
+                if (tn < ntiles) load_tile<NKS>(into, A, lda, tn * kRows, n, K, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tile_product<NKS, NBLK, NKS / 2, NKS>(from, image, lane, acc);
+            store_c(acc, NBLK, C, ldc, tile * kRows, n, N, lane, relu);
+            if constexpr (kPrefetch == 0) {
+                if (tn < ntiles) load_tile<NKS>(into, A, lda, tn * kRows, n, K, lane);
+            }
+            tile = tn;
+        };
+        if (tile < ntiles) load_tile<NKS>(t0, A, lda, tile * kRows, n, K, lane);
+        while (tile < ntiles) {
+            one_tile(t0, t1);
+            if (tile >= ntiles) break;
+            one_tile(t1, t0);
+        }
+    } else {
+        TileA<NKS> cur, nxt;
+        if (tile < ntiles) load_tile<NKS>(cur, A, lda, tile * kRows, n, K, lane);
+        while (tile < ntiles) {
+            const int64_t tn = tile + stride;
+            zero_acc(acc);
+            if constexpr (kPrefetch == 2) {           // probe: the whole next tile in flight from the start (spills)
+                if (tn < ntiles) load_tile<NKS>(nxt, A, lda, tn * kRows, n, K, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tile_product<NKS, NBLK, 0, NKS / 2>(cur, image, lane, acc);
+            // the next tile's loads go out once half of this one's registers are free, and land under the second half
+            // of its MFMAs, its stores and the other wave of the SIMD
+            if constexpr (kPrefetch == 1) {
+                if (tn < ntiles) load_tile<NKS>(nxt, A, lda, tn * kRows, n, K, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tile_product<NKS, NBLK, NKS / 2, NKS>(cur, image, lane, acc);
+            store_c(acc, NBLK, C, ldc, tile * kRows, n, N, lane, relu);
+            if constexpr (kPrefetch == 0) {           // probe: no prefetch (the other wave of the SIMD is the only overlap)
+                if (tn < ntiles) load_tile<NKS>(nxt, A, lda, tn * kRows, n, K, lane);
+            }
+            cur = nxt;
+            tile = tn;
+        }
+    }
+}
+
+template <int NKS, int NBLK, bool MASK>
+int launch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm, int64_t n, int K, int N,
+           const float *W, int64_t ldw, int transposed, float *C, int64_t ldc, int relu, int workgroups, hipStream_t s) {
+    auto kern = dense_kernel<NKS, NBLK, MASK>;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(-1, "hipGetDevice");
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kImageBytes) != hipSuccess)
+            return fail(-1, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)workgroups), dim3(kThreads), kImageBytes, s, A, lda, Y, ldy, Gm, ldgm, n, K, N, W, ldw,
+                       transposed, C, ldc, relu);
+    return hipGetLastError() == hipSuccess ? 0 : fail(-1, "kernel launch");
+}
+
+template <bool MASK>
+int dispatch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm, int64_t n, int K, int N,
+             const float *W, int64_t ldw, int transposed, float *C, int64_t ldc, int relu, hipStream_t s) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+        return fail(-1, "hipDeviceGetAttribute(MultiprocessorCount)");
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const int64_t need = (ntiles + kWaves - 1) / kWaves;
+    const int wgs = (int)(need < cus ? need : cus);           // one persistent workgroup per CU (96 KB of LDS each)
+    const int nks = (K + 15) / 16, nblk = (N + 31) / 32;
+#define PGCN_DENSE_CASE(KS, NB)                                                                                              \
+    if (nks <= KS && nblk <= NB)                                                                                             \
+        return launch<KS, NB, MASK>(A, lda, Y, ldy, Gm, ldgm, n, K, N, W, ldw, transposed, C, ldc, relu, wgs, s);
+    PGCN_DENSE_CASE(4, 2)
+    PGCN_DENSE_CASE(4, 4)
+    PGCN_DENSE_CASE(8, 2)
+    PGCN_DENSE_CASE(8, 4)
+#undef PGCN_DENSE_CASE
+    return fail(-2, "pgcn_dense: widths above 128");
+}
+
+}  // namespace pgcn_dense
+
+#else  // PGCN_DENSE_HOST_EMU
+// ---- host emulation: the same index functions, lane by lane, with the MFMA spelled out -----------------------------------
+}  // namespace pgcn_dense
+
+namespace {
+using namespace pgcn_dense;
+
+// D += A . B of v_mfma_f32_32x32x16_bf16 over the 64 lanes: A[m = lo][k = 8 hi + j] is element j of lane (lo, hi) of a,
+// B[k = 8 hi + j][n = lo] element j of b, D[m = (r & 3) + 8 (r >> 2) + 4 hi][n = lo] register r of acc.
+void mfma_emu(const u32x4 (&a)[64], const u32x4 (&b)[64], f32x16 (&acc)[64]) {
+    float Am[32][16], Bm[16][32];
+    for (int lane = 0; lane < 64; ++lane) {
+        const int lo = lane & 31, hi = lane >> 5;
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t wa = a[lane][j >> 1], wb = b[lane][j >> 1];
+            Am[lo][8 * hi + j] = bf16_as_f32((j & 1) ? (wa >> 16) : (wa & 0xffffu));
+            Bm[8 * hi + j][lo] = bf16_as_f32((j & 1) ? (wb >> 16) : (wb & 0xffffu));
+        }
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        const int lo = lane & 31, hi = lane >> 5;
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float s = acc[lane][r];
+            for (int k = 0; k < 16; ++k) s += Am[m][k] * Bm[k][lo];
+            acc[lane][r] = s;
+        }
+    }
+}
+
+f32x4 load4(const float *base, const Piece &p) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p.ok) memcpy(&v, base + p.off, 16);
+    return v;
+}
+}  // namespace
+
+// mode 0: C = [relu](A . W^T), W: N x K;  mode 1: Gm = A (.) [Y > 0] (when Gm), C = Gm . W, W: K x N.
+extern "C" int pgcn_dense_emulate(int mode, const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm,
+                                  int64_t n, int K, int N, const float *W, int64_t ldw, float *C, int64_t ldc, int relu);
+namespace pgcn_dense {
+typedef void *hipStream_t;
+// the host build's stand-in for the launch: HOST pointers, the stream is ignored
+template <bool MASK>
+int dispatch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm, int64_t n, int K, int N,
+             const float *W, int64_t ldw, int transposed, float *C, int64_t ldc, int relu, hipStream_t) {
+    if (transposed != (MASK ? 0 : 1)) return fail(-1, "emulation: mode / layout mismatch");
+    return pgcn_dense_emulate(MASK ? 1 : 0, A, lda, Y, ldy, Gm, ldgm, n, K, N, W, ldw, C, ldc, relu);
+}
+}  // namespace pgcn_dense
+extern "C" int pgcn_dense_emulate(int mode, const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm,
+                                  int64_t n, int K, int N, const float *W, int64_t ldw, float *C, int64_t ldc, int relu) {
+    if (K <= 0 || N <= 0 || K > kMaxF || N > kMaxF || K % 4) return -2;
+    alignas(16) static char image[kImageBytes];
+    memset(image, 0xff, sizeof image);                       // (slots the kernel does not fill must not be read)
+    const int nks = (K + 15) / 16, nblk = (N + 31) / 32;
+    for (int s = 0; s < kSlotsPerPlane; ++s) {
+        const int ks = s >> 8, nb = (s >> 6) & 3;
+        if (ks < nks && nb < nblk) {
+            float v[8];
+            slot_load(W, ldw, mode == 0, K, N, s, v);
+            slot_store(image, s, v);
+        }
+    }
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        static f32x4 v[64][8][2];
+        for (int lane = 0; lane < 64; ++lane)
+            for (int ks = 0; ks < nks; ++ks)
+                for (int h = 0; h < 2; ++h) {
+                    v[lane][ks][h] = load4(A, piece_of(tile * kRows, n, K, lda, lane, ks, h));
+                    if (mode == 1) {
+                        v[lane][ks][h] = mask4(v[lane][ks][h], load4(Y, piece_of(tile * kRows, n, K, ldy, lane, ks, h)));
+                        const Piece pm = piece_of(tile * kRows, n, K, ldgm, lane, ks, h);
+                        if (Gm && pm.ok) memcpy(Gm + pm.off, &v[lane][ks][h], 16);
+                    }
+                }
+        static f32x16 acc[4][64];
+        for (int nb = 0; nb < nblk; ++nb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 16; ++r) acc[nb][lane][r] = 0.f;
+        for (int ks = 0; ks < nks; ++ks) {
+            static u32x4 a[3][64], b[3][64];
+            for (int lane = 0; lane < 64; ++lane) {
+                u32x4 p[3];
+                split8(v[lane][ks][0], v[lane][ks][1], p);
+                for (int pl = 0; pl < 3; ++pl) a[pl][lane] = p[pl];
+            }
+            for (int nb = 0; nb < nblk; ++nb) {
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int pl = 0; pl < 3; ++pl) memcpy(&b[pl][lane], image + image_offset(pl, ks, nb, lane), 16);
+                PGCN_DENSE_PRODUCTS;
+                for (int i = 0; i < 6; ++i) mfma_emu(a[kPA[i]], b[kPB[i]], acc[nb]);
+            }
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            f32x16 mine[4];
+            for (int nb = 0; nb < nblk; ++nb) mine[nb] = acc[nb][lane];
+            store_c(mine, nblk, C, ldc, tile * kRows, n, N, lane, relu);
+        }
+    }
+    return 0;
+}
+#endif
+
+// ---- the C ABI (include/pgcn_gemm.h); in the host build the same checks in front of the emulator ------------------------------
+extern "C" const char *pgcn_dense_last_error(void) { return pgcn_dense::g_err; }
+
+// Y (n x fout, ldy) = [relu] (X (n x fin, ldx) . W^T),  W: fout x fin row-major (nn.Linear's weight), on `stream`.
+// 0; -2: shape / alignment outside what the kernel takes (the caller uses the library GEMM); -1: errors.
+extern "C" int pgcn_linear_relu_f32(const float *X, int64_t ldx, int64_t n, int32_t fin, const float *W, int64_t ldw, int32_t fout,
+                                    float *Y, int64_t ldy, int32_t relu, void *stream) {
+    using namespace pgcn_dense;
+    if (int rc = check(X, ldx, n, fin, fout, W, ldw, fout, fin, Y, ldy)) return rc;
+    if (n == 0) return 0;
+    return dispatch<false>(X, ldx, nullptr, 0, nullptr, 0, n, fin, fout, W, ldw, 1, Y, ldy, relu ? 1 : 0, (hipStream_t)stream);
+}
+
+// Gm = G (.) [Y > 0] (written when Gm != NULL; may be G itself),  dX (n x fin, lddx) = Gm . W;  G, Y, Gm: n x fout.
+extern "C" int pgcn_linear_relu_grad_input_f32(const float *G, int64_t ldg, const float *Y, int64_t ldy, float *Gm, int64_t ldgm,
+                                               int64_t n, int32_t fout, const float *W, int64_t ldw, int32_t fin, float *dX,
+                                               int64_t lddx, void *stream) {
+    using namespace pgcn_dense;
+    if (int rc = check(G, ldg, n, fout, fin, W, ldw, fout, fin, dX, lddx)) return rc;
+    if (!Y && n > 0) return fail(-1, "pgcn_linear_relu_grad_input_f32: Y is NULL");
+    if (ldy % 4 || (uintptr_t)Y % 16 || ldy < fout) return fail(-2, "pgcn_dense: rows of Y must be 16-byte pieces");
+    if (Gm && (ldgm % 4 || (uintptr_t)Gm % 16 || ldgm < fout)) return fail(-2, "pgcn_dense: rows of Gm must be 16-byte pieces");
+    if (n == 0) return 0;
+    return dispatch<true>(G, ldg, Y, ldy, Gm, ldgm, n, fout, fin, W, ldw, 0, dX, lddx, 0, (hipStream_t)stream);
+}

@@ -1,0 +1,154 @@
+// dense_fused_bench.cpp -- first contact + timing of gemm/pgcn_dense.hip without Python (a cold `import torch` costs a minute
+// of a GPU call): runs pgcn_linear_relu_f32 and pgcn_linear_relu_grad_input_f32 at the benchmark layer shape (n = 232 965,
+// f = 128) and at ragged shapes, checks sampled rows against float64 on the host (bound: 2e-6 of sum |a||b|, the mask
+// exactly), and times K launches of each with HIP events.  Prints one JSON line per case; exit code 1 on any mismatch.
+//   tools/micro/build_dense_fused_bench.sh && tools/micro/dense_fused_bench.bin [n] [reps]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "../../include/pgcn_gemm.h"
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__);    \
+            exit(2);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+static uint64_t rng_state = 0x9e3779b97f4a7c15ull;
+static float rnd() {                      // xorshift, uniform in (-1, 1)
+    rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+    return (float)((double)(rng_state >> 11) / (double)(1ull << 53) * 2.0 - 1.0);
+}
+
+typedef int (*fwd_fn)(const float *, int64_t, int64_t, int32_t, const float *, int64_t, int32_t, float *, int64_t, int32_t, void *);
+typedef int (*bwd_fn)(const float *, int64_t, const float *, int64_t, float *, int64_t, int64_t, int32_t, const float *, int64_t, int32_t,
+                      float *, int64_t, void *);
+typedef const char *(*err_fn)(void);
+// probe builds of the same kernels (build_dense_fused_bench.sh sets their macros)
+extern "C" {
+int pgcn_linear_relu_f32_p0(const float *, int64_t, int64_t, int32_t, const float *, int64_t, int32_t, float *, int64_t, int32_t, void *);
+int pgcn_linear_relu_grad_input_f32_p0(const float *, int64_t, const float *, int64_t, float *, int64_t, int64_t, int32_t, const float *,
+                                       int64_t, int32_t, float *, int64_t, void *);
+const char *pgcn_dense_last_error_p0(void);
+int pgcn_linear_relu_f32_p2(const float *, int64_t, int64_t, int32_t, const float *, int64_t, int32_t, float *, int64_t, int32_t, void *);
+int pgcn_linear_relu_grad_input_f32_p2(const float *, int64_t, const float *, int64_t, float *, int64_t, int64_t, int32_t, const float *,
+                                       int64_t, int32_t, float *, int64_t, void *);
+const char *pgcn_dense_last_error_p2(void);
+}
+struct Variant {
+    const char *name;
+    fwd_fn fwd;
+    bwd_fn bwd;
+    err_fn err;
+};
+static const Variant kVariants[3] = {
+    {"library (pipelined steps, prefetch mid-tile, masked operand by half tiles)", pgcn_linear_relu_f32, pgcn_linear_relu_grad_input_f32, pgcn_dense_last_error},
+    {"p0 (pipelined steps, loads after the stores, masked operand by whole tiles)", pgcn_linear_relu_f32_p0, pgcn_linear_relu_grad_input_f32_p0, pgcn_dense_last_error_p0},
+    {"p2 (first version: unpipelined steps, loads after the stores, whole tiles)", pgcn_linear_relu_f32_p2, pgcn_linear_relu_grad_input_f32_p2, pgcn_dense_last_error_p2},
+};
+
+static int run_case(int64_t n, int fin, int fout, int reps, bool time_it, const Variant &V) {
+#define pgcn_linear_relu_f32 V.fwd
+#define pgcn_linear_relu_grad_input_f32 V.bwd
+#define pgcn_dense_last_error V.err
+    std::vector<float> X((size_t)n * fin), W((size_t)fout * fin), G((size_t)n * fout);
+    for (auto &v : X) v = rnd();
+    for (auto &v : W) v = rnd() * 0.1f;
+    for (auto &v : G) v = rnd();
+    float *dX_, *dW_, *dY_, *dG_, *dGm_, *dDX_;
+    CK(hipMalloc(&dX_, X.size() * 4 + 16)); CK(hipMalloc(&dW_, W.size() * 4)); CK(hipMalloc(&dY_, (size_t)n * fout * 4 + 16));
+    CK(hipMalloc(&dG_, G.size() * 4 + 16)); CK(hipMalloc(&dGm_, G.size() * 4 + 16)); CK(hipMalloc(&dDX_, X.size() * 4 + 16));
+    CK(hipMemcpy(dX_, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW_, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dG_, G.data(), G.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dY_, 0xff, (size_t)n * fout * 4)); CK(hipMemset(dGm_, 0xff, G.size() * 4)); CK(hipMemset(dDX_, 0xff, X.size() * 4));
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    int rc = pgcn_linear_relu_f32(dX_, fin, n, fin, dW_, fin, fout, dY_, fout, 1, s);
+    if (rc) { fprintf(stderr, "forward rc %d: %s\n", rc, pgcn_dense_last_error()); return 1; }
+    rc = pgcn_linear_relu_grad_input_f32(dG_, fout, dY_, fout, dGm_, fout, n, fout, dW_, fin, fin, dDX_, fin, s);
+    if (rc) { fprintf(stderr, "backward rc %d: %s\n", rc, pgcn_dense_last_error()); return 1; }
+    CK(hipStreamSynchronize(s));
+    std::vector<float> Y((size_t)n * fout), Gm(G.size()), DX(X.size());
+    CK(hipMemcpy(Y.data(), dY_, Y.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(Gm.data(), dGm_, Gm.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(DX.data(), dDX_, DX.size() * 4, hipMemcpyDeviceToHost));
+    // rows to check: the first and last 64 (tile edges, the ragged tail) and a stride through the middle
+    double ef = 0, eb = 0;
+    int64_t bad_mask = 0, rows = 0;
+    const int64_t step = n > 4096 ? n / 1500 : 1;
+    for (int64_t i = 0; i < n; i += (i < 64 || i >= n - 65 ? 1 : step)) {
+        ++rows;
+        for (int o = 0; o < fout; ++o) {
+            double sum = 0, den = 0;
+            for (int k = 0; k < fin; ++k) { sum += (double)X[i * fin + k] * W[(size_t)o * fin + k]; den += fabs((double)X[i * fin + k] * W[(size_t)o * fin + k]); }
+            const double want = sum > 0 ? sum : 0;
+            const double e = fabs((double)Y[i * fout + o] - want) / (den + 1e-30);
+            if (!(e <= ef)) ef = e;                                   // (NaN-catching comparison)
+            const float gm = Y[i * fout + o] > 0.f ? G[i * fout + o] : 0.f;
+            if (!(Gm[i * fout + o] == gm)) ++bad_mask;
+        }
+        for (int k = 0; k < fin; ++k) {
+            double sum = 0, den = 0;
+            for (int o = 0; o < fout; ++o) { const double gm = Y[i * fout + o] > 0.f ? G[i * fout + o] : 0.f; sum += gm * W[(size_t)o * fin + k]; den += fabs(gm * W[(size_t)o * fin + k]); }
+            const double e = fabs((double)DX[i * fin + k] - sum) / (den + 1e-30);
+            if (!(e <= eb)) eb = e;
+        }
+    }
+    double ms_f = 0, ms_b = 0, ms_b0 = 0;
+    if (time_it) {
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        float ms;
+        for (int w = 0; w < 3; ++w) pgcn_linear_relu_f32(dX_, fin, n, fin, dW_, fin, fout, dY_, fout, 1, s);
+        CK(hipEventRecord(a, s));
+        for (int r = 0; r < reps; ++r) pgcn_linear_relu_f32(dX_, fin, n, fin, dW_, fin, fout, dY_, fout, 1, s);
+        CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); ms_f = ms / reps;
+        CK(hipEventRecord(a, s));
+        for (int r = 0; r < reps; ++r) pgcn_linear_relu_grad_input_f32(dG_, fout, dY_, fout, dGm_, fout, n, fout, dW_, fin, fin, dDX_, fin, s);
+        CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); ms_b = ms / reps;
+        CK(hipEventRecord(a, s));                                                    // ... and without writing Gm
+        for (int r = 0; r < reps; ++r) pgcn_linear_relu_grad_input_f32(dG_, fout, dY_, fout, nullptr, 0, n, fout, dW_, fin, fin, dDX_, fin, s);
+        CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); ms_b0 = ms / reps;
+    }
+    const bool ok = ef <= 2e-6 && eb <= 2e-6 && bad_mask == 0;
+    const double bytes_f = (double)n * (fin + fout) * 4, bytes_b = (double)n * (3.0 * fout + fin) * 4;
+    printf("{\"variant\": \"%s\", \"input_grad_no_gm_us\": %.1f, ", V.name, ms_b0 * 1e3);
+    printf("\"n\": %lld, \"fin\": %d, \"fout\": %d, \"rows_checked\": %lld, \"err_forward\": %.3g, \"err_input_grad\": %.3g, \"mask_mismatches\": %lld, "
+           "\"ok\": %s, \"forward_us\": %.1f, \"forward_GBps\": %.0f, \"input_grad_us\": %.1f, \"input_grad_GBps\": %.0f}\n",
+           (long long)n, fin, fout, (long long)rows, ef, eb, (long long)bad_mask, ok ? "true" : "false", ms_f * 1e3,
+           ms_f > 0 ? bytes_f / (ms_f * 1e-3) / 1e9 : 0.0, ms_b * 1e3, ms_b > 0 ? bytes_b / (ms_b * 1e-3) / 1e9 : 0.0);
+    fflush(stdout);
+    hipFree(dX_); hipFree(dW_); hipFree(dY_); hipFree(dG_); hipFree(dGm_); hipFree(dDX_);
+    hipStreamDestroy(s);
+    return ok ? 0 : 1;
+#undef pgcn_linear_relu_f32
+#undef pgcn_linear_relu_grad_input_f32
+#undef pgcn_dense_last_error
+}
+
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 232965;
+    const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    int fails = 0;
+    for (int v = 0; v < 3; ++v) {
+        rng_state = 0x9e3779b97f4a7c15ull;                        // the same data for every variant
+        fails += run_case(n, 128, 128, reps, true, kVariants[v]);  // the benchmark layer
+    }
+    fails += run_case(1000, 128, 40, 1, false, kVariants[0]);      // ragged widths / row counts
+    fails += run_case(77, 64, 128, 1, false, kVariants[0]);
+    fails += run_case(4097, 36, 100, 1, false, kVariants[0]);
+    fails += run_case(33, 4, 4, 1, false, kVariants[0]);
+    fails += run_case(n, 64, 64, reps, true, kVariants[0]);        // the papers shape's width
+    fails += run_case(n, 64, 64, reps, true, kVariants[1]);
+    fails += run_case(n, 64, 64, reps, true, kVariants[2]);
+    return fails ? 1 : 0;
+}
