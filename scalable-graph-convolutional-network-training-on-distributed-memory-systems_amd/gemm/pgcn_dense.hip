@@ -54,6 +54,24 @@ constexpr bool kMaskPipe = PGCN_DENSE_MASK_PIPE != 0;
 #define PGCN_DENSE_PIPE 1
 #endif
 constexpr bool kPipe = PGCN_DENSE_PIPE != 0;
+// ... candidates prepared at the end of r04, not yet run on hardware (the library keeps them off until they have been):
+//   PGCN_DENSE_FASTPATH 1: tiles that lie inside the matrix (all but a wave's last) load and store without per-piece predicates
+//     (the first version wraps each of its 16 loads and 64 stores in an exec-mask branch);
+//   PGCN_DENSE_NT_STORE 1: the stores of C carry the non-temporal hint (C is not read again by this kernel);
+// and TIMING-ONLY probes (wrong results by construction; tools/micro/dense_fused_bench labels them):
+//   PGCN_DENSE_PROBE 1: no MFMAs;  2: no stores of C (one never-true predicate over all accumulators keeps the products alive);
+//   3: the wave's first tile is multiplied again and again (no loads after the first; registers made opaque per tile).
+#ifndef PGCN_DENSE_FASTPATH
+#define PGCN_DENSE_FASTPATH 0
+#endif
+#ifndef PGCN_DENSE_NT_STORE
+#define PGCN_DENSE_NT_STORE 0
+#endif
+#ifndef PGCN_DENSE_PROBE
+#define PGCN_DENSE_PROBE 0
+#endif
+constexpr bool kFastPath = PGCN_DENSE_FASTPATH != 0, kNtStore = PGCN_DENSE_NT_STORE != 0;
+constexpr int kProbe = PGCN_DENSE_PROBE;
 constexpr int kRows = 32;                 // rows of a wave's tile = M of the MFMA
 constexpr int kMaxF = 128;                // K and N of a product
 constexpr int kThreads = 512;
@@ -167,8 +185,39 @@ PG_HD f32x4 mask4(const f32x4 &g, const f32x4 &y) {
 PG_HD float relu1(float x) { return x < 0.f ? 0.f : x; }                      // clamp_min(0): NaN stays NaN
 
 // accumulator register r of lane (lo, hi), column block nb -> element (row0 + (r & 3) + 8 (r >> 2) + 4 hi, 32 nb + lo) of C
+PG_HD void store1(float *p, float x) {
+#ifndef PGCN_DENSE_HOST_EMU
+    if constexpr (kNtStore) {
+        __builtin_nontemporal_store(x, p);
+        return;
+    }
+#endif
+    *p = x;
+}
 PG_HD void store_c(const f32x16 *acc, int nblk, float *C, int64_t ldc, int64_t row0, int64_t n, int N, int lane, int relu) {
     const int hi = lane >> 5, lo = lane & 31;
+#ifndef PGCN_DENSE_HOST_EMU
+    if constexpr (kProbe == 2) {                      // timing only: every accumulator is needed, nothing is written
+        float sum = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < nblk; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[nb][r];
+        if (sum == 123456.789f) C[row0 * ldc + lo] = sum;
+        return;
+    }
+    if constexpr (kFastPath) {
+        if (row0 + kRows <= n && 32 * nblk == N) {    // (wave-uniform) the tile lies inside C: no predicates
+            float *base = C + (row0 + 4 * hi) * ldc + lo;
+#pragma unroll
+            for (int nb = 0; nb < nblk; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    store1(base + (int64_t)((r & 3) + 8 * (r >> 2)) * ldc + 32 * nb, relu ? relu1(acc[nb][r]) : acc[nb][r]);
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int nb = 0; nb < nblk; ++nb) {
         const int col = 32 * nb + lo;
@@ -176,7 +225,15 @@ PG_HD void store_c(const f32x16 *acc, int nblk, float *C, int64_t ldc, int64_t r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (row < n) C[row * ldc + col] = relu ? relu1(acc[nb][r]) : acc[nb][r];
+            if (row < n) {
+#ifndef PGCN_DENSE_HOST_EMU
+                if constexpr (kNtStore) {
+                    store1(&C[row * ldc + col], relu ? relu1(acc[nb][r]) : acc[nb][r]);
+                    continue;
+                }
+#endif
+                C[row * ldc + col] = relu ? relu1(acc[nb][r]) : acc[nb][r];
+            }
         }
     }
 }
@@ -210,6 +267,16 @@ struct TileA {
 
 template <int NKS>
 PG_HD void load_tile(TileA<NKS> &t, const float *__restrict__ A, int64_t lda, int64_t row0, int64_t n, int K, int lane) {
+    if constexpr (kFastPath) {
+        if (row0 + kRows <= n && 16 * NKS == K) {     // (wave-uniform) the tile lies inside A: 16 loads off one address
+            const float *base = A + (row0 + (lane & 31)) * lda + 8 * (lane >> 5);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) t.v[ks][h] = *reinterpret_cast<const f32x4 *>(base + 16 * ks + 4 * h);
+            return;
+        }
+    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -264,9 +331,14 @@ PG_HD void product_steps(const f32x4 (&v)[CNT][2], const char *image, int lane, 
         if (nb == 0) split8(v[i][0], v[i][1], a);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < 6; ++j) {
+            if constexpr (kProbe == 1) {              // timing only: the operands stay needed, the matrix pipe stays idle
+                acc[nb][j] += __builtin_bit_cast(float, a[kPA[j]].x ^ b[t & 1][kPB[j]].x);
+                continue;
+            }
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kPA[j]]),
                                                                __builtin_bit_cast(bf16x8, b[t & 1][kPB[j]]), acc[nb], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -318,6 +390,20 @@ struct HalfRaw {
 template <int CNT>
 PG_HD void load_half(HalfRaw<CNT> &r, const float *__restrict__ G, int64_t ldg, const float *__restrict__ Y, int64_t ldy,
                      int64_t row0, int64_t n, int K, int lane, int ks0) {
+    if constexpr (kFastPath) {
+        if (row0 + kRows <= n && 32 * CNT == K) {     // (wave-uniform) inside the matrix: no predicates
+            const int64_t at = 8 * (lane >> 5) + 16 * ks0;
+            const float *gb = G + (row0 + (lane & 31)) * ldg + at, *yb = Y + (row0 + (lane & 31)) * ldy + at;
+#pragma unroll
+            for (int i = 0; i < CNT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    r.g[i][h] = *reinterpret_cast<const f32x4 *>(gb + 16 * i + 4 * h);
+                    r.y[i][h] = *reinterpret_cast<const f32x4 *>(yb + 16 * i + 4 * h);
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < CNT; ++i)
 #pragma unroll
@@ -332,6 +418,19 @@ PG_HD void load_half(HalfRaw<CNT> &r, const float *__restrict__ G, int64_t ldg, 
 template <int CNT>
 PG_HD void mask_half(f32x4 (&v)[CNT][2], const HalfRaw<CNT> &r, float *__restrict__ Gm, int64_t ldgm, int64_t row0, int64_t n, int K,
                      int lane, int ks0) {
+    if constexpr (kFastPath) {
+        if (row0 + kRows <= n && 32 * CNT == K) {
+            float *mb = Gm ? Gm + (row0 + (lane & 31)) * ldgm + 8 * (lane >> 5) + 16 * ks0 : nullptr;
+#pragma unroll
+            for (int i = 0; i < CNT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    v[i][h] = mask4(r.g[i][h], r.y[i][h]);
+                    if (mb) *reinterpret_cast<f32x4 *>(mb + 16 * i + 4 * h) = v[i][h];
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < CNT; ++i)
 #pragma unroll
@@ -431,6 +530,14 @@ __global__ __launch_bounds__(kThreads, 2) void dense_kernel(const float *__restr
         auto one_tile = [&](const TileA<NKS> &from, TileA<NKS> &into) {
             const int64_t tn = tile + stride;
             zero_acc(acc);
+            if constexpr (kProbe == 3) {              // timing only: no loads after the first tile
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) { asm volatile("" : "+v"(t0.v[ks][0]), "+v"(t0.v[ks][1])); }
+                tile_product<NKS, NBLK, 0, NKS>(t0, image, lane, acc);
+                store_c(acc, NBLK, C, ldc, tile * kRows, n, N, lane, relu);
+                tile = tn;
+                return;
+            }
             if constexpr (kPrefetch == 2) {
                 if (tn < ntiles) load_tile<NKS>(into, A, lda, tn * kRows, n, K, lane);
                 __builtin_amdgcn_sched_barrier(0);
