@@ -1,7 +1,7 @@
 // pgcn_dense.hip -- the dense products of a layer on the bf16 matrix cores at fp32 accuracy, fused with what surrounds them:
 //     forward    Y  = relu(X . W^T)                  (/root/reference/GPU/PGCN.py:146-147  `F.relu(self.linear(AH))`)
 //     backward   Gm = G (.) [Y > 0],  dX = Gm . W    (autograd of the same two lines; dW = Gm^T . X stays a library GEMM)
-// north_star reserves MFMA for exactly this contraction; rounds 1-4 ran it as stock rocBLAS kernels (64 us per product at
+// north_star reserves MFMA for exactly this contraction; rounds 1-4 ran it as stock rocBLAS kernels (85 us per product at
 // n = 232 965, f = 128: profiles/r04_gemm_pick.txt) plus a ReLU pass (35 us) and a mask pass (50 us).  An n x K x N product with
 // K, N <= 128 moves 2 x n x 512 B and needs 2 n K N flops: HBM-bound (30 us at 8 TB/s for the benchmark layer) as long as the
 // matrix pipes stay under that, which the fp32 MFMA does not (49 us at its peak) and six bf16 MFMAs do (18 us).

@@ -78,8 +78,8 @@ class Tuning:
     dense_fused: int = 0             # relu(x . W^T) (1) and also (g (.) mask) . W (2) as the package's own bf16-split MFMA kernels
                                      # (gemm/pgcn_dense.hip, fp32 accuracy) instead of library GEMM + ReLU / mask passes.  Written at the end of
                                      # r04: checked on hardware through tools/micro/dense_fused_bench only (profiles/r04_dense_fused_*.txt:
-                                     # forward 74.6 us against 64 + 35 us of rocBLAS + clamp at n = 232 965, f = 128; input gradient 131 us
-                                     # against 50 + 65 us), no epoch has been timed with it -- off until one has
+                                     # forward 74.6 us against 85 + 35 us of rocBLAS + clamp at n = 232 965, f = 128; input gradient 131 us
+                                     # against 50 + 86 us), no epoch has been timed with it -- off until one has
     # ---- GAT path -------------------------------------------------------------------------------------------
     gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
     gat_sliced: bool = True          # XCD-sliced edge gradient
