@@ -206,6 +206,7 @@ PG_HD void store_c(const f32x16 *acc, int nblk, float *C, int64_t ldc, int64_t r
         if (sum == 123456.789f) C[row0 * ldc + lo] = sum;
         return;
     }
+#endif
     if constexpr (kFastPath) {
         if (row0 + kRows <= n && 32 * nblk == N) {    // (wave-uniform) the tile lies inside C: no predicates
             float *base = C + (row0 + 4 * hi) * ldc + lo;
@@ -217,7 +218,6 @@ PG_HD void store_c(const f32x16 *acc, int nblk, float *C, int64_t ldc, int64_t r
             return;
         }
     }
-#endif
 #pragma unroll
     for (int nb = 0; nb < nblk; ++nb) {
         const int col = 32 * nb + lo;
@@ -256,10 +256,7 @@ int check(const void *A, int64_t lda, int64_t n, int K, int N, const void *W, in
 }
 
 
-#ifndef PGCN_DENSE_HOST_EMU
-// ---- device ---------------------------------------------------------------------------------------------------------
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-
+// ---- a wave's operand tiles (both builds: the host build runs these lane by lane) -----------------------------------------------
 template <int NKS>
 struct TileA {
     f32x4 v[NKS][2];
@@ -311,6 +308,73 @@ PG_HD void load_tile_masked(TileA<NKS> &t, const float *__restrict__ G, int64_t 
             }
     }
 }
+
+// ---- the masked operand as a stream of HALF tiles (k steps [KS0, KS0 + CNT) of a tile) ---------------------------------------
+// G and Y of a half are 2 x CNT x 2 loads of 16 bytes; while one half is multiplied the next one (the second half of the tile,
+// or the first half of the wave's next tile) is in flight: 32 + 64 + 64 registers instead of the 128 + 64 a whole tile of
+// G and Y would hold beside the accumulators.
+template <int CNT>
+struct HalfRaw {
+    f32x4 g[CNT][2], y[CNT][2];
+};
+template <int CNT>
+PG_HD void load_half(HalfRaw<CNT> &r, const float *__restrict__ G, int64_t ldg, const float *__restrict__ Y, int64_t ldy,
+                     int64_t row0, int64_t n, int K, int lane, int ks0) {
+    if constexpr (kFastPath) {
+        if (row0 + kRows <= n && 32 * CNT == K) {     // (wave-uniform) inside the matrix: no predicates
+            const int64_t at = 8 * (lane >> 5) + 16 * ks0;
+            const float *gb = G + (row0 + (lane & 31)) * ldg + at, *yb = Y + (row0 + (lane & 31)) * ldy + at;
+#pragma unroll
+            for (int i = 0; i < CNT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    r.g[i][h] = *reinterpret_cast<const f32x4 *>(gb + 16 * i + 4 * h);
+                    r.y[i][h] = *reinterpret_cast<const f32x4 *>(yb + 16 * i + 4 * h);
+                }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CNT; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const Piece pg = piece_of(row0, n, K, ldg, lane, ks0 + i, h);
+            const Piece py = piece_of(row0, n, K, ldy, lane, ks0 + i, h);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            r.g[i][h] = pg.ok ? *reinterpret_cast<const f32x4 *>(G + pg.off) : z;
+            r.y[i][h] = py.ok ? *reinterpret_cast<const f32x4 *>(Y + py.off) : z;
+        }
+}
+template <int CNT>
+PG_HD void mask_half(f32x4 (&v)[CNT][2], const HalfRaw<CNT> &r, float *__restrict__ Gm, int64_t ldgm, int64_t row0, int64_t n, int K,
+                     int lane, int ks0) {
+    if constexpr (kFastPath) {
+        if (row0 + kRows <= n && 32 * CNT == K) {
+            float *mb = Gm ? Gm + (row0 + (lane & 31)) * ldgm + 8 * (lane >> 5) + 16 * ks0 : nullptr;
+#pragma unroll
+            for (int i = 0; i < CNT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    v[i][h] = mask4(r.g[i][h], r.y[i][h]);
+                    if (mb) *reinterpret_cast<f32x4 *>(mb + 16 * i + 4 * h) = v[i][h];
+                }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CNT; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v[i][h] = mask4(r.g[i][h], r.y[i][h]);
+            if (Gm) {
+                const Piece pm = piece_of(row0, n, K, ldgm, lane, ks0 + i, h);
+                if (pm.ok) *reinterpret_cast<f32x4 *>(Gm + pm.off) = v[i][h];
+            }
+        }
+}
+#ifndef PGCN_DENSE_HOST_EMU
+// ---- device ---------------------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 PG_HD void read_b(u32x4 (&b)[3], const char *image, int ks, int nb, int lane) {
 #pragma unroll
@@ -379,69 +443,6 @@ PG_HD void zero_acc(f32x16 (&acc)[NBLK]) {
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 }
 
-// ---- the masked operand as a stream of HALF tiles (k steps [KS0, KS0 + CNT) of a tile) ---------------------------------------
-// G and Y of a half are 2 x CNT x 2 loads of 16 bytes; while one half is multiplied the next one (the second half of the tile,
-// or the first half of the wave's next tile) is in flight: 32 + 64 + 64 registers instead of the 128 + 64 a whole tile of
-// G and Y would hold beside the accumulators.
-template <int CNT>
-struct HalfRaw {
-    f32x4 g[CNT][2], y[CNT][2];
-};
-template <int CNT>
-PG_HD void load_half(HalfRaw<CNT> &r, const float *__restrict__ G, int64_t ldg, const float *__restrict__ Y, int64_t ldy,
-                     int64_t row0, int64_t n, int K, int lane, int ks0) {
-    if constexpr (kFastPath) {
-        if (row0 + kRows <= n && 32 * CNT == K) {     // (wave-uniform) inside the matrix: no predicates
-            const int64_t at = 8 * (lane >> 5) + 16 * ks0;
-            const float *gb = G + (row0 + (lane & 31)) * ldg + at, *yb = Y + (row0 + (lane & 31)) * ldy + at;
-#pragma unroll
-            for (int i = 0; i < CNT; ++i)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    r.g[i][h] = *reinterpret_cast<const f32x4 *>(gb + 16 * i + 4 * h);
-                    r.y[i][h] = *reinterpret_cast<const f32x4 *>(yb + 16 * i + 4 * h);
-                }
-            return;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < CNT; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const Piece pg = piece_of(row0, n, K, ldg, lane, ks0 + i, h);
-            const Piece py = piece_of(row0, n, K, ldy, lane, ks0 + i, h);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            r.g[i][h] = pg.ok ? *reinterpret_cast<const f32x4 *>(G + pg.off) : z;
-            r.y[i][h] = py.ok ? *reinterpret_cast<const f32x4 *>(Y + py.off) : z;
-        }
-}
-template <int CNT>
-PG_HD void mask_half(f32x4 (&v)[CNT][2], const HalfRaw<CNT> &r, float *__restrict__ Gm, int64_t ldgm, int64_t row0, int64_t n, int K,
-                     int lane, int ks0) {
-    if constexpr (kFastPath) {
-        if (row0 + kRows <= n && 32 * CNT == K) {
-            float *mb = Gm ? Gm + (row0 + (lane & 31)) * ldgm + 8 * (lane >> 5) + 16 * ks0 : nullptr;
-#pragma unroll
-            for (int i = 0; i < CNT; ++i)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    v[i][h] = mask4(r.g[i][h], r.y[i][h]);
-                    if (mb) *reinterpret_cast<f32x4 *>(mb + 16 * i + 4 * h) = v[i][h];
-                }
-            return;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < CNT; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            v[i][h] = mask4(r.g[i][h], r.y[i][h]);
-            if (Gm) {
-                const Piece pm = piece_of(row0, n, K, ldgm, lane, ks0 + i, h);
-                if (pm.ok) *reinterpret_cast<f32x4 *>(Gm + pm.off) = v[i][h];
-            }
-        }
-}
 template <int NBLK, int CNT>
 PG_HD void half_product(const f32x4 (&v)[CNT][2], const char *image, int lane, int ks0, f32x16 (&acc)[NBLK]) {
     if constexpr (kPipe) {
@@ -659,10 +660,63 @@ void mfma_emu(const u32x4 (&a)[64], const u32x4 (&b)[64], f32x16 (&acc)[64]) {
     }
 }
 
-f32x4 load4(const float *base, const Piece &p) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (p.ok) memcpy(&v, base + p.off, 16);
-    return v;
+// One launch with the kernel's template parameters: the image as the kernel fills it, every tile loaded by the kernel's own
+// loaders (forward: load_tile; backward: load_half + mask_half, the two halves of a tile), stored by its store_c.
+template <int NKS, int NBLK>
+int emulate(int mode, const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm, int64_t n, int K, int N,
+            const float *W, int64_t ldw, float *C, int64_t ldc, int relu) {
+    alignas(16) static char image[kImageBytes];
+    memset(image, 0xff, sizeof image);                       // (slots the kernel does not fill must not be read)
+    for (int s = 0; s < kSlotsPerPlane; ++s) {
+        const int ks = s >> 8, nb = (s >> 6) & 3;
+        if (ks < NKS && nb < NBLK) {
+            float v[8];
+            slot_load(W, ldw, mode == 0, K, N, s, v);
+            slot_store(image, s, v);
+        }
+    }
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        static TileA<NKS> t[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            if (mode == 0) {
+                load_tile<NKS>(t[lane], A, lda, tile * kRows, n, K, lane);
+            } else {
+                constexpr int H = NKS / 2;
+                for (int half = 0; half < 2; ++half) {
+                    HalfRaw<H> raw;
+                    f32x4 v[H][2];
+                    load_half<H>(raw, A, lda, Y, ldy, tile * kRows, n, K, lane, half * H);
+                    mask_half<H>(v, raw, Gm, ldgm, tile * kRows, n, K, lane, half * H);
+                    for (int i = 0; i < H; ++i) { t[lane].v[half * H + i][0] = v[i][0]; t[lane].v[half * H + i][1] = v[i][1]; }
+                }
+            }
+        }
+        static f32x16 acc[NBLK][64];
+        for (int nb = 0; nb < NBLK; ++nb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 16; ++r) acc[nb][lane][r] = 0.f;
+        for (int ks = 0; ks < NKS; ++ks) {
+            static u32x4 a[3][64], b[3][64];
+            for (int lane = 0; lane < 64; ++lane) {
+                u32x4 p[3];
+                split8(t[lane].v[ks][0], t[lane].v[ks][1], p);
+                for (int pl = 0; pl < 3; ++pl) a[pl][lane] = p[pl];
+            }
+            for (int nb = 0; nb < NBLK; ++nb) {
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int pl = 0; pl < 3; ++pl) memcpy(&b[pl][lane], image + image_offset(pl, ks, nb, lane), 16);
+                PGCN_DENSE_PRODUCTS;
+                for (int i = 0; i < 6; ++i) mfma_emu(a[kPA[i]], b[kPB[i]], acc[nb]);
+            }
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            f32x16 mine[NBLK];
+            for (int nb = 0; nb < NBLK; ++nb) mine[nb] = acc[nb][lane];
+            store_c(mine, NBLK, C, ldc, tile * kRows, n, N, lane, relu);
+        }
+    }
+    return 0;
 }
 }  // namespace
 
@@ -682,55 +736,15 @@ int dispatch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm
 extern "C" int pgcn_dense_emulate(int mode, const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm,
                                   int64_t n, int K, int N, const float *W, int64_t ldw, float *C, int64_t ldc, int relu) {
     if (K <= 0 || N <= 0 || K > kMaxF || N > kMaxF || K % 4) return -2;
-    alignas(16) static char image[kImageBytes];
-    memset(image, 0xff, sizeof image);                       // (slots the kernel does not fill must not be read)
-    const int nks = (K + 15) / 16, nblk = (N + 31) / 32;
-    for (int s = 0; s < kSlotsPerPlane; ++s) {
-        const int ks = s >> 8, nb = (s >> 6) & 3;
-        if (ks < nks && nb < nblk) {
-            float v[8];
-            slot_load(W, ldw, mode == 0, K, N, s, v);
-            slot_store(image, s, v);
-        }
-    }
-    const int64_t ntiles = (n + kRows - 1) / kRows;
-    for (int64_t tile = 0; tile < ntiles; ++tile) {
-        static f32x4 v[64][8][2];
-        for (int lane = 0; lane < 64; ++lane)
-            for (int ks = 0; ks < nks; ++ks)
-                for (int h = 0; h < 2; ++h) {
-                    v[lane][ks][h] = load4(A, piece_of(tile * kRows, n, K, lda, lane, ks, h));
-                    if (mode == 1) {
-                        v[lane][ks][h] = mask4(v[lane][ks][h], load4(Y, piece_of(tile * kRows, n, K, ldy, lane, ks, h)));
-                        const Piece pm = piece_of(tile * kRows, n, K, ldgm, lane, ks, h);
-                        if (Gm && pm.ok) memcpy(Gm + pm.off, &v[lane][ks][h], 16);
-                    }
-                }
-        static f32x16 acc[4][64];
-        for (int nb = 0; nb < nblk; ++nb)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int r = 0; r < 16; ++r) acc[nb][lane][r] = 0.f;
-        for (int ks = 0; ks < nks; ++ks) {
-            static u32x4 a[3][64], b[3][64];
-            for (int lane = 0; lane < 64; ++lane) {
-                u32x4 p[3];
-                split8(v[lane][ks][0], v[lane][ks][1], p);
-                for (int pl = 0; pl < 3; ++pl) a[pl][lane] = p[pl];
-            }
-            for (int nb = 0; nb < nblk; ++nb) {
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int pl = 0; pl < 3; ++pl) memcpy(&b[pl][lane], image + image_offset(pl, ks, nb, lane), 16);
-                PGCN_DENSE_PRODUCTS;
-                for (int i = 0; i < 6; ++i) mfma_emu(a[kPA[i]], b[kPB[i]], acc[nb]);
-            }
-        }
-        for (int lane = 0; lane < 64; ++lane) {
-            f32x16 mine[4];
-            for (int nb = 0; nb < nblk; ++nb) mine[nb] = acc[nb][lane];
-            store_c(mine, nblk, C, ldc, tile * kRows, n, N, lane, relu);
-        }
-    }
-    return 0;
+    const int nks = (K + 15) / 16, nblk = (N + 31) / 32;      // the kernel's own choice of instantiation (dispatch)
+#define PGCN_DENSE_CASE(KS, NB) \
+    if (nks <= KS && nblk <= NB) return emulate<KS, NB>(mode, A, lda, Y, ldy, Gm, ldgm, n, K, N, W, ldw, C, ldc, relu);
+    PGCN_DENSE_CASE(4, 2)
+    PGCN_DENSE_CASE(4, 4)
+    PGCN_DENSE_CASE(8, 2)
+    PGCN_DENSE_CASE(8, 4)
+#undef PGCN_DENSE_CASE
+    return -2;
 }
 #endif
 

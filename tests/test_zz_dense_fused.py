@@ -37,15 +37,25 @@ def test_library_exports_the_dense_entry_points():
     assert P.bind_dense_library(P.GEMM_LIB_PATH).pgcn_linear_relu_f32.argtypes is not None
 
 
-@pytest.fixture(scope="module")
-def emu(tmp_path_factory):
-    """The host build of gemm/pgcn_dense.hip, bound like the library."""
+def _host_build(tmp_path_factory, name, *flags):
     if not os.path.exists(CLANG):
         pytest.skip("no clang++ for the host build of gemm/pgcn_dense.hip")
-    out = str(tmp_path_factory.mktemp("dense_emu") / "libpgcn_dense_emu.so")
+    out = str(tmp_path_factory.mktemp(name) / ("libpgcn_%s.so" % name))
     subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DPGCN_DENSE_HOST_EMU", "-Wno-pass-failed",
-                           SRC, "-o", out])
+                           *flags, SRC, "-o", out])
     return pkg("PGCN").bind_dense_library(out)
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    """The host build of gemm/pgcn_dense.hip (the library's configuration), bound like the library."""
+    return _host_build(tmp_path_factory, "dense_emu")
+
+
+@pytest.fixture(scope="module")
+def emu_fast(tmp_path_factory):
+    """... and of the candidate with predicate-free loads / stores of tiles that lie inside the matrices (r05's first probe)."""
+    return _host_build(tmp_path_factory, "dense_emu_fast", "-DPGCN_DENSE_FASTPATH=1")
 
 
 def _rel(got, want, den):
@@ -79,6 +89,21 @@ SHAPES = [(77, 128, 128), (32, 64, 64), (100, 36, 128), (65, 128, 40), (5, 8, 4)
 def test_host_build_reproduces_the_products(emu, n, fin, fout):
     ef, eb = _check_pair(pkg("PGCN"), emu, n, fin, fout, None)
     assert ef <= BOUND and eb <= BOUND, (ef, eb)
+
+
+@pytest.mark.parametrize("n,fin,fout", SHAPES + [(96, 128, 128), (64, 64, 64), (97, 64, 128), (200, 128, 64)])
+def test_host_build_of_the_predicate_free_candidate(emu, emu_fast, n, fin, fout):
+    """Inner tiles of full-width operands take the unguarded path, ragged ones the guarded one: the same bits as the library's build."""
+    P = pkg("PGCN")
+    ef, eb = _check_pair(P, emu_fast, n, fin, fout, None)
+    assert ef <= BOUND and eb <= BOUND, (ef, eb)
+    g0 = torch.Generator().manual_seed(9)
+    x, w = torch.randn(n, fin, generator=g0), torch.randn(fout, fin, generator=g0)
+    assert torch.equal(P.linear_relu_call(emu_fast, x, w, True, None), P.linear_relu_call(emu, x, w, True, None))
+    g = torch.randn(n, fout, generator=g0)
+    y = P.linear_relu_call(emu, x, w, True, None)
+    a, b = P.linear_relu_grad_input_call(emu_fast, g, y, w, None), P.linear_relu_grad_input_call(emu, g, y, w, None)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 def test_host_build_padded_rows_and_in_place_mask(emu):
