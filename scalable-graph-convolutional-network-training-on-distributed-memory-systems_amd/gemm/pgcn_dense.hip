@@ -58,6 +58,9 @@ constexpr bool kPipe = PGCN_DENSE_PIPE != 0;
 //   PGCN_DENSE_FASTPATH 1: tiles that lie inside the matrix (all but a wave's last) load and store without per-piece predicates
 //     (the first version wraps each of its 16 loads and 64 stores in an exec-mask branch);
 //   PGCN_DENSE_NT_STORE 1: the stores of C carry the non-temporal hint (C is not read again by this kernel);
+//   PGCN_DENSE_CT 1: the MFMA computes the TRANSPOSED tile (the image of W as the A operand, the rows of X as B -- both operands
+//     have the same lane layout, so only the two arguments swap): a lane then holds 4 x 4 CONSECUTIVE columns of ONE row of C
+//     and stores 16 bytes at a time, 16 store instructions per tile instead of 64, addressed like its loads;
 // and TIMING-ONLY probes (wrong results by construction; tools/micro/dense_fused_bench labels them):
 //   PGCN_DENSE_PROBE 1: no MFMAs;  2: no stores of C (one never-true predicate over all accumulators keeps the products alive);
 //   3: the wave's first tile is multiplied again and again (no loads after the first; registers made opaque per tile).
@@ -70,7 +73,10 @@ constexpr bool kPipe = PGCN_DENSE_PIPE != 0;
 #ifndef PGCN_DENSE_PROBE
 #define PGCN_DENSE_PROBE 0
 #endif
-constexpr bool kFastPath = PGCN_DENSE_FASTPATH != 0, kNtStore = PGCN_DENSE_NT_STORE != 0;
+#ifndef PGCN_DENSE_CT
+#define PGCN_DENSE_CT 0
+#endif
+constexpr bool kFastPath = PGCN_DENSE_FASTPATH != 0, kNtStore = PGCN_DENSE_NT_STORE != 0, kCT = PGCN_DENSE_CT != 0;
 constexpr int kProbe = PGCN_DENSE_PROBE;
 constexpr int kRows = 32;                 // rows of a wave's tile = M of the MFMA
 constexpr int kMaxF = 128;                // K and N of a product
@@ -194,8 +200,39 @@ PG_HD void store1(float *p, float x) {
 #endif
     *p = x;
 }
+// ... and of the transposed tile (kCT): register r = 4 q + e of lane (lo, hi), block nb -> element (row0 + lo, 32 nb + 8 q + 4 hi + e)
+PG_HD void store_ct(const f32x16 *acc, int nblk, float *C, int64_t ldc, int64_t row0, int64_t n, int N, int lane, int relu) {
+    const int hi = lane >> 5, lo = lane & 31;
+    const int64_t row = row0 + lo;
+    if (row >= n) return;
+    float *dst = C + row * ldc;
+    const bool wide = ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && N % 4 == 0;      // (uniform) whole, aligned 16-byte stores
+    if (wide) {
+#pragma unroll
+        for (int nb = 0; nb < nblk; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = 32 * nb + 8 * q + 4 * hi;
+                f32x4 v = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
+                if (relu) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
+                if (col < N) *reinterpret_cast<f32x4 *>(dst + col) = v;
+            }
+        return;
+    }
+#pragma unroll
+    for (int nb = 0; nb < nblk; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = 32 * nb + 8 * (r >> 2) + 4 * hi + (r & 3);
+            if (col < N) dst[col] = relu ? relu1(acc[nb][r]) : acc[nb][r];
+        }
+}
 PG_HD void store_c(const f32x16 *acc, int nblk, float *C, int64_t ldc, int64_t row0, int64_t n, int N, int lane, int relu) {
     const int hi = lane >> 5, lo = lane & 31;
+    if constexpr (kCT) {
+        store_ct(acc, nblk, C, ldc, row0, n, N, lane, relu);
+        return;
+    }
 #ifndef PGCN_DENSE_HOST_EMU
     if constexpr (kProbe == 2) {                      // timing only: every accumulator is needed, nothing is written
         float sum = 0.f;
@@ -376,6 +413,11 @@ PG_HD void mask_half(f32x4 (&v)[CNT][2], const HalfRaw<CNT> &r, float *__restric
 // ---- device ---------------------------------------------------------------------------------------------------------
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
+// one partial product: x = a plane of the streamed operand (rows of X / G), w = a plane of the image
+PG_HD f32x16 mma(const u32x4 &x, const u32x4 &w, const f32x16 &c) {
+    if constexpr (kCT) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, w), c, 0, 0, 0);
+}
 PG_HD void read_b(u32x4 (&b)[3], const char *image, int ks, int nb, int lane) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(image + image_offset(pl, ks, nb, lane));
@@ -400,8 +442,7 @@ PG_HD void product_steps(const f32x4 (&v)[CNT][2], const char *image, int lane, 
                 acc[nb][j] += __builtin_bit_cast(float, a[kPA[j]].x ^ b[t & 1][kPB[j]].x);
                 continue;
             }
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kPA[j]]),
-                                                               __builtin_bit_cast(bf16x8, b[t & 1][kPB[j]]), acc[nb], 0, 0, 0);
+            acc[nb] = mma(a[kPA[j]], b[t & 1][kPB[j]], acc[nb]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -429,8 +470,7 @@ PG_HD void tile_product(const TileA<NKS> &t, const char *image, int lane, f32x16
             for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(image + image_offset(pl, ks, nb, lane));
 #pragma unroll
             for (int i = 0; i < 6; ++i)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kPA[i]]),
-                                                                   __builtin_bit_cast(bf16x8, b[kPB[i]]), acc[nb], 0, 0, 0);
+                acc[nb] = mma(a[kPA[i]], b[kPB[i]], acc[nb]);
             __builtin_amdgcn_sched_barrier(0);     // (left alone the scheduler hoists every split and LDS read of the tile: spills)
         }
     }
@@ -461,8 +501,7 @@ PG_HD void half_product(const f32x4 (&v)[CNT][2], const char *image, int lane, i
             for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(image + image_offset(pl, ks0 + i, nb, lane));
 #pragma unroll
             for (int j = 0; j < 6; ++j)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kPA[j]]),
-                                                                   __builtin_bit_cast(bf16x8, b[kPB[j]]), acc[nb], 0, 0, 0);
+                acc[nb] = mma(a[kPA[j]], b[kPB[j]], acc[nb]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -707,7 +746,10 @@ int emulate(int mode, const float *A, int64_t lda, const float *Y, int64_t ldy, 
                 for (int lane = 0; lane < 64; ++lane)
                     for (int pl = 0; pl < 3; ++pl) memcpy(&b[pl][lane], image + image_offset(pl, ks, nb, lane), 16);
                 PGCN_DENSE_PRODUCTS;
-                for (int i = 0; i < 6; ++i) mfma_emu(a[kPA[i]], b[kPB[i]], acc[nb]);
+                for (int i = 0; i < 6; ++i) {
+                    if (kCT) mfma_emu(b[kPB[i]], a[kPA[i]], acc[nb]);      // (the kernel's mma(): operands swapped)
+                    else mfma_emu(a[kPA[i]], b[kPB[i]], acc[nb]);
+                }
             }
         }
         for (int lane = 0; lane < 64; ++lane) {

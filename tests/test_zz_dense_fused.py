@@ -91,6 +91,27 @@ def test_host_build_reproduces_the_products(emu, n, fin, fout):
     assert ef <= BOUND and eb <= BOUND, (ef, eb)
 
 
+@pytest.fixture(scope="module")
+def emu_ct(tmp_path_factory):
+    """... and of the candidate that lets the MFMA compute the transposed tile (16-byte stores of C)."""
+    return _host_build(tmp_path_factory, "dense_emu_ct", "-DPGCN_DENSE_FASTPATH=1", "-DPGCN_DENSE_CT=1")
+
+
+@pytest.mark.parametrize("n,fin,fout", SHAPES + [(96, 128, 128), (97, 64, 128), (50, 128, 41), (10, 8, 7)])
+def test_host_build_of_the_transposed_tile_candidate(emu, emu_ct, n, fin, fout):
+    """Swapped MFMA operands + the row-wise store routine: the same bits as the library's build, ragged widths included."""
+    P = pkg("PGCN")
+    g0 = torch.Generator().manual_seed(11)
+    x, w = torch.randn(n, fin, generator=g0), torch.randn(fout, fin, generator=g0)
+    y = P.linear_relu_call(emu, x, w, True, None)
+    assert torch.equal(P.linear_relu_call(emu_ct, x, w, True, None), y)
+    assert torch.equal(P.linear_relu_call(emu_ct, x, w, False, None), P.linear_relu_call(emu, x, w, False, None))
+    if fout % 4 == 0:
+        g = torch.randn(n, fout, generator=g0)
+        a, b = P.linear_relu_grad_input_call(emu_ct, g, y, w, None), P.linear_relu_grad_input_call(emu, g, y, w, None)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("n,fin,fout", SHAPES + [(96, 128, 128), (64, 64, 64), (97, 64, 128), (200, 128, 64)])
 def test_host_build_of_the_predicate_free_candidate(emu, emu_fast, n, fin, fout):
     """Inner tiles of full-width operands take the unguarded path, ragged ones the guarded one: the same bits as the library's build."""

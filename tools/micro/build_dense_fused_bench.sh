@@ -10,12 +10,13 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
 objs=("$HERE/dense_fused_kernels.o")
 # probe builds under their own symbol names: p0 = pipelined steps, loads after the stores, masked operand by whole tiles;
 # p2 = the first version (LDS reads / wait / MFMAs per step, cur = nxt copies, no prefetch, whole tiles); f1 / f2 = the candidates
-# of the end of r04 (predicate-free inner tiles; + non-temporal stores); t1-t3 = timing-only probes (see gemm/pgcn_dense.hip)
+# of the end of r04 (predicate-free inner tiles; + non-temporal stores; c1 = + the transposed tile with 16-byte stores); t1-t3 = timing-only probes (see gemm/pgcn_dense.hip)
 declare -A VAR=([p0]="-DPGCN_DENSE_PIPE=1 -DPGCN_DENSE_PREFETCH=0 -DPGCN_DENSE_MASK_PIPE=0"
                 [p2]="-DPGCN_DENSE_PIPE=0 -DPGCN_DENSE_PREFETCH=0 -DPGCN_DENSE_MASK_PIPE=0"
                 [f1]="-DPGCN_DENSE_FASTPATH=1" [f2]="-DPGCN_DENSE_FASTPATH=1 -DPGCN_DENSE_NT_STORE=1"
+                [c1]="-DPGCN_DENSE_FASTPATH=1 -DPGCN_DENSE_CT=1"
                 [t1]="-DPGCN_DENSE_PROBE=1" [t2]="-DPGCN_DENSE_PROBE=2" [t3]="-DPGCN_DENSE_PROBE=3")
-for v in p0 p2 f1 f2 t1 t2 t3; do
+for v in p0 p2 f1 f2 c1 t1 t2 t3; do
   "$HIPCC" $F ${VAR[$v]} -Dpgcn_dense=pgcn_dense_$v -Dpgcn_linear_relu_f32=pgcn_linear_relu_f32_$v \
     -Dpgcn_linear_relu_grad_input_f32=pgcn_linear_relu_grad_input_f32_$v -Dpgcn_dense_last_error=pgcn_dense_last_error_$v \
     -c "$SRC" -o "$HERE/dense_fused_kernels_$v.o" &
