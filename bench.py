@@ -958,6 +958,10 @@ def main():
                                   "dW: PyTorch's default pick" if not partition._T.gemm_tunableop else
                                   "stock rocBLAS / hipBLASLt via PyTorch, kernel per shape picked by TunableOp in set-up") if gemm_tuned
                                  else "stock rocBLAS / hipBLASLt via PyTorch (default pick)",
+                   "dense_fused": {0: "off (library GEMM + clamp / mask passes)",
+                                   1: "relu(x.W^T) by gemm/pgcn_dense.hip (bf16-split MFMA, fp32 accuracy)",
+                                   2: "relu(x.W^T) and (g (.) mask).W by gemm/pgcn_dense.hip (bf16-split MFMA, fp32 accuracy)"
+                                   }.get(int(partition._T.dense_fused), str(partition._T.dense_fused)),
                    "strip_tiles": {"min_entries": partition.STRIP_MIN, "layer_min": partition.STRIP_LAYER_MIN,
                                    "whole_graphs_from_nnz": partition._T.strip_big_nnz, "min_entries_big": partition._T.strip_min_big,
                                    "layer_min_big": partition._T.strip_layer_min_big}
