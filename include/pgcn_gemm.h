@@ -43,6 +43,17 @@ int pgcn_linear_relu_grad_input_f32(const float *G, int64_t ldg, const float *Y,
                                     int64_t n, int32_t fout, const float *W, int64_t ldw, int32_t fin, float *dX,
                                     int64_t lddx, void *stream);
 
+/* dW (fout x fin, lddw) = Gm^T . X, the weight gradient of the same layer (autograd's `grad_output.t() @ input`), same arithmetic
+ * (source: <package>/gemm/pgcn_wgrad.hip): one workgroup per CU multiplies a contiguous range of rows into a partial matrix in
+ * `ws`, a second kernel adds the partials in a fixed order (deterministic).  Gm: n x fout (ldg), X: n x fin (ldx), widths up to
+ * 128, no alignment requirement; ws: at least pgcn_linear_weight_grad_ws_elems() floats of device memory (32 MB), free for
+ * other use once the stream has passed the call.  Return values as above (pgcn_wgrad_last_error()).
+ * Written at the end of round 4 and checked through its host build only: not yet run on hardware. */
+const char *pgcn_wgrad_last_error(void);
+int64_t pgcn_linear_weight_grad_ws_elems(void);
+int pgcn_linear_weight_grad_f32(const float *Gm, int64_t ldg, const float *X, int64_t ldx, int64_t n, int32_t fout, int32_t fin,
+                                float *dW, int64_t lddw, float *ws, int64_t ws_elems, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

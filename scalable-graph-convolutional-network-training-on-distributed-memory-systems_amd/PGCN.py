@@ -298,6 +298,18 @@ def bind_dense_library(path):
     L.pgcn_linear_relu_grad_input_f32.restype = ctypes.c_int
     L.pgcn_linear_relu_grad_input_f32.argtypes = [ptr, i64, ptr, i64, ptr, i64, i64, i32, ptr, i64, i32, ptr, i64, ptr]
     L.pgcn_dense_last_error.restype = ctypes.c_char_p
+    if hasattr(L, "pgcn_linear_weight_grad_f32"):        # (gemm/pgcn_wgrad.hip: its host build is a library of its own)
+        bind_wgrad_entry_points(L)
+    return L
+
+
+def bind_wgrad_entry_points(L):
+    import ctypes
+    i32, i64, ptr = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    L.pgcn_linear_weight_grad_f32.restype = ctypes.c_int
+    L.pgcn_linear_weight_grad_f32.argtypes = [ptr, i64, ptr, i64, i64, i32, i32, ptr, i64, ptr, i64, ptr]
+    L.pgcn_linear_weight_grad_ws_elems.restype = i64
+    L.pgcn_wgrad_last_error.restype = ctypes.c_char_p
     return L
 
 
@@ -351,6 +363,35 @@ def linear_relu_grad_input_call(L, g, y, weight, stream):
     if rc != 0:
         raise RuntimeError("pgcn_linear_relu_grad_input_f32: %s" % L.pgcn_dense_last_error().decode())
     return gm, gx
+
+
+_wgrad_ws = {}
+
+
+def linear_weight_grad_call(L, gm, x, ws, stream):
+    """gm^T . x through pgcn_linear_weight_grad_f32 of `L` (ws: float32 work-space of pgcn_linear_weight_grad_ws_elems()
+    elements on the operands' device), or None (-2)."""
+    if gm.dim() != 2 or x.dim() != 2 or gm.shape[0] != x.shape[0] or gm.stride(1) != 1 or x.stride(1) != 1:
+        return None
+    gw = torch.empty((gm.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
+    rc = L.pgcn_linear_weight_grad_f32(gm.data_ptr(), gm.stride(0), x.data_ptr(), x.stride(0), x.shape[0], gm.shape[1], x.shape[1],
+                                       gw.data_ptr(), gw.stride(0), ws.data_ptr(), ws.numel(), stream)
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError("pgcn_linear_weight_grad_f32: %s" % L.pgcn_wgrad_last_error().decode())
+    return gw
+
+
+def linear_weight_grad_fused(gm, x):
+    """gm^T . x (the weight gradient of the layer) by the package's matrix-core kernel on the current stream, or None."""
+    if not _dense_operand_ok(gm, x):
+        return None
+    L = _dense_lib()
+    key = (x.device.type, x.device.index)
+    if key not in _wgrad_ws:
+        _wgrad_ws[key] = torch.empty(L.pgcn_linear_weight_grad_ws_elems(), dtype=torch.float32, device=x.device)
+    return linear_weight_grad_call(L, gm, x, _wgrad_ws[key], _dense_stream(x))
 
 
 def linear_relu_fused(x, weight, relu=True):
@@ -437,7 +478,9 @@ class _LinearReluNoBias(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gx = mm_nn(g, weight)
         if ctx.needs_input_grad[1]:
-            gw = _LinearNoBias.weight_grad(g, x)
+            gw = linear_weight_grad_fused(g, x) if _dense_fused_level() >= 3 else None
+            if gw is None:
+                gw = _LinearNoBias.weight_grad(g, x)
         return gx, gw
 
 

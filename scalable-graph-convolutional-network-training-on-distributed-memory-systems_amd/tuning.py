@@ -75,7 +75,8 @@ class Tuning:
     gemm_tuning: bool = True         # use the recorded kernel choices for the n x f x f GEMMs of a layer (tunableop/gfx950.csv + cache) ...
     gemm_tunableop: bool = False     # ... through PyTorch's TunableOp, which also TIMES shapes without a record (set-up: + 20-30 s on a
                                      # cold box) instead of replaying the rocBLAS records by solution index (r04 default)
-    dense_fused: int = 0             # relu(x . W^T) (1) and also (g (.) mask) . W (2) as the package's own bf16-split MFMA kernels
+    dense_fused: int = 0             # relu(x . W^T) (1), also (g (.) mask) . W (2), also gm^T . x (3: gemm/pgcn_wgrad.hip, NOT yet run on
+                                     # hardware) as the package's own bf16-split MFMA kernels
                                      # (gemm/pgcn_dense.hip, fp32 accuracy) instead of library GEMM + ReLU / mask passes.  Written at the end of
                                      # r04: checked on hardware through tools/micro/dense_fused_bench only (profiles/r04_dense_fused_*.txt:
                                      # forward 74.6 us against 85 + 35 us of rocBLAS + clamp at n = 232 965, f = 128; input gradient 131 us

@@ -29,27 +29,31 @@ def test_library_exports_the_dense_entry_points():
     P = pkg("PGCN")
     src = open(os.path.join(ROOT, "include", "pgcn_gemm.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = sorted(set(re.findall(r"\b(pgcn_(?:linear|dense)_[a-z0-9_]+)\s*\(", src)))
-    assert names == ["pgcn_dense_last_error", "pgcn_linear_relu_f32", "pgcn_linear_relu_grad_input_f32"]
+    names = sorted(set(re.findall(r"\b(pgcn_(?:linear|dense|wgrad)_[a-z0-9_]+)\s*\(", src)))
+    assert names == ["pgcn_dense_last_error", "pgcn_linear_relu_f32", "pgcn_linear_relu_grad_input_f32", "pgcn_linear_weight_grad_f32",
+                     "pgcn_linear_weight_grad_ws_elems", "pgcn_wgrad_last_error"]
     L = ctypes.CDLL(P.GEMM_LIB_PATH)
     for n in names:
         assert hasattr(L, n), "libpgcn_gemm.so does not export %s" % n
     assert P.bind_dense_library(P.GEMM_LIB_PATH).pgcn_linear_relu_f32.argtypes is not None
 
 
-def _host_build(tmp_path_factory, name, *flags):
+SRC_WGRAD = os.path.join(PKG_DIR, "gemm", "pgcn_wgrad.hip")
+
+
+def _host_build(tmp_path_factory, name, *flags, sources=(SRC,)):
     if not os.path.exists(CLANG):
         pytest.skip("no clang++ for the host build of gemm/pgcn_dense.hip")
     out = str(tmp_path_factory.mktemp(name) / ("libpgcn_%s.so" % name))
     subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DPGCN_DENSE_HOST_EMU", "-Wno-pass-failed",
-                           *flags, SRC, "-o", out])
+                           *flags, *sources, "-o", out])
     return pkg("PGCN").bind_dense_library(out)
 
 
 @pytest.fixture(scope="module")
 def emu(tmp_path_factory):
-    """The host build of gemm/pgcn_dense.hip (the library's configuration), bound like the library."""
-    return _host_build(tmp_path_factory, "dense_emu")
+    """The host build of gemm/pgcn_dense.hip + gemm/pgcn_wgrad.hip (the library's configuration), bound like the library."""
+    return _host_build(tmp_path_factory, "dense_emu", sources=(SRC, SRC_WGRAD))
 
 
 @pytest.fixture(scope="module")
@@ -160,6 +164,42 @@ def test_refusals_are_minus_two_and_errors_minus_one(emu):
     assert emu.pgcn_linear_relu_f32(y.data_ptr(), 2, 4, 4, y.data_ptr(), 4, 4, y.data_ptr(), 4, 1, None) != 0   # ld below the width
 
 
+WGRAD_SHAPES = [(77, 128, 128, 3), (1000, 40, 128, 7), (33, 4, 4, 1), (500, 100, 36, 4), (64, 64, 64, 2), (0, 8, 8, 1), (1, 128, 128, 1),
+                (2000, 41, 7, 5), (300, 128, 64, 300), (4097, 128, 128, 256)]
+
+
+def _check_wgrad(P, L, n, fout, fin, stream, dev="cpu"):
+    g0 = torch.Generator().manual_seed(n + fout)
+    gm, x = torch.randn(n, fout, generator=g0).to(dev), torch.randn(n, fin, generator=g0).to(dev)
+    ws = torch.empty(L.pgcn_linear_weight_grad_ws_elems(), dtype=torch.float32, device=dev)
+    gw = P.linear_weight_grad_call(L, gm, x, ws, stream)
+    assert gw is not None and gw.shape == (fout, fin)
+    want, den = gm.double().t() @ x.double(), gm.double().abs().t() @ x.double().abs()
+    return (_rel(gw, want, den) if n else float(gw.abs().max())), gw, (gm, x, ws)
+
+
+@pytest.mark.parametrize("n,fout,fin,parts", WGRAD_SHAPES)
+def test_host_build_of_the_weight_gradient(emu, n, fout, fin, parts):
+    """gemm/pgcn_wgrad.hip: the kernel's column loaders, its partition of the rows over `parts` workgroups, the layout of the partial
+    matrices and their ordered sum, around the emulated MFMA (the host build takes the number of workgroups in the stream argument)."""
+    P = pkg("PGCN")
+    e, gw, (gm, x, ws) = _check_wgrad(P, emu, n, fout, fin, parts)
+    assert e <= BOUND, e
+    if n:                                                             # padded rows: leading dimensions above the widths
+        gmp, xp = torch.zeros(n, fout + 3), torch.zeros(n, fin + 5)
+        gmp[:, :fout], xp[:, :fin] = gm, x
+        assert torch.equal(P.linear_weight_grad_call(emu, gmp[:, :fout], xp[:, :fin], ws, parts), gw)
+
+
+def test_weight_gradient_refusals(emu):
+    P = pkg("PGCN")
+    ws = torch.empty(emu.pgcn_linear_weight_grad_ws_elems())
+    assert P.linear_weight_grad_call(emu, torch.randn(9, 130), torch.randn(9, 8), ws, None) is None     # wider than 128
+    assert P.linear_weight_grad_call(emu, torch.randn(9, 8), torch.randn(8, 8), ws, None) is None       # row counts disagree
+    with pytest.raises(RuntimeError, match="work-space"):
+        P.linear_weight_grad_call(emu, torch.randn(9, 8), torch.randn(9, 8), torch.empty(10), None)
+
+
 def test_autograd_node_through_the_host_build(emu, monkeypatch):
     """PGCN._LinearReluNoBias with tuning.dense_fused = 2 takes both entry points (here: the host build on CPU tensors) and
     agrees with the stock route; level 0 never touches them."""
@@ -171,17 +211,17 @@ def test_autograd_node_through_the_host_build(emu, monkeypatch):
     torch.manual_seed(1)
     x0, w0 = torch.randn(90, 64), torch.randn(32, 64) / 8
     out = {}
-    for level in (0, 1, 2):
+    for level in (0, 1, 2, 3):
         monkeypatch.setattr(tuning.T, "dense_fused", level)
         x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
         calls.clear()
         y = P._LinearReluNoBias.apply(x, w)
         (y * torch.arange(32.0)).sum().backward()
         out[level] = (y.detach(), x.grad, w.grad, len(calls))
-    assert [out[l][3] for l in (0, 1, 2)] == [0, 1, 2]
-    for level in (1, 2):
-        for a, b in zip(out[level][:3], out[0][:3]):
-            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    assert [out[l][3] for l in (0, 1, 2, 3)] == [0, 1, 2, 3]
+    for level in (1, 2, 3):
+        for a, b in zip(out[level][:3], out[0][:3]):                    # (sums with cancellation: relative to the tensor's scale)
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (level, float((a - b).abs().max()))
     assert torch.equal(out[1][0], out[2][0])
     # operands the kernel refuses (width 132) fall through to the library product under any level
     monkeypatch.setattr(tuning.T, "dense_fused", 2)
@@ -269,3 +309,21 @@ def test_layer_with_the_kernels_switched_on(monkeypatch):
     for a, b in zip(out[2], out[0]):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+
+
+UNRUN = pytest.mark.skipif(os.environ.get("PGCN_TEST_UNRUN") != "1",
+                           reason="gemm/pgcn_wgrad.hip has not met hardware yet (written after the r04 GPU budget was spent): "
+                                  "tools/probes_r05/p1_dense_fused.sh runs these with PGCN_TEST_UNRUN=1")
+
+
+@pytest.mark.gpu
+@UNRUN
+@pytest.mark.parametrize("n,fout,fin,parts", WGRAD_SHAPES + [(232965, 128, 128, 0), (100003, 64, 64, 0)])
+def test_weight_gradient_kernel(n, fout, fin, parts):
+    P = pkg("PGCN")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    e, gw, (gm, x, ws) = _check_wgrad(P, P._dense_lib(), n, fout, fin, torch.cuda.current_stream(dev).cuda_stream, dev=dev)
+    torch.cuda.synchronize()
+    assert e <= BOUND, e
+    assert torch.equal(P.linear_weight_grad_fused(gm, x), gw)          # reproducible, through the public entry too

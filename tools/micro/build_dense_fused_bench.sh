@@ -7,7 +7,8 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 SRC="$HERE/../../$PKG/gemm/pgcn_dense.hip"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
 "$HIPCC" $F -c "$SRC" -o "$HERE/dense_fused_kernels.o" ${PGCN_EXTRA_FLAGS:-} &
-objs=("$HERE/dense_fused_kernels.o")
+"$HIPCC" $F -c "$HERE/../../$PKG/gemm/pgcn_wgrad.hip" -o "$HERE/dense_fused_wgrad.o" &
+objs=("$HERE/dense_fused_kernels.o" "$HERE/dense_fused_wgrad.o")
 # probe builds under their own symbol names: p0 = pipelined steps, loads after the stores, masked operand by whole tiles;
 # p2 = the first version (LDS reads / wait / MFMAs per step, cur = nxt copies, no prefetch, whole tiles); f1 / f2 = the candidates
 # of the end of r04 (predicate-free inner tiles; + non-temporal stores; c1 = + the transposed tile with 16-byte stores); t1-t3 = timing-only probes (see gemm/pgcn_dense.hip)

@@ -142,6 +142,47 @@ static int run_case(int64_t n, int fin, int fout, int reps, bool time_it, const 
 #undef pgcn_dense_last_error
 }
 
+// the weight gradient dW = Gm^T . X (gemm/pgcn_wgrad.hip): 512 sampled entries against float64 over all rows, timed
+static int run_wgrad(int64_t n, int fout, int fin, int reps) {
+    std::vector<float> G((size_t)n * fout), X((size_t)n * fin), DW((size_t)fout * fin);
+    for (auto &v : G) v = rnd();
+    for (auto &v : X) v = rnd();
+    float *dG_, *dX_, *dDW_, *ws;
+    const int64_t ws_elems = pgcn_linear_weight_grad_ws_elems();
+    CK(hipMalloc(&dG_, G.size() * 4)); CK(hipMalloc(&dX_, X.size() * 4)); CK(hipMalloc(&dDW_, DW.size() * 4)); CK(hipMalloc(&ws, ws_elems * 4));
+    CK(hipMemcpy(dG_, G.data(), G.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dX_, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dDW_, 0xff, DW.size() * 4));
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    int rc = pgcn_linear_weight_grad_f32(dG_, fout, dX_, fin, n, fout, fin, dDW_, fin, ws, ws_elems, s);
+    if (rc) { fprintf(stderr, "weight gradient rc %d: %s\n", rc, pgcn_wgrad_last_error()); return 1; }
+    CK(hipStreamSynchronize(s));
+    CK(hipMemcpy(DW.data(), dDW_, DW.size() * 4, hipMemcpyDeviceToHost));
+    double err = 0;
+    for (int t = 0; t < 512; ++t) {
+        const int o = (t * 37) % fout, k = (t * 101 + t / 7) % fin;
+        double sum = 0, den = 0;
+        for (int64_t i = 0; i < n; ++i) { const double p = (double)G[i * fout + o] * X[i * fin + k]; sum += p; den += fabs(p); }
+        const double e = fabs((double)DW[(size_t)o * fin + k] - sum) / (den + 1e-30);
+        if (!(e <= err)) err = e;
+    }
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float ms;
+    for (int w = 0; w < 3; ++w) pgcn_linear_weight_grad_f32(dG_, fout, dX_, fin, n, fout, fin, dDW_, fin, ws, ws_elems, s);
+    CK(hipEventRecord(a, s));
+    for (int r = 0; r < reps; ++r) pgcn_linear_weight_grad_f32(dG_, fout, dX_, fin, n, fout, fin, dDW_, fin, ws, ws_elems, s);
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+    const bool ok = err <= 2e-6;
+    printf("{\"variant\": \"weight gradient Gm^T.X (gemm/pgcn_wgrad.hip)\", \"n\": %lld, \"fout\": %d, \"fin\": %d, \"entries_checked\": 512, "
+           "\"err\": %.3g, \"ok\": %s, \"us\": %.1f, \"GBps\": %.0f}\n", (long long)n, fout, fin, err, ok ? "true" : "false",
+           ms / reps * 1e3, (double)n * (fout + fin) * 4 / (ms / reps * 1e-3) / 1e9);
+    fflush(stdout);
+    (void)hipFree(dG_); (void)hipFree(dX_); (void)hipFree(dDW_); (void)hipFree(ws); (void)hipStreamDestroy(s);
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 232965;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
@@ -162,5 +203,8 @@ int main(int argc, char **argv) {
         rng_state = 0x9e3779b97f4a7c15ull;
         if (v != 1 && v != 2) fails += run_case(n, 64, 64, reps, true, kVariants[v]);     // the papers shape's width
     }
+    fails += run_wgrad(n, 128, 128, reps);
+    fails += run_wgrad(n, 64, 64, reps);
+    fails += run_wgrad(4099, 41, 100, 1);
     return fails ? 1 : 0;
 }

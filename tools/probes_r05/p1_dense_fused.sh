@@ -18,9 +18,9 @@ for l in open('gpurun_out/r05_p1/harness.txt'):
         elif not r['ok']:
             print('MISMATCH', l.strip())
 PY
-timeout 300 python -m pytest tests/test_zz_dense_fused.py -m gpu -x -q > $out/pytest.txt 2>&1; tail -3 $out/pytest.txt
+PGCN_TEST_UNRUN=1 timeout 300 python -m pytest tests/test_zz_dense_fused.py -m gpu -q > $out/pytest.txt 2>&1; tail -3 $out/pytest.txt
 run() { n=$(echo "$1" | tr '/+ =,' '_-__.' | tr -s '_')_$2
   PGCN_TUNING="$1" python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$out/bench_$n.json" 2> "$out/bench_$n.err"
   python -c "
 import json; r=json.load(open('$out/bench_$n.json')); print('%-20s'%'[$1]', 'ms/epoch %.3f'%r['ms_per_step'], 'loss', r.get('loss'), '|', r['config'].get('dense_fused'))" || tail -3 "$out/bench_$n.err"; }
-for rep in 1 2; do for t in "dense_fused=0" "dense_fused=1" "dense_fused=2"; do run "$t" $rep; done; done
+for rep in 1 2; do for t in "dense_fused=0" "dense_fused=1" "dense_fused=2" "dense_fused=3"; do run "$t" $rep; done; done
