@@ -335,7 +335,8 @@ def _dense_stream(t):
 def linear_relu_call(L, x, weight, relu, stream):
     """[relu](x . weight^T) through pgcn_linear_relu_f32 of `L` on `stream`, or None when the entry point does not take the
     operands (-2).  x: n x fin, weight: fout x fin, unit inner strides."""
-    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1] or x.stride(1) != 1 or weight.stride(1) != 1:
+    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1] or x.stride(1) != 1 or weight.stride(1) != 1 or \
+            x.dtype is not torch.float32 or weight.dtype is not torch.float32:
         return None
     y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
     rc = L.pgcn_linear_relu_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], weight.data_ptr(), weight.stride(0),
@@ -351,7 +352,8 @@ def linear_relu_grad_input_call(L, g, y, weight, stream):
     """(g (.) [y > 0], that . weight) through pgcn_linear_relu_grad_input_f32 of `L`, or None (-2).  g, y: n x fout,
     weight: fout x fin."""
     if g.dim() != 2 or g.shape != y.shape or weight.dim() != 2 or g.shape[1] != weight.shape[0] or \
-            g.stride(1) != 1 or y.stride(1) != 1 or weight.stride(1) != 1:
+            g.stride(1) != 1 or y.stride(1) != 1 or weight.stride(1) != 1 or \
+            not (g.dtype is y.dtype is weight.dtype is torch.float32):
         return None
     gm = torch.empty_like(g, memory_format=torch.contiguous_format)
     gx = torch.empty((g.shape[0], weight.shape[1]), dtype=torch.float32, device=g.device)
@@ -371,7 +373,8 @@ _wgrad_ws = {}
 def linear_weight_grad_call(L, gm, x, ws, stream):
     """gm^T . x through pgcn_linear_weight_grad_f32 of `L` (ws: float32 work-space of pgcn_linear_weight_grad_ws_elems()
     elements on the operands' device), or None (-2)."""
-    if gm.dim() != 2 or x.dim() != 2 or gm.shape[0] != x.shape[0] or gm.stride(1) != 1 or x.stride(1) != 1:
+    if gm.dim() != 2 or x.dim() != 2 or gm.shape[0] != x.shape[0] or gm.stride(1) != 1 or x.stride(1) != 1 or \
+            not (gm.dtype is x.dtype is ws.dtype is torch.float32):
         return None
     gw = torch.empty((gm.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
     rc = L.pgcn_linear_weight_grad_f32(gm.data_ptr(), gm.stride(0), x.data_ptr(), x.stride(0), x.shape[0], gm.shape[1], x.shape[1],
@@ -388,10 +391,11 @@ def linear_weight_grad_fused(gm, x):
     if not _dense_operand_ok(gm, x):
         return None
     L = _dense_lib()
-    key = (x.device.type, x.device.index)
+    stream = _dense_stream(x)
+    key = (x.device.type, x.device.index, stream)        # one work-space per stream: two streams may be inside the call at once
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.empty(L.pgcn_linear_weight_grad_ws_elems(), dtype=torch.float32, device=x.device)
-    return linear_weight_grad_call(L, gm, x, _wgrad_ws[key], _dense_stream(x))
+    return linear_weight_grad_call(L, gm, x, _wgrad_ws[key], stream)
 
 
 def linear_relu_fused(x, weight, relu=True):

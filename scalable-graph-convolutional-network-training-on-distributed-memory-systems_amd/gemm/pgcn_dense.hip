@@ -28,6 +28,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #ifdef PGCN_DENSE_HOST_EMU
 #define PG_HD inline
 #else
@@ -583,12 +585,16 @@ int launch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, 
            const float *W, int64_t ldw, int transposed, float *C, int64_t ldc, int relu, int workgroups, hipStream_t s) {
     auto kern = dense_kernel<NKS, NBLK, MASK>;
     static bool attr_set[64] = {false};
+    static std::mutex attr_mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(-1, "hipGetDevice");
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kImageBytes) != hipSuccess)
-            return fail(-1, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    {
+        std::lock_guard<std::mutex> lock(attr_mu);          // (first calls from two threads)
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kImageBytes) != hipSuccess)
+                return fail(-1, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)workgroups), dim3(kThreads), kImageBytes, s, A, lda, Y, ldy, Gm, ldgm, n, K, N, W, ldw,
                        transposed, C, ldc, relu);
