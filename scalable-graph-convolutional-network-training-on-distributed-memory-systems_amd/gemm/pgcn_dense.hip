@@ -59,6 +59,7 @@ constexpr bool kPipe = PGCN_DENSE_PIPE != 0;
 // ... candidates prepared at the end of r04, not yet run on hardware (the library keeps them off until they have been):
 //   PGCN_DENSE_FASTPATH 1: tiles that lie inside the matrix (all but a wave's last) load and store without per-piece predicates
 //     (the first version wraps each of its 16 loads and 64 stores in an exec-mask branch);
+//   PGCN_DENSE_SPREAD 1: a wave's tiles are numbered so that the last, partial round is spread over all CUs;
 //   PGCN_DENSE_NT_STORE 1: the stores of C carry the non-temporal hint (C is not read again by this kernel);
 //   PGCN_DENSE_CT 1: the MFMA computes the TRANSPOSED tile (the image of W as the A operand, the rows of X as B -- both operands
 //     have the same lane layout, so only the two arguments swap): a lane then holds 4 x 4 CONSECUTIVE columns of ONE row of C
@@ -78,6 +79,10 @@ constexpr bool kPipe = PGCN_DENSE_PIPE != 0;
 #ifndef PGCN_DENSE_CT
 #define PGCN_DENSE_CT 0
 #endif
+#ifndef PGCN_DENSE_SPREAD
+#define PGCN_DENSE_SPREAD 0
+#endif
+constexpr bool kSpread = PGCN_DENSE_SPREAD != 0;
 constexpr bool kFastPath = PGCN_DENSE_FASTPATH != 0, kNtStore = PGCN_DENSE_NT_STORE != 0, kCT = PGCN_DENSE_CT != 0;
 constexpr int kProbe = PGCN_DENSE_PROBE;
 constexpr int kRows = 32;                 // rows of a wave's tile = M of the MFMA
@@ -485,7 +490,10 @@ __global__ __launch_bounds__(kThreads, 2) void dense_kernel(const float *__restr
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ntiles = (n + kRows - 1) / kRows;
     const int64_t stride = (int64_t)gridDim.x * kWaves;
-    int64_t tile = (int64_t)blockIdx.x * kWaves + w;
+    // first tile of this wave; kSpread: wave w of workgroup b = global wave w B + b, so that the tiles of the last, partial round
+    // (7 281 tiles over 2 048 waves at the benchmark size) land on waves 0-3 (+ some 4) of EVERY CU instead of on all waves of the
+    // first 142 workgroups
+    int64_t tile = kSpread ? (int64_t)w * gridDim.x + blockIdx.x : (int64_t)blockIdx.x * kWaves + w;
     f32x16 acc[NBLK];
     if constexpr (MASK && kMaskPipe) {
         constexpr int H = NKS / 2;

@@ -17,8 +17,9 @@ declare -A VAR=([p0]="-DPGCN_DENSE_PIPE=1 -DPGCN_DENSE_PREFETCH=0 -DPGCN_DENSE_M
                 [f1]="-DPGCN_DENSE_FASTPATH=1" [f2]="-DPGCN_DENSE_FASTPATH=1 -DPGCN_DENSE_NT_STORE=1"
                 [c1]="-DPGCN_DENSE_FASTPATH=1 -DPGCN_DENSE_CT=1"
                 [f3]="-DPGCN_DENSE_FASTPATH=1 -DPGCN_DENSE_PREFETCH=0" [c2]="-DPGCN_DENSE_FASTPATH=1 -DPGCN_DENSE_CT=1 -DPGCN_DENSE_PREFETCH=0"
+                [g1]="-DPGCN_DENSE_FASTPATH=1 -DPGCN_DENSE_CT=1 -DPGCN_DENSE_SPREAD=1"
                 [t1]="-DPGCN_DENSE_PROBE=1" [t2]="-DPGCN_DENSE_PROBE=2" [t3]="-DPGCN_DENSE_PROBE=3")
-for v in p0 p2 f1 f2 f3 c1 c2 t1 t2 t3; do
+for v in p0 p2 f1 f2 f3 c1 c2 g1 t1 t2 t3; do
   "$HIPCC" $F ${VAR[$v]} -Dpgcn_dense=pgcn_dense_$v -Dpgcn_linear_relu_f32=pgcn_linear_relu_f32_$v \
     -Dpgcn_linear_relu_grad_input_f32=pgcn_linear_relu_grad_input_f32_$v -Dpgcn_dense_last_error=pgcn_dense_last_error_$v \
     -c "$SRC" -o "$HERE/dense_fused_kernels_$v.o" &

@@ -39,7 +39,7 @@ typedef const char *(*err_fn)(void);
     extern "C" int pgcn_linear_relu_grad_input_f32_##sfx(const float *, int64_t, const float *, int64_t, float *, int64_t, int64_t, int32_t,   \
                                                          const float *, int64_t, int32_t, float *, int64_t, void *);                    \
     extern "C" const char *pgcn_dense_last_error_##sfx(void);
-DECLARE_VARIANT(p0) DECLARE_VARIANT(p2) DECLARE_VARIANT(f1) DECLARE_VARIANT(f2) DECLARE_VARIANT(f3) DECLARE_VARIANT(c1) DECLARE_VARIANT(c2) DECLARE_VARIANT(t1) DECLARE_VARIANT(t2) DECLARE_VARIANT(t3)
+DECLARE_VARIANT(p0) DECLARE_VARIANT(p2) DECLARE_VARIANT(f1) DECLARE_VARIANT(f2) DECLARE_VARIANT(f3) DECLARE_VARIANT(c1) DECLARE_VARIANT(c2) DECLARE_VARIANT(g1) DECLARE_VARIANT(t1) DECLARE_VARIANT(t2) DECLARE_VARIANT(t3)
 struct Variant {
     const char *name;
     fwd_fn fwd;
@@ -58,6 +58,7 @@ static const Variant kVariants[] = {
     VARIANT("f3 (f1 with the next tile's loads AFTER the stores)", f3, false),
     VARIANT("c1 (f1 + transposed tile: 16-byte stores of C, 16 per tile instead of 64)", c1, false),
     VARIANT("c2 (c1 with the next tile's loads AFTER the stores)", c2, false),
+    VARIANT("g1 (c1 + the last round's tiles spread over all CUs)", g1, false),
     VARIANT("t1 (TIMING ONLY: library without MFMAs)", t1, true),
     VARIANT("t2 (TIMING ONLY: library without the stores of C)", t2, true),
     VARIANT("t3 (TIMING ONLY: forward without loads after a wave's first tile)", t3, true),
