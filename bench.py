@@ -88,8 +88,8 @@ def kernel_source_stamp():
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, PKG)
-    files = sorted(glob.glob(os.path.join(base, "csrc", "*"))) + [os.path.join(base, "partition.py"),
-                                                                    os.path.join(base, "kernels.py")]
+    files = sorted(glob.glob(os.path.join(base, "csrc", "*"))) + sorted(glob.glob(os.path.join(base, "gemm", "*"))) + \
+        [os.path.join(base, x) for x in ("partition.py", "kernels.py", "tuning.py")]     # (tuning.py: the defaults the layout is built with)
     for fn in files:
         if os.path.isfile(fn) and not fn.endswith((".o", ".so")):
             h.update(os.path.basename(fn).encode())
@@ -470,7 +470,7 @@ def multirank_selftest(rank, world, dev, kernels, exch, n=8192, nnz=400000, f=32
     return rec
 
 
-def graph_replay(model, make_model, H, labels, n, P, steps, dev, eager_ms, world=1):
+def graph_replay(model, make_model, H, labels, n, P, steps, dev, eager_ms, world=1, on_timeout=None):
     """Capture ONE training step (forward, loss, backward, gradient all-reduce, Adam) in a HIP graph and time `steps`
     replays.  The C-ABI library never allocates or synchronises and the engine orders its streams with events only, so
     the whole step -- ~80 launches on a whole graph, ~150 on a shard with its halo groups, the RCCL calls of the
@@ -522,13 +522,16 @@ def graph_replay(model, make_model, H, labels, n, P, steps, dev, eager_ms, world
         torch.cuda.synchronize(dev)
         for _ in range(2):
             g.replay()
-        engine._wait_or_die(dev, "the first replays of the captured %d-rank training step" % world)
+        engine._wait_or_die(dev, "the first replays of the captured %d-rank training step" % world, on_timeout=on_timeout)
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             g.replay()
         t_host = time.perf_counter() - t0
+        if world > 1:                                      # (a deadline instead of a bare synchronize: 0.2 ms granularity, N > 1 only)
+            engine._wait_or_die(dev, "the %d timed replays of the captured %d-rank training step" % (steps, world),
+                                on_timeout=on_timeout, poll_s=0.0002)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -734,9 +737,11 @@ def main():
     ap.add_argument("--real", action="store_true", help="label the --shards / --mtx input as real data in the JSON line")
     ap.add_argument("--no-selftest", action="store_true",
                     help="N > 1: skip the small-graph check of the multi-rank path that runs before the timed region")
-    ap.add_argument("--graph", action="store_true",
+    ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=("on", "off", "auto"),
                     help="after the timed (eager) region: capture ONE training step in a HIP graph -- the RCCL calls of an "
-                         "N > 1 run included -- and time its replays (reported as `graph_replay`; all ranks or none)")
+                         "N > 1 run included -- and time its replays (reported as `graph_replay`; all ranks or none).  auto "
+                         "(default): on for N > 1, where the host-side enqueue of ~150 launches per step is 13 %% of a rank's "
+                         "step (r04: 3.06 ms eager, 2.71 replayed on rank 0 of 8), off for N = 1 (device-bound: 10.66 vs 10.64 ms)")
     ap.add_argument("--emulate-rank", default=None, metavar="r/P",
                     help="one GPU runs rank r of a P-rank job with a no-op exchange (per-rank compute of 2/4/8 GPUs)")
     args = ap.parse_args()
@@ -903,9 +908,10 @@ def main():
         if bavg:
             roofline["avg_launch_ms_backward_AT"] = bavg
         # per-kernel split of the launch group: a few extra forward launches OUTSIDE the timed region
+        real_lib, real_lane = K.lib, K.single_lane
         try:
             K.spmm = timer._spmm
-            real_lib, K.lib = K.lib, SplitTimer(K.lib)
+            K.lib = SplitTimer(real_lib)
             K.single_lane = True                # (the split is of the kernels one after the other, whatever tuning.lanes says)
             eng.A_loc.launch_cache.clear()
             Csplit = torch.empty((part.n_local, f), device=dev)
@@ -914,10 +920,11 @@ def main():
                     K.spmm(eng.A_loc, H.detach(), Csplit)
             torch.cuda.synchronize()
             roofline["split_us"] = K.lib.summary_us()         # the kernels one after the other on one stream (lanes off)
-            K.lib, K.single_lane = real_lib, False
-            eng.A_loc.launch_cache.clear()
         except Exception as e:
             roofline["split_us"] = {"error": repr(e)}
+        finally:                                # whatever happened: what runs after this (--graph) sees the configured library and lanes
+            K.lib, K.single_lane = real_lib, real_lane
+            eng.A_loc.launch_cache.clear()
     halo_groups = None
     if part.size > 1:       # the halo launch groups of this rank (A_halo[r] . slab, one per exchange round)
         halo_groups = []
@@ -974,14 +981,25 @@ def main():
     }
     if halo_groups is not None:
         out["halo_groups"] = halo_groups
-    if args.graph:
-        out["graph_replay"] = graph_replay(model, lambda: nn.Sequential(*[P.PGCN(eng, f, f) for _ in range(L)]).to(dev),
-                                           H, labels, n, P, args.steps, dev, ms_per_step, world)
     if world > 1:
         vol = torch.tensor([eng.stats["send_volume"]], dtype=torch.float64, device=dev)
         P._all_reduce(vol)
         out["exchange_rows_total"] = float(vol)
         out["selftest"] = selftest
+    if args.graph == "on" or (args.graph == "auto" and world > 1 and dev.type == "cuda"):
+        # LAST thing that touches the device: the eager line above is complete.  A replay whose collectives never finish cannot be
+        # recovered from, but it must not cost the eager line either: on a deadline every rank leaves, rank 0 with its line printed.
+        def bail(what):
+            out["graph_replay"] = {"captured": True, "ranks": world, "eager_ms_per_step": ms_per_step,
+                                   "error": "%s did not complete within its deadline; the eager line stands" % what}
+            if rank == 0:
+                out.setdefault("cpu_baseline", None)
+                print(json.dumps(out), flush=True)
+            sys.stderr.write("pgcn bench: rank %d leaves after a stuck graph replay (%s)\n" % (rank, what))
+            sys.stderr.flush()
+            os._exit(0)
+        out["graph_replay"] = graph_replay(model, lambda: nn.Sequential(*[P.PGCN(eng, f, f) for _ in range(L)]).to(dev),
+                                           H, labels, n, P, args.steps, dev, ms_per_step, world, on_timeout=bail)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not emul:
         try:
             out["cpu_baseline"] = cpu_baseline(part, f, L, args.cpu_budget)

@@ -22,6 +22,11 @@ int pgcn_gemm_rocblas_version(char *buf, int64_t n);
 int pgcn_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k, const float *A, int64_t lda,
                   const float *B, int64_t ldb, float *C, int64_t ldc, int32_t solution_index, void *stream);
 
+/* rocBLAS atomics mode of the handles behind pgcn_gemm_f32 (one handle per (device, stream): concurrent streams do not share a
+ * device work-space): 1 = allowed (default, PyTorch's default), 0 = not allowed (what torch.use_deterministic_algorithms(True)
+ * sets on PyTorch's own handles; the binding copies that flag before every product). */
+void pgcn_gemm_set_atomics(int32_t allowed);
+
 /* ---- the same products as the package's own matrix-core kernels (source: <package>/gemm/pgcn_dense.hip) -----------------------
  * v_mfma_f32_32x32x16_bf16 on a three-plane bf16 split of both operands (six partial products, fp32 accumulation: the error
  * class of an fp32 dot product), one persistent workgroup per CU with the split weight matrix in LDS, fused with the
@@ -43,16 +48,9 @@ int pgcn_linear_relu_grad_input_f32(const float *G, int64_t ldg, const float *Y,
                                     int64_t n, int32_t fout, const float *W, int64_t ldw, int32_t fin, float *dX,
                                     int64_t lddx, void *stream);
 
-/* dW (fout x fin, lddw) = Gm^T . X, the weight gradient of the same layer (autograd's `grad_output.t() @ input`), same arithmetic
- * (source: <package>/gemm/pgcn_wgrad.hip): one workgroup per CU multiplies a contiguous range of rows into a partial matrix in
- * `ws`, a second kernel adds the partials in a fixed order (deterministic).  Gm: n x fout (ldg), X: n x fin (ldx), widths up to
- * 128, no alignment requirement; ws: at least pgcn_linear_weight_grad_ws_elems() floats of device memory (32 MB), free for
- * other use once the stream has passed the call.  Return values as above (pgcn_wgrad_last_error()).
- * Written at the end of round 4 and checked through its host build only: not yet run on hardware. */
-const char *pgcn_wgrad_last_error(void);
-int64_t pgcn_linear_weight_grad_ws_elems(void);
-int pgcn_linear_weight_grad_f32(const float *Gm, int64_t ldg, const float *X, int64_t ldx, int64_t n, int32_t fout, int32_t fin,
-                                float *dW, int64_t lddw, float *ws, int64_t ws_elems, void *stream);
+/* The third product of the layer, dW = Gm^T . X, stays the library's 64-slab batched GEMM (78 us at n = 232 965, f = 128); the
+ * package's own kernel for it measured 500 + 58 us on the MI355X in r05 and was moved out of the library
+ * (tools/experiments/pgcn_wgrad.hip). */
 
 #ifdef __cplusplus
 }

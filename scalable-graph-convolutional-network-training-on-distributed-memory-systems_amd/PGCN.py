@@ -213,6 +213,8 @@ def _gemm_direct_table():
                                     ctypes.c_void_p]
         L.pgcn_gemm_rocblas_version.restype = ctypes.c_int
         L.pgcn_gemm_rocblas_version.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+        L.pgcn_gemm_set_atomics.restype = None
+        L.pgcn_gemm_set_atomics.argtypes = [ctypes.c_int32]
         buf = ctypes.create_string_buffer(256)
         if L.pgcn_gemm_rocblas_version(buf, 256) != 0:
             return st["table"]
@@ -263,6 +265,10 @@ def _gemm_direct_call(trans, w, x, m, n, k):
     if idx is None:
         return None
     out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    det = torch.are_deterministic_algorithms_enabled()
+    if det != _gemm_direct.get("det"):       # the side handles follow torch.use_deterministic_algorithms like PyTorch's own
+        _gemm_direct["lib"].pgcn_gemm_set_atomics(0 if det else 1)
+        _gemm_direct["det"] = det
     rc = _gemm_direct["lib"].pgcn_gemm_f32(1 if trans[0] == "t" else 0, 0, m, n, k, w.data_ptr(), w.stride(0), x.data_ptr(),
                                             x.stride(0), out.data_ptr(), m, idx, torch.cuda.current_stream(x.device).cuda_stream)
     if rc != 0:
@@ -289,7 +295,7 @@ _dense = {"lib": None}
 
 def bind_dense_library(path):
     """ctypes handle of a library that exports the entry points of include/pgcn_gemm.h's second half (lib/libpgcn_gemm.so;
-    the tests also bind the host emulation build of gemm/pgcn_dense.hip)."""
+    the tests also bind tests/native/pgcn_dense_emu.cpp, the host build of the kernel's index arithmetic)."""
     import ctypes
     L = ctypes.CDLL(path)
     i32, i64, ptr = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
@@ -298,18 +304,6 @@ def bind_dense_library(path):
     L.pgcn_linear_relu_grad_input_f32.restype = ctypes.c_int
     L.pgcn_linear_relu_grad_input_f32.argtypes = [ptr, i64, ptr, i64, ptr, i64, i64, i32, ptr, i64, i32, ptr, i64, ptr]
     L.pgcn_dense_last_error.restype = ctypes.c_char_p
-    if hasattr(L, "pgcn_linear_weight_grad_f32"):        # (gemm/pgcn_wgrad.hip: its host build is a library of its own)
-        bind_wgrad_entry_points(L)
-    return L
-
-
-def bind_wgrad_entry_points(L):
-    import ctypes
-    i32, i64, ptr = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
-    L.pgcn_linear_weight_grad_f32.restype = ctypes.c_int
-    L.pgcn_linear_weight_grad_f32.argtypes = [ptr, i64, ptr, i64, i64, i32, i32, ptr, i64, ptr, i64, ptr]
-    L.pgcn_linear_weight_grad_ws_elems.restype = i64
-    L.pgcn_wgrad_last_error.restype = ctypes.c_char_p
     return L
 
 
@@ -365,37 +359,6 @@ def linear_relu_grad_input_call(L, g, y, weight, stream):
     if rc != 0:
         raise RuntimeError("pgcn_linear_relu_grad_input_f32: %s" % L.pgcn_dense_last_error().decode())
     return gm, gx
-
-
-_wgrad_ws = {}
-
-
-def linear_weight_grad_call(L, gm, x, ws, stream):
-    """gm^T . x through pgcn_linear_weight_grad_f32 of `L` (ws: float32 work-space of pgcn_linear_weight_grad_ws_elems()
-    elements on the operands' device), or None (-2)."""
-    if gm.dim() != 2 or x.dim() != 2 or gm.shape[0] != x.shape[0] or gm.stride(1) != 1 or x.stride(1) != 1 or \
-            not (gm.dtype is x.dtype is ws.dtype is torch.float32):
-        return None
-    gw = torch.empty((gm.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
-    rc = L.pgcn_linear_weight_grad_f32(gm.data_ptr(), gm.stride(0), x.data_ptr(), x.stride(0), x.shape[0], gm.shape[1], x.shape[1],
-                                       gw.data_ptr(), gw.stride(0), ws.data_ptr(), ws.numel(), stream)
-    if rc == -2:
-        return None
-    if rc != 0:
-        raise RuntimeError("pgcn_linear_weight_grad_f32: %s" % L.pgcn_wgrad_last_error().decode())
-    return gw
-
-
-def linear_weight_grad_fused(gm, x):
-    """gm^T . x (the weight gradient of the layer) by the package's matrix-core kernel on the current stream, or None."""
-    if not _dense_operand_ok(gm, x):
-        return None
-    L = _dense_lib()
-    stream = _dense_stream(x)
-    key = (x.device.type, x.device.index, stream)        # one work-space per stream: two streams may be inside the call at once
-    if key not in _wgrad_ws:
-        _wgrad_ws[key] = torch.empty(L.pgcn_linear_weight_grad_ws_elems(), dtype=torch.float32, device=x.device)
-    return linear_weight_grad_call(L, gm, x, _wgrad_ws[key], stream)
 
 
 def linear_relu_fused(x, weight, relu=True):
@@ -482,9 +445,7 @@ class _LinearReluNoBias(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gx = mm_nn(g, weight)
         if ctx.needs_input_grad[1]:
-            gw = linear_weight_grad_fused(g, x) if _dense_fused_level() >= 3 else None
-            if gw is None:
-                gw = _LinearNoBias.weight_grad(g, x)
+            gw = _LinearNoBias.weight_grad(g, x)       # (the package's own kernel for this product lost 7 x: tools/experiments)
         return gx, gw
 
 
@@ -566,7 +527,7 @@ def tune_dense_gemms(n_rows, f, dev):
     except Exception:                                # an older PyTorch without TunableOp: the default pick
         return False
     was_enabled, was_tuning = tunable.is_enabled(), tunable.tuning_is_enabled()
-    x = g = w = None
+    x = g = w = _ = None
     try:
         tunable.enable(True)
         tunable.set_max_tuning_duration(30)          # ms per candidate

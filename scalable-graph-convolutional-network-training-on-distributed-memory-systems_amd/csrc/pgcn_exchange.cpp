@@ -74,21 +74,31 @@ extern "C" int pgcn_exchange_alltoallv_f32(void *comm, const float *send, const 
     }
     if (send_off[c->rank + 1] != send_off[c->rank] || recv_off[c->rank + 1] != recv_off[c->rank])
         return pgcn_set_error(PGCN_EINVAL, "pgcn_exchange_alltoallv_f32: own-rank segment must be empty");
+    // A group that was opened is ALWAYS closed: returning between ncclGroupStart and ncclGroupEnd would leave the communicator
+    // inside an open group and the next collective of this rank (and with it every peer) would hang.  The first failure is
+    // remembered, the remaining calls of the group are skipped, the group is ended, and the first failure is reported.
     PGCN_NCCL_CHECK(ncclGroupStart());
-    for (int q = 0; q < c->nranks; ++q) {
+    ncclResult_t first = ncclSuccess;
+    const char *what = nullptr;
+    bool null_slab = false;
+    for (int q = 0; q < c->nranks && first == ncclSuccess && !null_slab; ++q) {
         if (q == c->rank) continue;
         const int64_t ns = send_off[q + 1] - send_off[q];
         const int64_t nr = recv_off[q + 1] - recv_off[q];
+        if ((ns > 0 && !send) || (nr > 0 && !recv)) { null_slab = true; break; }
         if (ns > 0) {
-            if (!send) { ncclGroupEnd(); return pgcn_set_error(PGCN_EINVAL, "pgcn_exchange_alltoallv_f32: null send slab"); }
-            PGCN_NCCL_CHECK(ncclSend(send + send_off[q] * f, (size_t)(ns * f), ncclFloat, q, c->comm, s));
+            first = ncclSend(send + send_off[q] * f, (size_t)(ns * f), ncclFloat, q, c->comm, s);
+            if (first != ncclSuccess) { what = "ncclSend"; break; }
         }
         if (nr > 0) {
-            if (!recv) { ncclGroupEnd(); return pgcn_set_error(PGCN_EINVAL, "pgcn_exchange_alltoallv_f32: null recv slab"); }
-            PGCN_NCCL_CHECK(ncclRecv(recv + recv_off[q] * f, (size_t)(nr * f), ncclFloat, q, c->comm, s));
+            first = ncclRecv(recv + recv_off[q] * f, (size_t)(nr * f), ncclFloat, q, c->comm, s);
+            if (first != ncclSuccess) { what = "ncclRecv"; break; }
         }
     }
-    PGCN_NCCL_CHECK(ncclGroupEnd());
+    const ncclResult_t end = ncclGroupEnd();
+    if (null_slab) return pgcn_set_error(PGCN_EINVAL, "pgcn_exchange_alltoallv_f32: null send / recv slab with a non-empty segment");
+    if (first != ncclSuccess) return pgcn_set_error2(PGCN_ERCCL, what, ncclGetErrorString(first));
+    if (end != ncclSuccess) return pgcn_set_error2(PGCN_ERCCL, "ncclGroupEnd", ncclGetErrorString(end));
     return PGCN_OK;
 }
 

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "pgcn_spmm_bodies.h"
+#include "pgcn_once.h"
 
 namespace {
 
@@ -129,14 +130,13 @@ extern "C" int pgcn_spmm_core_f32(const int32_t *work, int64_t nwork, const int3
     const bool v4 = aligned16(B, partial_ws, ldb, 4, f);
     if (v4) {
         size_t smem = (size_t)(TC + 1) * 32 * 4 * 4 + (kCoreThreads / 64) * 512;
-        int dev = 0;
-        PGCN_HIP_CHECK(hipGetDevice(&dev));
-        static bool attr_set[64] = {false};              // the attribute is per device
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_core_kernel<4>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
-        }
+        static PgcnPerDeviceOnce once;
+        if (int rc = once.run([&]() -> int {
+                PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_core_kernel<4>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                return PGCN_OK;
+            }))
+            return rc;
         const int ntiles = (f + 127) / 128;
         hipLaunchKernelGGL((spmm_core_kernel<4>), dim3((unsigned)nwork, ntiles), dim3(kCoreThreads), smem, s,
                            reinterpret_cast<const int4 *>(work), tile_panel, tile_base, seg_off, ccol, cval,

@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include "pgcn_internal.h"
+#include "pgcn_once.h"
 
 namespace {
 
@@ -217,17 +218,15 @@ extern "C" int pgcn_spmm_dense_f32(const int32_t *work, int64_t nwork, const int
     if (partial_ws_elems < nslots_total * (int64_t)f)
         return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_dense_f32: partial work-space too small");
     if (nwork > 0x7fffffffLL) return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_dense_f32: work list too long");
-    int dev = 0;
-    PGCN_HIP_CHECK(hipGetDevice(&dev));
-    static bool attr_set_dev[64] = {false};              // the attribute is per device
-    const bool attr_set = dev >= 0 && dev < 64 && attr_set_dev[dev];
-    if (!attr_set) {
-        PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem));
-        PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem));
-        PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem));
-        PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem));
-        if (dev >= 0 && dev < 64) attr_set_dev[dev] = true;
-    }
+    static PgcnPerDeviceOnce once;
+    if (int rc = once.run([&]() -> int {
+            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem));
+            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem));
+            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem));
+            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem));
+            return PGCN_OK;
+        }))
+        return rc;
     const int4 *w4 = reinterpret_cast<const int4 *>(work);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)nwork, (unsigned)((f + kT - 1) / kT)), block(kThreads);

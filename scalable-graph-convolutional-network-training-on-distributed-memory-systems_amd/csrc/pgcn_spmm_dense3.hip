@@ -51,6 +51,7 @@
 #include <type_traits>
 
 #include "pgcn_internal.h"
+#include "pgcn_once.h"
 
 #pragma clang diagnostic ignored "-Winline-asm"
 
@@ -450,17 +451,15 @@ extern "C" int pgcn_spmm_dense_bf16x3_f32(const int32_t *work, int64_t nwork, co
         return pgcn_set_error(PGCN_ENOMEM, "pgcn_spmm_dense_bf16x3_f32: partial work-space too small");
     if (nwork > 0x7fffffffLL || npanels > 0x7fffffffLL)
         return pgcn_set_error(PGCN_EINVAL, "pgcn_spmm_dense_bf16x3_f32: work / panel list too long");
-    int dev = 0;
-    PGCN_HIP_CHECK(hipGetDevice(&dev));
-    static bool attr_set_dev[64] = {false};
-    const bool attr_set = dev >= 0 && dev < 64 && attr_set_dev[dev];
-    if (!attr_set) {
-        PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem3));
-        PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem3));
-        PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem3));
-        PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem3));
-        if (dev >= 0 && dev < 64) attr_set_dev[dev] = true;
-    }
+    static PgcnPerDeviceOnce once;
+    if (int rc = once.run([&]() -> int {
+            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem3));
+            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem3));
+            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem3));
+            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_dense3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem3));
+            return PGCN_OK;
+        }))
+        return rc;
     hipStream_t s = (hipStream_t)stream;
     const unsigned nfb = (unsigned)((f + kT - 1) / kT);
     hipLaunchKernelGGL(spmm_split_panels_kernel, dim3((unsigned)npanels, nfb), dim3(kSplitThreads), 0, s, panel_list, B, ldb, ncols, f,

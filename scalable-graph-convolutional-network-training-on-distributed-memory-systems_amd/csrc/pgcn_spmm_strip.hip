@@ -36,6 +36,7 @@
 #include <stdlib.h>
 
 #include "pgcn_internal.h"
+#include "pgcn_once.h"
 
 #pragma clang diagnostic ignored "-Winline-asm"   // the copies set M0 themselves ("m0" on the clobber list)
 
@@ -387,18 +388,17 @@ extern "C" int pgcn_spmm_strip_f32(const int32_t *work, int64_t nwork, const int
     const int4 *r4 = reinterpret_cast<const int4 *>(recs);
     const bool vec = f % 4 == 0 && ldb % 4 == 0 && (uintptr_t)B % 16 == 0 && (uintptr_t)partial_ws % 16 == 0;
     if (vec) {
-        int dev = 0;
-        PGCN_HIP_CHECK(hipGetDevice(&dev));
-        static bool attr_set[64] = {false};
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {   // the attribute is per device
-            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
+        static PgcnPerDeviceOnce once;
+        if (int rc = once.run([&]() -> int {
+                PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
 #ifdef PGCN_EXPERIMENTS
-            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
-            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
-            PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
+                PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
+                PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
+                PGCN_HIP_CHECK(hipFuncSetAttribute((const void *)spmm_strip_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
 #endif
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
-        }
+                return PGCN_OK;
+            }))
+            return rc;
         const dim3 grid((unsigned)nwork, (unsigned)((f + 127) / 128));
 #ifdef PGCN_EXPERIMENTS
         // measurement build only (tools/ab_build.sh exp -DPGCN_EXPERIMENTS): PGCN_STRIP_PROBE = 1 no compute phase,

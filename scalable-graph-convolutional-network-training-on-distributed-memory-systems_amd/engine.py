@@ -117,7 +117,7 @@ class RcclExchanger:
 SELFTEST_TIMEOUT_S = float(os.environ.get("PGCN_SELFTEST_TIMEOUT", "90"))
 
 
-def _wait_or_die(device: torch.device, what: str, timeout_s: float = None) -> None:
+def _wait_or_die(device: torch.device, what: str, timeout_s: float = None, on_timeout=None, poll_s: float = 0.002) -> None:
     """Wait for everything queued on ``device`` with a deadline: a collective whose peers never arrive (a mismatched
     send / receive pair, a dead link) spins on the GPU for ever -- the process then says what it was doing and
     exits with status 3 instead of hanging the launcher until its own limit."""
@@ -133,8 +133,10 @@ def _wait_or_die(device: torch.device, what: str, timeout_s: float = None) -> No
                              "PGCN_EXCHANGE=torch selects torch.distributed's all_to_all_single instead of the C-ABI "
                              "communicator\n" % (what, timeout_s, device))
             sys.stderr.flush()
+            if on_timeout is not None:          # (the caller's way out, e.g. bench.py printing the line it already has; must not return)
+                on_timeout(what)
             os._exit(3)
-        time.sleep(0.002)
+        time.sleep(poll_s)
 
 
 def exchange_selftest(ex, rank: int, size: int, device: torch.device, group=None, f: int = 4, rows: int = 3):

@@ -17,26 +17,44 @@
 namespace {
 thread_local char g_err[256] = "";
 std::mutex g_mu;
-rocblas_handle g_handle[64] = {nullptr};
+// One rocBLAS handle per (device, stream): a handle owns a device work-space that solutions with a split reduction use, so two
+// streams must not share one (two PyTorch streams inside mm_nt / mm_nn at once would race on it).  A process uses a handful of
+// streams; the table is searched linearly under the mutex, handles live until the process ends.
+struct HandleSlot { int dev; void *stream; rocblas_handle h; };
+constexpr int kMaxHandles = 256;
+HandleSlot g_slots[kMaxHandles];
+int g_nslots = 0;
+int g_atomics_allowed = 1;      // PyTorch's default; pgcn_gemm_set_atomics(0) under torch.use_deterministic_algorithms(True)
 
 int fail(int code, const char *what, int status) {
     snprintf(g_err, sizeof(g_err), "%s (status %d)", what, status);
     return code;
 }
 
-rocblas_handle handle_for(int dev) {
-    std::lock_guard<std::mutex> lock(g_mu);
-    if (dev < 0 || dev >= 64) return nullptr;
-    if (!g_handle[dev]) {
-        rocblas_handle h = nullptr;
-        if (rocblas_create_handle(&h) != rocblas_status_success) return nullptr;
-        g_handle[dev] = h;
+// (g_mu held)
+rocblas_handle handle_for(int dev, void *stream) {
+    for (int i = 0; i < g_nslots; ++i)
+        if (g_slots[i].dev == dev && g_slots[i].stream == stream) return g_slots[i].h;
+    if (g_nslots == kMaxHandles) return nullptr;
+    rocblas_handle h = nullptr;
+    if (rocblas_create_handle(&h) != rocblas_status_success) return nullptr;
+    if (rocblas_set_stream(h, (hipStream_t)stream) != rocblas_status_success) {
+        rocblas_destroy_handle(h);
+        return nullptr;
     }
-    return g_handle[dev];
+    g_slots[g_nslots++] = HandleSlot{dev, stream, h};
+    return h;
 }
 }  // namespace
 
 extern "C" const char *pgcn_gemm_last_error(void) { return g_err; }
+
+// allowed = 0: kernels that reduce with atomics are refused by rocBLAS (what torch.use_deterministic_algorithms(True) sets on
+// PyTorch's own handles); 1 (default): PyTorch's default mode.
+extern "C" void pgcn_gemm_set_atomics(int32_t allowed) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_atomics_allowed = allowed ? 1 : 0;
+}
 
 // rocBLAS build string ("5.0.2.20250912-42-1199-g2584e35062") of the library this process bound.
 extern "C" int pgcn_gemm_rocblas_version(char *buf, int64_t n) {
@@ -57,11 +75,11 @@ extern "C" int pgcn_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t 
         return fail(-1, "pgcn_gemm_f32: dimension beyond the 32-bit interface", 0);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(-1, "hipGetDevice", 0);
-    rocblas_handle h = handle_for(dev);
-    if (!h) return fail(-1, "rocblas_create_handle", 0);
-    std::lock_guard<std::mutex> lock(g_mu);          // one handle per device: stream + launch as one step
-    rocblas_status st = rocblas_set_stream(h, (hipStream_t)stream);
-    if (st != rocblas_status_success) return fail(-1, "rocblas_set_stream", (int)st);
+    std::lock_guard<std::mutex> lock(g_mu);          // the table and the enqueue as one step
+    rocblas_handle h = handle_for(dev, stream);
+    if (!h) return fail(-1, "rocblas_create_handle / rocblas_set_stream (or more than 256 (device, stream) pairs)", 0);
+    rocblas_status st = rocblas_set_atomics_mode(h, g_atomics_allowed ? rocblas_atomics_allowed : rocblas_atomics_not_allowed);
+    if (st != rocblas_status_success) return fail(-1, "rocblas_set_atomics_mode", (int)st);
     const float one = 1.0f, zero = 0.0f;
     st = rocblas_gemm_ex(h, transa ? rocblas_operation_transpose : rocblas_operation_none,
                          transb ? rocblas_operation_transpose : rocblas_operation_none, (rocblas_int)m, (rocblas_int)n,

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import dataclasses
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Optional
 
 import numpy as np
@@ -48,6 +48,7 @@ class DeviceCSR:
     nslices: int = 1
     seg: Optional[object] = None          # ctypes int64[nslices+1] (host) task segment bounds
     ws: Optional[torch.Tensor] = None     # fp32 work-space for split rows (grown on demand)
+    retired_ws: list = field(default_factory=list)   # outgrown work-spaces, kept allocated (see _bind_spmm)
     core: Optional["DeviceCore"] = None   # dense-tile part (LDS-tiled kernel)
     dense: Optional["DeviceDense"] = None  # densest tiles (fp32 matrix cores)
     strip: Optional["DeviceStrip"] = None  # 512 x 128 strip tiles (LDS-staged, async pipeline)
@@ -92,6 +93,7 @@ class DeviceDense3:
     npanels: int
     nnz: int
     image: Optional[torch.Tensor] = None      # uint8 work-space of the split panels (grown on demand, per width)
+    retired: list = field(default_factory=list)   # outgrown images: a HIP graph captured earlier still launches into them
 
 
 @dataclass
@@ -345,7 +347,9 @@ class HipKernels:
             return simple
         need = A.nslots_total * f
         if need and (A.ws is None or A.ws.numel() < need):
-            A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            if A.ws is not None:
+                A.retired_ws.append(A.ws)       # a HIP graph captured earlier (or a copy of this matrix made with dataclasses.replace)
+            A.ws = torch.empty(need, dtype=torch.float32, device=self.device)   # still launches into the old one: it stays allocated
             A.launch_cache.clear()              # other bindings hold the old work-space pointer
         ws, ws_n = _ptr(A.ws), (0 if A.ws is None else A.ws.numel())
         tasks, ntasks, seg, nslices = _ptr(A.tasks), A.ntasks, A.seg, A.nslices
@@ -362,6 +366,8 @@ class HipKernels:
         if d3 is not None:
             need3 = int(lib.pgcn_dense_bf16x3_image_bytes(d3.npanels, f))
             if d3.image is None or d3.image.numel() < need3:
+                if d3.image is not None:
+                    d3.retired.append(d3.image)   # (scratch of one launch group: a stale binding stays correct, it only must not dangle)
                 d3.image = torch.empty(need3, dtype=torch.uint8, device=self.device)
                 A.launch_cache.clear()          # other bindings hold the old work-space pointer
             w3, n3, bi3, v3, pl3, np3, img3, imgb3 = (d3.work.data_ptr(), d3.npieces, d3.blk_img.data_ptr(), d3.vals3.data_ptr(),
@@ -448,7 +454,7 @@ class HipKernels:
         if plane.dtype is not torch.float32 or not plane.is_cuda or plane.dim() != 1 or plane.stride(0) != 1 \
                 or plane.numel() < A.col.numel():
             raise _lib.PgcnError("value plane must be a contiguous fp32 CUDA vector of nnz entries")
-        return dataclasses.replace(A, val=plane, launch_cache={}, ws=None)
+        return dataclasses.replace(A, val=plane, launch_cache={}, ws=None, retired_ws=[])
 
     @staticmethod
     def _lists(A: DeviceCSR):

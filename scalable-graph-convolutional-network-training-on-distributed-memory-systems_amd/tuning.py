@@ -35,7 +35,9 @@ class Tuning:
     core_min_nnz: int = 2000000      # a smaller tiled part does not pay for its three extra launches (r03: the 1.7 M-entry
                                      # local block of an 8-way shard runs 0.067 ms gather-only, 0.099 ms tiled)
     core_min_frac: float = 0.1
-    dense: bool = True               # fp32-MFMA tiles (128 x 128; only where dense_bf16x3 is off)
+    dense: bool = True               # fp32-MFMA tiles (128 x 128).  IGNORED (like dense_tau / dense_piece) unless dense_bf16x3 = 0: with the
+                                     # bf16 blocks on, partition.csr_from_coo never builds fp32 tiles -- also for matrices that end up with
+                                     # no bf16 block at all (fewer than dense3_min_blocks: their entries go to the strips / the LDS core)
     dense_tau: float = 0.30          # tiles at least this full go to the matrix cores
     dense_piece: int = 0             # tiles per MFMA piece (0 = adaptive)
     dense_bf16x3: bool = True        # r04: 512 x 128 blocks on the bf16 matrix cores at fp32 accuracy (three-plane split, six
@@ -75,12 +77,10 @@ class Tuning:
     gemm_tuning: bool = True         # use the recorded kernel choices for the n x f x f GEMMs of a layer (tunableop/gfx950.csv + cache) ...
     gemm_tunableop: bool = False     # ... through PyTorch's TunableOp, which also TIMES shapes without a record (set-up: + 20-30 s on a
                                      # cold box) instead of replaying the rocBLAS records by solution index (r04 default)
-    dense_fused: int = 0             # relu(x . W^T) (1), also (g (.) mask) . W (2), also gm^T . x (3: gemm/pgcn_wgrad.hip, NOT yet run on
-                                     # hardware) as the package's own bf16-split MFMA kernels
-                                     # (gemm/pgcn_dense.hip, fp32 accuracy) instead of library GEMM + ReLU / mask passes.  Written at the end of
-                                     # r04: checked on hardware through tools/micro/dense_fused_bench only (profiles/r04_dense_fused_*.txt:
-                                     # forward 74.6 us against 85 + 35 us of rocBLAS + clamp at n = 232 965, f = 128; input gradient 131 us
-                                     # against 50 + 86 us), no epoch has been timed with it -- off until one has
+    dense_fused: int = 0             # relu(x . W^T) (1), also (g (.) mask) . W (2) as the package's own bf16-split MFMA kernels
+                                     # (gemm/pgcn_dense.hip, fp32 accuracy) instead of library GEMM + ReLU / mask passes.  r05 harness on the
+                                     # MI355X at n = 232 965, f = 128: forward 63.3 us against 85 + 35 us of rocBLAS + clamp, input gradient
+                                     # 116.8 us against 50 + 86 us (profiles/r05_dense_fused_variants.txt); epochs: DESIGN.md section 4
     # ---- GAT path -------------------------------------------------------------------------------------------
     gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
     gat_sliced: bool = True          # XCD-sliced edge gradient

@@ -18,7 +18,7 @@ def test_gemm_library_exports_its_header():
     src = open(os.path.join(ROOT, "include", "pgcn_gemm.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(pgcn_gemm_[a-z0-9_]+)\s*\(", src)))
-    assert names == ["pgcn_gemm_f32", "pgcn_gemm_last_error", "pgcn_gemm_rocblas_version"]
+    assert names == ["pgcn_gemm_f32", "pgcn_gemm_last_error", "pgcn_gemm_rocblas_version", "pgcn_gemm_set_atomics"]
     L = ctypes.CDLL(P.GEMM_LIB_PATH)
     for n in names:
         assert hasattr(L, n)
