@@ -77,10 +77,12 @@ class Tuning:
     gemm_tuning: bool = True         # use the recorded kernel choices for the n x f x f GEMMs of a layer (tunableop/gfx950.csv + cache) ...
     gemm_tunableop: bool = False     # ... through PyTorch's TunableOp, which also TIMES shapes without a record (set-up: + 20-30 s on a
                                      # cold box) instead of replaying the rocBLAS records by solution index (r04 default)
-    dense_fused: int = 0             # relu(x . W^T) (1), also (g (.) mask) . W (2) as the package's own bf16-split MFMA kernels
-                                     # (gemm/pgcn_dense.hip, fp32 accuracy) instead of library GEMM + ReLU / mask passes.  r05 harness on the
-                                     # MI355X at n = 232 965, f = 128: forward 63.3 us against 85 + 35 us of rocBLAS + clamp, input gradient
-                                     # 116.8 us against 50 + 86 us (profiles/r05_dense_fused_variants.txt); epochs: DESIGN.md section 4
+    dense_fused: int = 2             # relu(x . W^T) (1), also (g (.) mask) . W (2) as the package's own bf16-split MFMA kernels
+                                     # (gemm/pgcn_dense.hip, fp32 accuracy) instead of library GEMM + ReLU / mask passes; 0 = the library
+                                     # route.  r05 on the MI355X at n = 232 965, f = 128: forward 63.3 us against 85 + 35 us of rocBLAS +
+                                     # clamp, input gradient 116.8 us against 50 + 86 us (profiles/r05_dense_fused_variants.txt); epoch, three
+                                     # runs each on one box: 10.52 / 10.48 / 10.45 ms off, 10.46 / 10.42 / 10.46 forward only,
+                                     # 10.37 / 10.36 / 10.34 both (profiles/r05_dense_fused_epochs.txt) -> on since r05
     # ---- GAT path -------------------------------------------------------------------------------------------
     gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
     gat_sliced: bool = True          # XCD-sliced edge gradient

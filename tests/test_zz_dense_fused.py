@@ -161,7 +161,7 @@ def test_autograd_node_through_the_host_build(emu, monkeypatch):
 
 def test_cpu_tensors_never_reach_the_kernels():
     P, tuning = pkg("PGCN"), pkg("tuning")
-    assert tuning.Tuning().dense_fused == 0                           # off by default (tuning.py says why)
+    assert tuning.Tuning().dense_fused == 2                           # on since r05 (tuning.py has the epochs)
     assert P.linear_relu_fused(torch.randn(8, 8), torch.randn(4, 8)) is None
     assert P.linear_relu_grad_input_fused(torch.randn(8, 4), torch.randn(8, 4), torch.randn(4, 8)) is None
 
