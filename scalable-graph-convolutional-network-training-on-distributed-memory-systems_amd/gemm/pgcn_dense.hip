@@ -162,6 +162,114 @@ __global__ __launch_bounds__(kThreads, 2) void dense_kernel(const float *__restr
     }
 }
 
+// ---- the same product with the fix-up of the aggregation as its loader (pgcn_dense_tile.h: sum_half) ------------------------------
+PG_HD int wave_max(int x) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const int y = __shfl_xor(x, o);
+        x = y > x ? y : x;
+    }
+    return x;
+}
+
+// C (n x N) = epi(S . Bm),  S[r] = the sum of row r's partial rows (or base[r]); S is written out when S_out != nullptr.
+// EPI 0: none, 1: relu, 2: C = product where M > 0 else 0.  No tile is prefetched across the loop: a tile's loads depend on its
+// rows' slot lists; the other seven waves of the workgroup cover a wave's round trips.
+template <int NKS, int NBLK, int EPI>
+__global__ __launch_bounds__(kThreads, 2) void fixup_dense_kernel(const RowFix *__restrict__ row_fix, const int32_t *__restrict__ slot_ids,
+                                                                  const float *__restrict__ partial, int64_t ldp,
+                                                                  const float *__restrict__ base, int64_t ldbase, int64_t n, int K, int N,
+                                                                  const float *__restrict__ W, int64_t ldw, int transposed,
+                                                                  float *__restrict__ S_out, int64_t lds, const float *__restrict__ M,
+                                                                  int64_t ldm, float *__restrict__ C, int64_t ldc) {
+    extern __shared__ __attribute__((aligned(16))) char image[];
+    {
+        constexpr int kMine = kSlotsPerPlane / kThreads;
+        float v[kMine][8];
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) {
+            const int s = (int)threadIdx.x + q * kThreads;
+            if ((s >> 8) < NKS && ((s >> 6) & 3) < NBLK) slot_load(W, ldw, transposed, K, N, s, v[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) {
+            const int s = (int)threadIdx.x + q * kThreads;
+            if ((s >> 8) < NKS && ((s >> 6) & 3) < NBLK) slot_store(image, s, v[q]);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const int64_t stride = (int64_t)gridDim.x * kWaves;
+    constexpr int H = NKS / 2;
+    f32x16 acc[NBLK];
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + w; tile < ntiles; tile += stride) {
+        const int64_t row0 = tile * kRows, row = row0 + (lane & 31);
+        RowFix rf = {0, 0};
+        if (row < n) rf = row_fix[row];
+        const int tmax = partial ? wave_max(rf.count) : 0;
+        zero_acc(acc);
+        f32x4 v[H][2];
+        sum_half<H>(v, partial, ldp, slot_ids, base, ldbase, row < n ? row : 0, rf, tmax, K, lane, 0);
+        if (S_out) store_half<H>(v, S_out, lds, row0, n, K, lane, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        product_steps<NBLK, H>(v, image, lane, 0, acc);
+        sum_half<H>(v, partial, ldp, slot_ids, base, ldbase, row < n ? row : 0, rf, tmax, K, lane, H);
+        if (S_out) store_half<H>(v, S_out, lds, row0, n, K, lane, H);
+        __builtin_amdgcn_sched_barrier(0);
+        product_steps<NBLK, H>(v, image, lane, H, acc);
+        if constexpr (EPI == 2) store_c_masked(acc, NBLK, C, ldc, M, ldm, row0, n, N, lane);
+        else store_c(acc, NBLK, C, ldc, row0, n, N, lane, EPI);
+    }
+}
+
+template <int NKS, int NBLK, int EPI>
+int launch_fixup(const RowFix *row_fix, const int32_t *slot_ids, const float *partial, int64_t ldp, const float *base, int64_t ldbase,
+                 int64_t n, int K, int N, const float *W, int64_t ldw, int transposed, float *S_out, int64_t lds, const float *M,
+                 int64_t ldm, float *C, int64_t ldc, int workgroups, hipStream_t s) {
+    auto kern = fixup_dense_kernel<NKS, NBLK, EPI>;
+    static bool attr_set[64] = {false};
+    static std::mutex attr_mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(-1, "hipGetDevice");
+    {
+        std::lock_guard<std::mutex> lock(attr_mu);          // (first calls from two threads)
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kImageBytes) != hipSuccess)
+                return fail(-1, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)workgroups), dim3(kThreads), kImageBytes, s, row_fix, slot_ids, partial, ldp, base, ldbase, n, K,
+                       N, W, ldw, transposed, S_out, lds, M, ldm, C, ldc);
+    return hipGetLastError() == hipSuccess ? 0 : fail(-1, "kernel launch");
+}
+
+template <int EPI>
+int dispatch_fixup(const RowFix *row_fix, const int32_t *slot_ids, const float *partial, int64_t ldp, const float *base, int64_t ldbase,
+                   int64_t n, int K, int N, const float *W, int64_t ldw, int transposed, float *S_out, int64_t lds, const float *M,
+                   int64_t ldm, float *C, int64_t ldc, hipStream_t s) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+        return fail(-1, "hipDeviceGetAttribute(MultiprocessorCount)");
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const int64_t need = (ntiles + kWaves - 1) / kWaves;
+    const int wgs = (int)(need < cus ? need : cus);
+    const int nks = (K + 15) / 16, nblk = (N + 31) / 32;
+#define PGCN_DENSE_CASE(KS, NB)                                                                                              \
+    if (nks <= KS && nblk <= NB)                                                                                             \
+        return launch_fixup<KS, NB, EPI>(row_fix, slot_ids, partial, ldp, base, ldbase, n, K, N, W, ldw, transposed, S_out, lds, M, ldm, C, \
+                                         ldc, wgs, s);
+    PGCN_DENSE_CASE(4, 2)
+    PGCN_DENSE_CASE(4, 4)
+    PGCN_DENSE_CASE(8, 2)
+    PGCN_DENSE_CASE(8, 4)
+#undef PGCN_DENSE_CASE
+    return fail(-2, "pgcn_fixup_linear_f32: widths above 128");
+}
+
 template <int NKS, int NBLK, bool MASK>
 int launch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm, int64_t n, int K, int N,
            const float *W, int64_t ldw, int transposed, float *C, int64_t ldc, int relu, int workgroups, hipStream_t s) {
@@ -231,4 +339,28 @@ extern "C" int pgcn_linear_relu_grad_input_f32(const float *G, int64_t ldg, cons
     if (Gm && (ldgm % 4 || (uintptr_t)Gm % 16 || ldgm < fout)) return fail(-2, "pgcn_dense: rows of Gm must be 16-byte pieces");
     if (n == 0) return 0;
     return dispatch<true>(G, ldg, Y, ldy, Gm, ldgm, n, fout, fin, W, ldw, 0, dX, lddx, 0, (hipStream_t)stream);
+}
+
+// C (n x N) = epi(S . Bm) with S[r] = the ordered sum of row r's partial rows -- csrc's fix-up folded into the dense product
+// (pgcn_dense_tile.h: sum_half; bit-identical to pgcn_spmm_fixup_f32 followed by pgcn_linear_relu_f32).
+//   row_fix: n x {begin, count} (count < 0: S[r] = base[r]);  slot_ids: the slot lists (NULL: slots begin .. begin + count);
+//   partial: the producers' work-space, rows ldp floats apart;  k: width of S;  W: wrows x wcols (ldw);
+//   transposed 1: Bm = W^T (W = nn.Linear's weight, N = wrows, wcols = k);  0: Bm = W (wrows = k, N = wcols);
+//   S_out (n x k, lds): S written out when not NULL;  epilogue 0: none, 1: relu, 2: keep where M (n x N, ldm) > 0, else 0.
+extern "C" int pgcn_fixup_linear_f32(const int32_t *row_fix, const int32_t *slot_ids, const float *partial, int64_t ldp,
+                                     const float *base, int64_t ldbase, int64_t n, int32_t k, const float *W, int64_t ldw,
+                                     int32_t wrows, int32_t wcols, int32_t transposed, float *S_out, int64_t lds, const float *M,
+                                     int64_t ldm, float *C, int64_t ldc, int32_t epilogue, void *stream) {
+    using namespace pgcn_dense;
+    if (wrows <= 0 || wcols <= 0 || (transposed ? wcols : wrows) != k) return fail(-1, "pgcn_fixup_linear_f32: W does not match the width of S");
+    const int N = transposed ? wrows : wcols;
+    if (int rc = check_fixup(row_fix, partial, ldp, base, ldbase, n, k, N, W, ldw, wcols, S_out, lds, M, ldm, C, ldc, epilogue)) return rc;
+    if (n == 0) return 0;
+    const RowFix *rf = reinterpret_cast<const RowFix *>(row_fix);
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case 0: return dispatch_fixup<0>(rf, slot_ids, partial, ldp, base, ldbase, n, k, N, W, ldw, transposed ? 1 : 0, S_out, lds, M, ldm, C, ldc, s);
+        case 1: return dispatch_fixup<1>(rf, slot_ids, partial, ldp, base, ldbase, n, k, N, W, ldw, transposed ? 1 : 0, S_out, lds, M, ldm, C, ldc, s);
+        default: return dispatch_fixup<2>(rf, slot_ids, partial, ldp, base, ldbase, n, k, N, W, ldw, transposed ? 1 : 0, S_out, lds, M, ldm, C, ldc, s);
+    }
 }

@@ -204,3 +204,141 @@ PG_HD void mask_half(f32x4 (&v)[CNT][2], const HalfRaw<CNT> &r, float *__restric
             }
         }
 }
+
+// ---- the operand as the SUM of a row's partial rows: the fix-up of the aggregation folded into its consumer (r05) ---------------
+// The producers of one aggregation (gather tasks, strips, bf16 blocks) leave partial rows in a work-space; csrc's
+// spmm_fixup_list_kernel adds a row's partial rows in list order and writes A.H, which the dense kernel then reads back.  Here
+// the dense kernel's loader does that sum itself, in the same order (bit-identical operand), so A.H is never written:
+//     row_fix[r] = {begin, count};  count >= 0:  S[r] = ((0 + P[id_0]) + P[id_1]) + ...,  id_t = slot_ids[begin + t]
+//                                                (id_t = begin + t when slot_ids == NULL),  P[i] = partial + i * ldp
+//                                   count <  0:  S[r] = base[r]   (a row some producer wrote directly)
+// A lane's 16-byte pieces are those of piece_of(); the ids of up to kIdChunk slots are fetched together, the pieces of slot
+// t + 1 are in flight while those of slot t are added.  Loads are unconditional (clamped ids, the sum kept by a select): a
+// branch per slot would fence the loads in flight.  `tmax` >= every lane's count (wave-uniform on the device).
+struct RowFix {
+    int32_t begin, count;
+};
+constexpr int kIdChunk = 8;
+
+template <int CNT>
+PG_HD void load_row_pieces(f32x4 (&x)[CNT][2], const float *__restrict__ rowp, int K, int lane, int ks0, bool full) {
+    // rowp = first element of the lane's row; pieces (ks0 + i, h) at 16 (ks0 + i) + 8 hi + 4 h
+    const float *p = rowp + 8 * (lane >> 5) + 16 * ks0;
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < CNT; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) x[i][h] = *reinterpret_cast<const f32x4 *>(p + 16 * i + 4 * h);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < CNT; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 16 * (ks0 + i) + 8 * (lane >> 5) + 4 * h;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            x[i][h] = k < K ? *reinterpret_cast<const f32x4 *>(p + 16 * i + 4 * h) : z;
+        }
+}
+
+template <int CNT>
+PG_HD void sum_half(f32x4 (&v)[CNT][2], const float *__restrict__ partial, int64_t ldp, const int32_t *__restrict__ slot_ids,
+                    const float *__restrict__ base, int64_t ldbase, int64_t row, RowFix rf, int tmax, int K, int lane, int ks0) {
+    const bool full = 16 * (ks0 + CNT) <= K;          // (uniform) every piece of this half lies inside the width
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) { v[i][0] = z; v[i][1] = z; }
+    if (rf.count < 0) load_row_pieces<CNT>(v, base + row * ldbase, K, lane, ks0, full);     // (rare: a branch)
+    for (int t0 = 0; t0 < tmax; t0 += kIdChunk) {
+        int32_t id[kIdChunk];
+#pragma unroll
+        for (int j = 0; j < kIdChunk; ++j) {
+            const int t = t0 + j;
+            const bool on = t < rf.count;
+            const int32_t at = on ? rf.begin + t : 0;
+            const int32_t got = slot_ids ? slot_ids[at] : at;
+            id[j] = on ? got : -1;
+        }
+        f32x4 x[2][CNT][2];
+        load_row_pieces<CNT>(x[0], partial + (int64_t)(id[0] < 0 ? 0 : id[0]) * ldp, K, lane, ks0, full);
+#pragma unroll
+        for (int j = 0; j < kIdChunk; ++j) {
+            if (t0 + j >= tmax) break;                // (uniform)
+            if (j + 1 < kIdChunk && t0 + j + 1 < tmax)
+                load_row_pieces<CNT>(x[(j + 1) & 1], partial + (int64_t)(id[j + 1] < 0 ? 0 : id[j + 1]) * ldp, K, lane, ks0, full);
+            const bool on = id[j] >= 0;
+#pragma unroll
+            for (int i = 0; i < CNT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 s = v[i][h] + x[j & 1][i][h];
+                    v[i][h].x = on ? s.x : v[i][h].x; v[i][h].y = on ? s.y : v[i][h].y;
+                    v[i][h].z = on ? s.z : v[i][h].z; v[i][h].w = on ? s.w : v[i][h].w;
+                }
+        }
+    }
+}
+// the summed half written out (the operand of the weight gradient in the backward; the aggregation itself when a caller wants it)
+template <int CNT>
+PG_HD void store_half(const f32x4 (&v)[CNT][2], float *__restrict__ S, int64_t lds, int64_t row0, int64_t n, int K, int lane, int ks0) {
+    if (row0 + kRows <= n && 16 * (ks0 + CNT) <= K) {
+        float *sb = S + (row0 + (lane & 31)) * lds + 8 * (lane >> 5) + 16 * ks0;
+#pragma unroll
+        for (int i = 0; i < CNT; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4 *>(sb + 16 * i + 4 * h) = v[i][h];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < CNT; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const Piece pm = piece_of(row0, n, K, lds, lane, ks0 + i, h);
+            if (pm.ok) *reinterpret_cast<f32x4 *>(S + pm.off) = v[i][h];
+        }
+}
+// C = the product where M > 0, else 0 (threshold_backward by the layer input M = relu(...) of the layer below: its mask pass
+// folded into this layer's input gradient); accumulator layout as in store_c
+PG_HD void store_c_masked(const f32x16 *acc, int nblk, float *C, int64_t ldc, const float *__restrict__ M, int64_t ldm, int64_t row0,
+                          int64_t n, int N, int lane) {
+    const int hi = lane >> 5, lo = lane & 31;
+    if (row0 + kRows <= n && 32 * nblk == N) {
+        float *base = C + (row0 + 4 * hi) * ldc + lo;
+        const float *mb = M + (row0 + 4 * hi) * ldm + lo;
+#pragma unroll
+        for (int nb = 0; nb < nblk; ++nb) {
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = mb[(int64_t)((r & 3) + 8 * (r >> 2)) * ldm + 32 * nb];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                store1(base + (int64_t)((r & 3) + 8 * (r >> 2)) * ldc + 32 * nb, m[r] <= 0.f ? 0.f : acc[nb][r]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int nb = 0; nb < nblk; ++nb) {
+        const int col = 32 * nb + lo;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row < n) store1(&C[row * ldc + col], M[row * ldm + col] <= 0.f ? 0.f : acc[nb][r]);
+        }
+    }
+}
+
+inline int check_fixup(const void *row_fix, const void *partial, int64_t ldp, const void *base, int64_t ldbase, int64_t n, int K, int N,
+                       const void *W, int64_t ldw, int wcols, const void *S, int64_t lds, const void *M, int64_t ldm, const void *C,
+                       int64_t ldc, int epilogue) {
+    if (n < 0 || K <= 0 || N <= 0 || !W || (n > 0 && (!row_fix || !C)) || epilogue < 0 || epilogue > 2)
+        return fail(-1, "pgcn_fixup_linear_f32: bad argument");
+    if (K > kMaxF || N > kMaxF) return fail(-2, "pgcn_fixup_linear_f32: widths above 128 are left to the separate fix-up + library GEMM");
+    if (K % 4) return fail(-2, "pgcn_fixup_linear_f32: the width of the summed rows must be a multiple of 4");
+    if (partial && (ldp % 4 || (uintptr_t)partial % 16 || ldp < K)) return fail(-2, "pgcn_fixup_linear_f32: partial rows must be 16-byte pieces");
+    if (base && (ldbase % 4 || (uintptr_t)base % 16 || ldbase < K)) return fail(-2, "pgcn_fixup_linear_f32: base rows must be 16-byte pieces");
+    if (S && (lds % 4 || (uintptr_t)S % 16 || lds < K)) return fail(-2, "pgcn_fixup_linear_f32: rows of S must be 16-byte pieces");
+    if (epilogue == 2 && (!M || ldm < N)) return fail(-1, "pgcn_fixup_linear_f32: the mask epilogue needs M");
+    if (ldc < N || ldw < wcols) return fail(-1, "pgcn_fixup_linear_f32: leading dimension below the width");
+    return 0;
+}
