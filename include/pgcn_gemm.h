@@ -48,6 +48,26 @@ int pgcn_linear_relu_grad_input_f32(const float *G, int64_t ldg, const float *Y,
                                     int64_t n, int32_t fout, const float *W, int64_t ldw, int32_t fin, float *dX,
                                     int64_t lddx, void *stream);
 
+/* C (n x N, ldc) = epi(X . Bm):  X: n x k (ldx);  W: wrows x wcols (ldw);  transposed 1: Bm = W^T (N = wrows, wcols = k), 0: Bm = W
+ * (wrows = k, N = wcols);  epilogue 0: none, 1: relu, 2: keep the product where M (n x N, ldm) > 0, else 0 -- a layer's input
+ * gradient with the ReLU mask of the layer below folded in (threshold_backward by that layer's output). */
+int pgcn_linear_epilogue_f32(const float *X, int64_t ldx, int64_t n, int32_t k, const float *W, int64_t ldw, int32_t wrows,
+                             int32_t wcols, int32_t transposed, const float *M, int64_t ldm, float *C, int64_t ldc,
+                             int32_t epilogue, void *stream);
+
+/* The same product with the FIX-UP of the aggregation as its loader (r05): the left operand is never materialised.
+ *   S[r] = count >= 0 ? ((0 + P[id_0]) + P[id_1]) + ... : base[r],   row_fix[r] = {begin, count} (n x 2 int32),
+ *   id_t = slot_ids[begin + t] (begin + t when slot_ids == NULL),  P[i] = partial + i * ldp  (the producers' work-space:
+ *   include/pgcn_hip.h, pgcn_spmm_*_f32 with PGCN_SPMM_NO_FIXUP), summed in list order exactly like pgcn_spmm_fixup_f32 does;
+ *   C = epi(S . Bm) as above;  S_out (n x k, lds) != NULL: S is also written (the operand of the weight gradient).
+ * Replaces pgcn_spmm_fixup_f32 + the product on its output: `H = PSpMM.apply(A, H); F.relu(self.linear(H))`,
+ * /root/reference/GPU/PGCN.py:144-147, and the same pair in the backward.  Bit-identical to that pair.  k a multiple of 4, widths
+ * up to 128, partial / base / S_out rows 16-byte pieces; -2 otherwise (nothing launched). */
+int pgcn_fixup_linear_f32(const int32_t *row_fix, const int32_t *slot_ids, const float *partial, int64_t ldp, const float *base,
+                          int64_t ldbase, int64_t n, int32_t k, const float *W, int64_t ldw, int32_t wrows, int32_t wcols,
+                          int32_t transposed, float *S_out, int64_t lds, const float *M, int64_t ldm, float *C, int64_t ldc,
+                          int32_t epilogue, void *stream);
+
 /* The third product of the layer, dW = Gm^T . X, stays the library's 64-slab batched GEMM (78 us at n = 232 965, f = 128); the
  * package's own kernel for it measured 500 + 58 us on the MI355X in r05 and was moved out of the library
  * (tools/experiments/pgcn_wgrad.hip). */

@@ -33,6 +33,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.utils.weak import WeakIdKeyDictionary
 
 from . import engine as _engine
 from . import ingest as _ingest
@@ -304,6 +305,10 @@ def bind_dense_library(path):
     L.pgcn_linear_relu_grad_input_f32.restype = ctypes.c_int
     L.pgcn_linear_relu_grad_input_f32.argtypes = [ptr, i64, ptr, i64, ptr, i64, i64, i32, ptr, i64, i32, ptr, i64, ptr]
     L.pgcn_dense_last_error.restype = ctypes.c_char_p
+    L.pgcn_linear_epilogue_f32.restype = ctypes.c_int
+    L.pgcn_linear_epilogue_f32.argtypes = [ptr, i64, i64, i32, ptr, i64, i32, i32, i32, ptr, i64, ptr, i64, i32, ptr]
+    L.pgcn_fixup_linear_f32.restype = ctypes.c_int
+    L.pgcn_fixup_linear_f32.argtypes = [ptr, ptr, ptr, i64, ptr, i64, i64, i32, ptr, i64, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i32, ptr]
     return L
 
 
@@ -359,6 +364,54 @@ def linear_relu_grad_input_call(L, g, y, weight, stream):
     if rc != 0:
         raise RuntimeError("pgcn_linear_relu_grad_input_f32: %s" % L.pgcn_dense_last_error().decode())
     return gm, gx
+
+
+EPI_NONE, EPI_RELU, EPI_MASK = 0, 1, 2
+
+
+def linear_epilogue_call(L, x, weight, transposed, epilogue, mask, stream):
+    """epi(x . weight^T) (transposed) or epi(x . weight) through pgcn_linear_epilogue_f32 of `L`; epilogue EPI_MASK keeps the product
+    where ``mask`` > 0.  None when the entry point does not take the operands (-2)."""
+    k = x.shape[1]
+    if x.dim() != 2 or weight.dim() != 2 or (weight.shape[1] if transposed else weight.shape[0]) != k or x.stride(1) != 1 or \
+            weight.stride(1) != 1 or x.dtype is not torch.float32 or weight.dtype is not torch.float32:
+        return None
+    n_out = weight.shape[0] if transposed else weight.shape[1]
+    if epilogue == EPI_MASK and (mask is None or mask.shape != (x.shape[0], n_out) or mask.stride(1) != 1 or mask.dtype is not torch.float32):
+        return None
+    y = torch.empty((x.shape[0], n_out), dtype=torch.float32, device=x.device)
+    rc = L.pgcn_linear_epilogue_f32(x.data_ptr(), x.stride(0), x.shape[0], k, weight.data_ptr(), weight.stride(0), weight.shape[0],
+                                    weight.shape[1], 1 if transposed else 0, mask.data_ptr() if epilogue == EPI_MASK else None,
+                                    mask.stride(0) if epilogue == EPI_MASK else 0, y.data_ptr(), y.stride(0), epilogue, stream)
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError("pgcn_linear_epilogue_f32: %s" % L.pgcn_dense_last_error().decode())
+    return y
+
+
+def fixup_linear_call(L, row_fix, slot_ids, ws, base, f, weight, transposed, epilogue, mask, want_sum, stream):
+    """epi(S . weight^T | S . weight) with S = the ordered per-row sums of a deferred aggregation (kernels.DeferredSum: row_fix,
+    slot_ids, ws, base; rows f floats apart) through pgcn_fixup_linear_f32 of `L`.  Returns (product, S or None), or None (-2)."""
+    n = row_fix.shape[0]
+    if weight.dim() != 2 or (weight.shape[1] if transposed else weight.shape[0]) != f or weight.stride(1) != 1 or \
+            weight.dtype is not torch.float32 or base.shape != (n, f) or base.stride(1) != 1:
+        return None
+    n_out = weight.shape[0] if transposed else weight.shape[1]
+    if epilogue == EPI_MASK and (mask is None or mask.shape != (n, n_out) or mask.stride(1) != 1 or mask.dtype is not torch.float32):
+        return None
+    y = torch.empty((n, n_out), dtype=torch.float32, device=base.device)
+    S = torch.empty((n, f), dtype=torch.float32, device=base.device) if want_sum else None
+    rc = L.pgcn_fixup_linear_f32(row_fix.data_ptr(), slot_ids.data_ptr() if slot_ids is not None else None,
+                                 ws.data_ptr() if ws is not None else None, f, base.data_ptr(), base.stride(0), n, f, weight.data_ptr(),
+                                 weight.stride(0), weight.shape[0], weight.shape[1], 1 if transposed else 0,
+                                 S.data_ptr() if want_sum else None, f, mask.data_ptr() if epilogue == EPI_MASK else None,
+                                 mask.stride(0) if epilogue == EPI_MASK else 0, y.data_ptr(), y.stride(0), epilogue, stream)
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError("pgcn_fixup_linear_f32: %s" % L.pgcn_dense_last_error().decode())
+    return y, S
 
 
 def linear_relu_fused(x, weight, relu=True):
@@ -447,6 +500,85 @@ class _LinearReluNoBias(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = _LinearNoBias.weight_grad(g, x)       # (the package's own kernel for this product lost 7 x: tools/experiments)
         return gx, gw
+
+
+# ---- one PGCN layer as ONE autograd node (r05, tuning.layer_fused) --------------------------------------------------------------
+# relu((A.H).W^T), PGCN.py:144-147, with the aggregation's fix-up folded into the dense product (forward AND backward) and the
+# backward re-associated:  T = A^T.Gm  (Gm = dY (.) [Y > 0]),  dH = T.W,  dW = T^T.H  -- the same products as autograd's
+# dAH = Gm.W, dH = A^T.dAH, dW = Gm^T.AH by associativity, but A.H is never needed again after the forward, so it is never
+# written: the forward's loader sums the producers' partial rows itself (gemm/pgcn_dense.hip, pgcn_fixup_linear_f32), and so does
+# the backward's, which also writes T (for dW) and applies the layer BELOW's ReLU mask to dH when its input is that layer's
+# output (threshold_backward by H = relu(...) is idempotent: the layer below may skip its own mask pass when it gets the very
+# tensor this node returned, and re-applies it otherwise -- correct either way).
+# (keyed by tensor IDENTITY: a plain WeakSet / WeakKeyDictionary would compare tensors with ==)
+_relu_outputs = WeakIdKeyDictionary()      # outputs of fused layers (their consumers may pre-mask the gradient they return)
+_premasked = WeakIdKeyDictionary()         # gradient tensor -> data_ptr of the relu output it was masked with
+
+
+def _layer_fused_level():
+    from .tuning import T as _T
+    return int(_T.layer_fused) if int(_T.dense_fused) >= 2 else 0
+
+
+def _layer_fused_on():
+    return _layer_fused_level() >= 1
+
+
+def _layer_fused_ok(A, H, weight):
+    return (_layer_fused_on() and hasattr(A, "forward_deferred") and H.is_cuda and weight.is_cuda and H.dim() == 2 and
+            H.dtype is torch.float32 and H.shape[1] % 4 == 0 and max(weight.shape) <= 128 and weight.shape[1] == H.shape[1] and
+            weight.shape[0] % 4 == 0 and H.device.index == torch.cuda.current_device() and H.device == weight.device)
+
+
+class _AggLinearRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H, weight, A, input_is_relu):
+        from .kernels import DeferredSum
+        L, stream = _dense_lib(), _dense_stream(H)
+        d = A.forward_deferred(H) if _layer_fused_level() >= 2 else A.forward(H)
+        y = None
+        if isinstance(d, DeferredSum):
+            out = fixup_linear_call(L, d.row_fix, d.slot_ids, d.ws, d.base, d.f, weight, True, EPI_RELU, None, False, stream)
+            if out is None:
+                d = d.finish()
+            else:
+                y = out[0]
+        if y is None:
+            y = linear_relu_call(L, d, weight, True, stream)
+            if y is None:
+                y = mm_nt(d, weight).clamp_min_(0.0)
+        ctx.A, ctx.input_is_relu = A, bool(input_is_relu)
+        ctx.save_for_backward(H, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .kernels import DeferredSum
+        H, weight, y = ctx.saved_tensors
+        L, stream = _dense_lib(), _dense_stream(y)
+        if _premasked.pop(g, None) != y.data_ptr():
+            g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
+        need_h = ctx.needs_input_grad[0]
+        epi = EPI_MASK if (ctx.input_is_relu and need_h) else EPI_NONE
+        d = ctx.A.backward_deferred(g) if _layer_fused_level() >= 2 else ctx.A.backward(g)
+        gh = T = None
+        if isinstance(d, DeferredSum):
+            out = fixup_linear_call(L, d.row_fix, d.slot_ids, d.ws, d.base, d.f, weight, False, epi, H, True, stream) if need_h else None
+            if out is None:
+                d = d.finish()
+            else:
+                gh, T = out
+        if T is None:
+            T = d
+            if need_h:
+                gh = linear_epilogue_call(L, T, weight, False, epi, H, stream)
+                if gh is None:
+                    gh = mm_nn(T, weight)
+                    epi = EPI_NONE
+        if gh is not None and epi == EPI_MASK:
+            _premasked[gh] = H.data_ptr()
+        gw = _LinearNoBias.weight_grad(T, H) if ctx.needs_input_grad[1] else None
+        return gh, gw, None, None
 
 
 _gemm_tuned_shapes = set()
@@ -576,6 +708,10 @@ class PGCN(nn.Module):
         self.recv_map = recv_map
 
     def forward(self, H):
+        if _layer_fused_ok(self.A, H, self.linear.weight):
+            Y = _AggLinearRelu.apply(H, self.linear.weight, self.A, H in _relu_outputs)
+            _relu_outputs[Y] = True
+            return Y
         H = PSpMM.apply(self.A, H)
         return _LinearReluNoBias.apply(H, self.linear.weight)      # == F.relu(self.linear(H)), PGCN.py:146-147
 

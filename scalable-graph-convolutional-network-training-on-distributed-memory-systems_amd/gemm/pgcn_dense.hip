@@ -91,8 +91,9 @@ PG_HD void zero_acc(f32x16 (&acc)[NBLK]) {
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 }
 
-// C (n x N) = op(A) (n x K) . Bm (K x N); MASK: op(A) = A (.) [Y > 0] (and Gm = op(A) when Gm != nullptr); relu: C = relu(C).
-template <int NKS, int NBLK, bool MASK>
+// C (n x N) = op(A) (n x K) . Bm (K x N); MASK: op(A) = A (.) [Y > 0] (and Gm = op(A) when Gm != nullptr); relu: C = relu(C);
+// EMASK (not with MASK): C = the product where Y (n x N, here the mask of the OUTPUT) > 0, else 0.
+template <int NKS, int NBLK, bool MASK, bool EMASK = false>
 __global__ __launch_bounds__(kThreads, 2) void dense_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ Y,
                                                             int64_t ldy, float *__restrict__ Gm, int64_t ldgm, int64_t n, int K,
                                                             int N, const float *__restrict__ W, int64_t ldw, int transposed,
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(kThreads, 2) void dense_kernel(const float *__restr
             if (tn < ntiles) load_tile<NKS>(into, A, lda, tn * kRows, n, K, lane);
             __builtin_amdgcn_sched_barrier(0);
             tile_product<NKS, NBLK, NKS / 2, NKS>(from, image, lane, acc);
-            store_c(acc, NBLK, C, ldc, tile * kRows, n, N, lane, relu);
+            if constexpr (EMASK) store_c_masked(acc, NBLK, C, ldc, Y, ldy, tile * kRows, n, N, lane);
+            else store_c(acc, NBLK, C, ldc, tile * kRows, n, N, lane, relu);
             tile = tn;
         };
         if (tile < ntiles) load_tile<NKS>(t0, A, lda, tile * kRows, n, K, lane);
@@ -270,10 +272,10 @@ int dispatch_fixup(const RowFix *row_fix, const int32_t *slot_ids, const float *
     return fail(-2, "pgcn_fixup_linear_f32: widths above 128");
 }
 
-template <int NKS, int NBLK, bool MASK>
+template <int NKS, int NBLK, bool MASK, bool EMASK = false>
 int launch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm, int64_t n, int K, int N,
            const float *W, int64_t ldw, int transposed, float *C, int64_t ldc, int relu, int workgroups, hipStream_t s) {
-    auto kern = dense_kernel<NKS, NBLK, MASK>;
+    auto kern = dense_kernel<NKS, NBLK, MASK, EMASK>;
     static bool attr_set[64] = {false};
     static std::mutex attr_mu;
     int dev = 0;
@@ -291,7 +293,7 @@ int launch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, 
     return hipGetLastError() == hipSuccess ? 0 : fail(-1, "kernel launch");
 }
 
-template <bool MASK>
+template <bool MASK, bool EMASK = false>
 int dispatch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm, int64_t n, int K, int N,
              const float *W, int64_t ldw, int transposed, float *C, int64_t ldc, int relu, hipStream_t s) {
     int dev = 0, cus = 0;
@@ -304,7 +306,7 @@ int dispatch(const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm
     const int nks = (K + 15) / 16, nblk = (N + 31) / 32;
 #define PGCN_DENSE_CASE(KS, NB)                                                                                              \
     if (nks <= KS && nblk <= NB)                                                                                             \
-        return launch<KS, NB, MASK>(A, lda, Y, ldy, Gm, ldgm, n, K, N, W, ldw, transposed, C, ldc, relu, wgs, s);
+        return launch<KS, NB, MASK, EMASK>(A, lda, Y, ldy, Gm, ldgm, n, K, N, W, ldw, transposed, C, ldc, relu, wgs, s);
     PGCN_DENSE_CASE(4, 2)
     PGCN_DENSE_CASE(4, 4)
     PGCN_DENSE_CASE(8, 2)
@@ -339,6 +341,24 @@ extern "C" int pgcn_linear_relu_grad_input_f32(const float *G, int64_t ldg, cons
     if (Gm && (ldgm % 4 || (uintptr_t)Gm % 16 || ldgm < fout)) return fail(-2, "pgcn_dense: rows of Gm must be 16-byte pieces");
     if (n == 0) return 0;
     return dispatch<true>(G, ldg, Y, ldy, Gm, ldgm, n, fout, fin, W, ldw, 0, dX, lddx, 0, (hipStream_t)stream);
+}
+
+// C (n x N, ldc) = epi(X . Bm):  X: n x k (ldx);  W: wrows x wcols (ldw);  transposed 1: Bm = W^T (N = wrows, wcols = k), 0: Bm = W
+// (wrows = k, N = wcols);  epilogue 0: none, 1: relu, 2: keep where M (n x N, ldm) > 0, else 0 -- the input gradient of a layer
+// with the ReLU mask of the layer below folded in.
+extern "C" int pgcn_linear_epilogue_f32(const float *X, int64_t ldx, int64_t n, int32_t k, const float *W, int64_t ldw, int32_t wrows,
+                                        int32_t wcols, int32_t transposed, const float *M, int64_t ldm, float *C, int64_t ldc,
+                                        int32_t epilogue, void *stream) {
+    using namespace pgcn_dense;
+    if (wrows <= 0 || wcols <= 0 || (transposed ? wcols : wrows) != k || epilogue < 0 || epilogue > 2)
+        return fail(-1, "pgcn_linear_epilogue_f32: W does not match the width of X / bad epilogue");
+    const int N = transposed ? wrows : wcols;
+    if (int rc = check(X, ldx, n, k, N, W, ldw, wrows, wcols, C, ldc)) return rc;
+    if (epilogue == 2 && (!M || ldm < N)) return fail(-1, "pgcn_linear_epilogue_f32: the mask epilogue needs M");
+    if (n == 0) return 0;
+    if (epilogue == 2)
+        return dispatch<false, true>(X, ldx, M, ldm, nullptr, 0, n, k, N, W, ldw, transposed ? 1 : 0, C, ldc, 0, (hipStream_t)stream);
+    return dispatch<false>(X, ldx, nullptr, 0, nullptr, 0, n, k, N, W, ldw, transposed ? 1 : 0, C, ldc, epilogue, (hipStream_t)stream);
 }
 
 // C (n x N) = epi(S . Bm) with S[r] = the ordered sum of row r's partial rows -- csrc's fix-up folded into the dense product

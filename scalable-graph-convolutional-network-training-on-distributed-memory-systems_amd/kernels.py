@@ -55,6 +55,8 @@ class DeviceCSR:
     dense3: Optional["DeviceDense3"] = None  # densest 512 x 128 blocks (bf16 matrix cores, three planes)
     fix_all: Optional[torch.Tensor] = None    # int32 [nfix_all,4] combined fix list (core + gather slots)
     slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
+    row_fix: Optional[torch.Tensor] = None    # int32 [nrows, 2] (begin, count) per row, count < 0: no slots (DeferredSum), built on demand
+    fix_heavy: Optional[torch.Tensor] = None  # int32 [nheavy, 4]: the fix records of rows with more than tuning.layer_fused_cap slots
     nslots_total: int = 0
     rows_wave: Optional[torch.Tensor] = None   # GAT kernels: int32 rows handled by one wave each ...
     rows_block: Optional[torch.Tensor] = None  # ... and by one 256-thread workgroup each (hub rows)
@@ -81,6 +83,20 @@ class DeviceDense:
     vals: torch.Tensor
     npieces: int
     nnz: int
+
+
+@dataclass
+class DeferredSum:
+    """An aggregation whose producers have run but whose fix-up has NOT: row r of the result is the ordered sum of the partial rows
+    ``slot_ids[begin .. begin + count)`` of ``ws`` (``row_fix[r] = (begin, count)``), or ``base[r]`` where count < 0 (a row a producer
+    wrote directly).  Consumed by pgcn_fixup_linear_f32 (gemm/pgcn_dense.hip: the fix-up as the loader of the dense product) or
+    completed by ``HipKernels.finish``.  Valid until the next SpMM on the same matrix reuses its work-space (stream order)."""
+    row_fix: torch.Tensor        # int32 [nrows, 2]
+    slot_ids: torch.Tensor       # int32
+    ws: torch.Tensor             # fp32 work-space, rows f floats apart
+    base: torch.Tensor           # fp32 [nrows, f]: the rows with count < 0
+    f: int
+    finish: object               # callable: runs the separate fix-up into ``base`` and returns it
 
 
 @dataclass
@@ -316,6 +332,40 @@ class HipKernels:
         fn(B, C)
         return C
 
+    def spmm_deferred(self, A: DeviceCSR, B: torch.Tensor, C: torch.Tensor):
+        """The producers of C = A.B without the fix-up: a DeferredSum for the consumer that does the sum itself, or None when this
+        matrix has no separate fix-up to defer (gather-only plans, row maps, widths the consumer does not take): the caller then
+        runs ``spmm``."""
+        f = B.shape[1]
+        if A.fix_all is None or A.slot_ids is None or A.row_map is not None or f % 4 or f > 128 or A.nrows == 0:
+            return None
+        key = (B.stride(0), C.stride(0), f, False, C.shape[1], B.stride(1), C.stride(1))
+        fn = A.launch_cache.get(key)
+        if fn is None:
+            fn = self._bind_spmm(A, B, C, False)
+            A.launch_cache[key] = fn
+        produce = getattr(fn, "produce", None)
+        if produce is None:
+            return None
+        if A.row_fix is None:
+            # rows with more partial rows than the consumer's loader keeps ids for in one go (hub rows: every strip piece, bf16 block
+            # and chunk of their row tile leaves one) are summed by the separate fix-up kernel into C and read from there: a wave's
+            # 32-row tile costs as many dependent round trips as its LONGEST list
+            cap = int(_T.layer_fused_cap)
+            light = A.fix_all[:, 2] <= cap
+            t = torch.zeros((A.nrows, 2), dtype=torch.int32, device=self.device)
+            t[:, 1] = -1
+            rows = A.fix_all[light, 0].long()
+            t[rows, 0] = A.fix_all[light, 1]
+            t[rows, 1] = A.fix_all[light, 2]
+            A.row_fix = t.contiguous()
+            A.fix_heavy = A.fix_all[~light].contiguous()
+        produce(B, C)
+        if A.fix_heavy.shape[0]:
+            _lib.check(self.lib.pgcn_spmm_fixup_f32(A.fix_heavy.data_ptr(), A.fix_heavy.shape[0], A.slot_ids.data_ptr(), None, A.ws.data_ptr(),
+                                                    C.data_ptr(), C.stride(0), f, 0, self._stream()), "pgcn_spmm_fixup_f32")
+        return DeferredSum(A.row_fix, A.slot_ids, A.ws, C, f, lambda: (fn.fixup(C), C)[1])
+
     def _bind_spmm(self, A: DeviceCSR, B: torch.Tensor, C: torch.Tensor, accumulate: bool):
         f = B.shape[1]
         self._check_dense(B, A.ncols, "B")
@@ -411,7 +461,7 @@ class HipKernels:
                 check(lib.pgcn_spmm_dense_bf16x3_f32(w3, n3, bi3, v3, pl3, np3, b, ldb, ncols, f, img3, imgb3, ws, ws_n, nst, s),
                       "pgcn_spmm_dense_bf16x3_f32")
 
-        def hybrid(B, C):
+        def produce(B, C):
             b, c, s = B.data_ptr(), C.data_ptr(), stream()
             if nside:
                 cur = torch.cuda.current_stream(dev)
@@ -429,7 +479,14 @@ class HipKernels:
                       "pgcn_spmm_core_f32")
             for i in range(nside):
                 cur.wait_stream(sides[i])
-            check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, c, ldc, f, fflags, s), "pgcn_spmm_fixup_f32")
+
+        def fixup(C):
+            check(lib.pgcn_spmm_fixup_f32(fixp, nfa, slots, rmap, ws, C.data_ptr(), ldc, f, fflags, stream()), "pgcn_spmm_fixup_f32")
+
+        def hybrid(B, C):
+            produce(B, C)
+            fixup(C)
+        hybrid.produce, hybrid.fixup = produce, fixup        # (spmm_deferred: the producers alone, the fix-up left to the consumer)
         return hybrid
 
     # -- GAT path (pgcn_gat.hip) ---------------------------------------------

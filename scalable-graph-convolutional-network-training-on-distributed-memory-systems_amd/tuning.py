@@ -83,6 +83,14 @@ class Tuning:
                                      # clamp, input gradient 116.8 us against 50 + 86 us (profiles/r05_dense_fused_variants.txt); epoch, three
                                      # runs each on one box: 10.52 / 10.48 / 10.45 ms off, 10.46 / 10.42 / 10.46 forward only,
                                      # 10.37 / 10.36 / 10.34 both (profiles/r05_dense_fused_epochs.txt) -> on since r05
+    layer_fused: int = 0             # r05, VERDICT r04 item 3 -- measured, NOT faster, off: a PGCN layer as ONE autograd node (PGCN._AggLinearRelu,
+                                     # needs dense_fused >= 2).  1: the backward re-associated (T = A^T.Gm, dH = T.W, dW = T^T.H: A.H is not kept
+                                     # for the backward) with the lower layer's ReLU mask folded into the input gradient; 2: + the aggregation's
+                                     # fix-up as the LOADER of both dense products (pgcn_fixup_linear_f32: A.H / T never round-trip), bit-identical
+                                     # forward.  Epochs on one MI355X (profiles/r05_layer_fused.txt): level 0 10.32-10.41 ms, level 1 10.35-10.43,
+                                     # level 2 10.33-10.42 (12.0 with every row through the folded loader: a wave's tile costs as many
+                                     # dependent round trips as its longest slot list, and the hub rows' lists have dozens of entries)
+    layer_fused_cap: int = 8         # level 2: rows with more partial rows than this go through the separate fix-up kernel
     # ---- GAT path -------------------------------------------------------------------------------------------
     gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
     gat_sliced: bool = True          # XCD-sliced edge gradient

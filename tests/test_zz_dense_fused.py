@@ -30,7 +30,9 @@ def test_library_exports_the_dense_entry_points():
     src = open(os.path.join(ROOT, "include", "pgcn_gemm.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(pgcn_(?:linear|dense|wgrad)_[a-z0-9_]+)\s*\(", src)))
-    assert names == ["pgcn_dense_last_error", "pgcn_linear_relu_f32", "pgcn_linear_relu_grad_input_f32"]
+    names += sorted(set(re.findall(r"\b(pgcn_fixup_[a-z0-9_]+)\s*\(", src)))
+    assert names == ["pgcn_dense_last_error", "pgcn_linear_epilogue_f32", "pgcn_linear_relu_f32", "pgcn_linear_relu_grad_input_f32",
+                     "pgcn_fixup_linear_f32"]
     L = ctypes.CDLL(P.GEMM_LIB_PATH)
     for n in names:
         assert hasattr(L, n), "libpgcn_gemm.so does not export %s" % n
@@ -159,9 +161,152 @@ def test_autograd_node_through_the_host_build(emu, monkeypatch):
     assert torch.allclose(yw, (xw @ ww.t()).clamp_min(0), atol=1e-5) and xw.grad is not None
 
 
+# ---- the fix-up of the aggregation as the loader of the product (pgcn_fixup_linear_f32) --------------------------------------------
+
+def _random_deferred(n, f, seed, dev="cpu", max_slots=11, ids=True):
+    """A random decomposition of an n x f matrix into partial rows: (row_fix, slot_ids, ws, base, S) with S the ordered fp32 sums
+    exactly as csrc's spmm_fixup_list_kernel forms them (((0 + x0) + x1) + ...).  Some rows are `direct` (count -1: taken from
+    base), some empty (count 0), some have more slots than one chunk of ids."""
+    g0 = torch.Generator().manual_seed(seed)
+    cnt = torch.randint(0, 6, (n,), generator=g0)
+    cnt[torch.rand(n, generator=g0) < 0.1] = torch.randint(9, max_slots + 1, (1,), generator=g0).item()
+    direct = torch.rand(n, generator=g0) < 0.15
+    cnt[direct] = 0
+    total = int(cnt.sum())
+    nslots = total + 5
+    ws = torch.randn(nslots, f, generator=g0)
+    if ids:
+        slot_ids = torch.randperm(nslots, generator=g0)[:total].to(torch.int32)
+        begin = torch.cumsum(cnt, 0) - cnt
+    else:                                             # consecutive slots: begin IS the first slot
+        slot_ids, begin = None, torch.cumsum(cnt, 0) - cnt
+    base = torch.randn(n, f, generator=g0)
+    S = torch.zeros(n, f)
+    for r in range(n):
+        if direct[r]:
+            S[r] = base[r]
+            continue
+        acc = torch.zeros(f)
+        for t in range(int(cnt[r])):
+            sid = int(slot_ids[begin[r] + t]) if ids else int(begin[r] + t)
+            acc = acc + ws[sid]
+        S[r] = acc
+    row_fix = torch.stack([begin, torch.where(direct, torch.full_like(cnt, -1), cnt)], 1).to(torch.int32).contiguous()
+    mv = lambda t: None if t is None else t.to(dev)
+    return mv(row_fix), mv(slot_ids), mv(ws), mv(base), mv(S)
+
+
+FIX_SHAPES = [(77, 128, 128), (64, 64, 64), (33, 16, 16), (100, 36, 128), (5, 8, 4), (1, 128, 128), (96, 128, 64), (200, 64, 128)]
+
+
+def _check_fixup(P, L, n, fin, fout, stream, dev="cpu", ids=True):
+    row_fix, slot_ids, ws, base, S = _random_deferred(n, fin, seed=n + fin, dev=dev, ids=ids)
+    g0 = torch.Generator().manual_seed(5)
+    w = (torch.randn(fout, fin, generator=g0) / 8).to(dev)
+    # forward: relu(S . W^T), bit-identical to the separate route (the ordered sum, then the product kernel on it)
+    y, none = P.fixup_linear_call(L, row_fix, slot_ids, ws, base, fin, w, True, P.EPI_RELU, None, False, stream)
+    assert none is None and torch.equal(y, P.linear_relu_call(L, S, w, True, stream))
+    # backward shape: S . W2 with the sum written out and the mask of the layer below folded in
+    w2 = (torch.randn(fin, fout, generator=g0) / 8).to(dev)
+    m = torch.randn(n, fout, generator=g0).to(dev)
+    y2, S2 = P.fixup_linear_call(L, row_fix, slot_ids, ws, base, fin, w2, False, P.EPI_MASK, m, True, stream)
+    assert torch.equal(S2, S)
+    plain = P.linear_epilogue_call(L, S, w2, False, P.EPI_NONE, None, stream)
+    assert torch.equal(y2, torch.where(m > 0, plain, torch.zeros((), device=dev)))
+    assert torch.equal(P.linear_epilogue_call(L, S, w2, False, P.EPI_MASK, m, stream), y2)
+    want = S.double() @ w2.double()
+    den = S.double().abs() @ w2.double().abs()
+    return _rel(plain, want, den) if n else 0.0
+
+
+@pytest.mark.parametrize("n,fin,fout", FIX_SHAPES)
+def test_host_build_of_the_fixup_loader(emu, n, fin, fout):
+    """gemm/pgcn_dense_tile.h sum_half / store_half / store_c_masked around the emulated MFMA: slot lists with ids and consecutive,
+    direct rows, empty rows, lists longer than one chunk of ids, ragged rows and widths."""
+    P = pkg("PGCN")
+    assert _check_fixup(P, emu, n, fin, fout, None) <= BOUND
+    assert _check_fixup(P, emu, n, fin, fout, None, ids=False) <= BOUND
+
+
+def test_fixup_loader_refusals(emu):
+    P = pkg("PGCN")
+    row_fix, slot_ids, ws, base, S = _random_deferred(10, 8, 1)
+    assert P.fixup_linear_call(emu, row_fix, slot_ids, ws, base, 8, torch.randn(4, 6), True, 1, None, False, None) is None   # W does not fit
+    rf6, ids6, ws6, base6, _ = _random_deferred(10, 6, 1)
+    assert P.fixup_linear_call(emu, rf6, ids6, ws6, base6, 6, torch.randn(4, 6), True, 1, None, False, None) is None        # width % 4
+    assert P.fixup_linear_call(emu, row_fix, slot_ids, ws, base, 8, torch.randn(8, 4), False, 2, None, False, None) is None  # mask missing
+    y = torch.empty(10, 4)
+    assert emu.pgcn_fixup_linear_f32(None, None, None, 8, base.data_ptr(), 8, 10, 8, torch.randn(4, 8).data_ptr(), 8, 4, 8, 1, None, 0,
+                                     None, 0, y.data_ptr(), 4, 1, None) == -1
+
+
+class _FakeEngine:
+    """AggregationEngine stand-in on CPU tensors: A is dense, every aggregation comes back as a kernels.DeferredSum whose partial rows
+    are a random split of the true rows (so that the loader's sum is exercised), as the HIP provider returns them."""
+
+    def __init__(self, A):
+        self.A = A
+        self.calls = []
+
+    def _split(self, X):
+        K = pkg("kernels")
+        n, f = X.shape
+        g0 = torch.Generator().manual_seed(len(self.calls))
+        a = torch.randn(n, f, generator=g0)
+        ws = torch.cat([a, X - a])                        # two slots per row: a and (X - a)
+        row_fix = torch.stack([2 * torch.arange(n), torch.full((n,), 2)], 1).to(torch.int32)
+        slot_ids = torch.stack([torch.arange(n), n + torch.arange(n)], 1).reshape(-1).to(torch.int32)
+        base = torch.empty(n, f)
+        def finish():
+            base.copy_(ws[:n] + ws[n:])
+            return base
+        return K.DeferredSum(row_fix, slot_ids, ws, base, f, finish)
+
+    def forward_deferred(self, H):
+        self.calls.append("f")
+        return self._split(self.A @ H)
+
+    def backward_deferred(self, G):
+        self.calls.append("b")
+        return self._split(self.A.t() @ G)
+
+
+def test_fused_layer_node_through_the_host_build(emu, monkeypatch):
+    """PGCN._AggLinearRelu (tuning.layer_fused): two stacked layers on the host build against plain autograd of the same two layers --
+    the re-associated backward (T = A^T.Gm, dH = T.W, dW = T^T.H), the mask of the layer below folded into the upper layer's input
+    gradient, and the lower layer recognising the pre-masked gradient it is handed."""
+    P, tuning = pkg("PGCN"), pkg("tuning")
+    monkeypatch.setattr(P, "_dense_stream", lambda t: None)
+    monkeypatch.setattr(P, "_dense_lib", lambda: emu)
+    monkeypatch.setattr(P, "_layer_fused_ok", lambda A, H, w: True)
+    monkeypatch.setattr(P, "_layer_fused_level", lambda: 2)
+    torch.manual_seed(4)
+    n, f = 70, 32
+    A = (torch.rand(n, n) < 0.1).float() * torch.rand(n, n)
+    eng = _FakeEngine(A)
+    l1, l2 = P.PGCN(eng, f, f), P.PGCN(eng, f, f)
+    H0 = torch.randn(n, f)
+    coef = torch.randn(n, f)
+    premasks = []
+    real_tb = torch.ops.aten.threshold_backward
+    H = H0.clone().requires_grad_(True)
+    out = l2(l1(H))
+    import unittest.mock as mock
+    with mock.patch.object(P.torch.ops.aten, "threshold_backward", side_effect=lambda *a: (premasks.append(1), real_tb(*a))[1]):
+        (out * coef).sum().backward()
+    Hr = H0.clone().requires_grad_(True)
+    w1, w2 = l1.linear.weight.detach().clone().requires_grad_(True), l2.linear.weight.detach().clone().requires_grad_(True)
+    ref = torch.relu((A @ torch.relu((A @ Hr) @ w1.t())) @ w2.t())
+    (ref * coef).sum().backward()
+    for got, want in ((out, ref), (H.grad, Hr.grad), (l1.linear.weight.grad, w1.grad), (l2.linear.weight.grad, w2.grad)):
+        assert float((got - want).detach().abs().max()) <= 5e-6 * float(want.detach().abs().max())
+    assert eng.calls == ["f", "f", "b", "b"]
+    assert len(premasks) == 1, "only the top layer runs a separate mask pass; the lower one is handed a pre-masked gradient"
+
+
 def test_cpu_tensors_never_reach_the_kernels():
     P, tuning = pkg("PGCN"), pkg("tuning")
-    assert tuning.Tuning().dense_fused == 2                           # on since r05 (tuning.py has the epochs)
+    assert tuning.Tuning().dense_fused == 2 and tuning.Tuning().layer_fused == 0   # (tuning.py has the epochs behind both)
     assert P.linear_relu_fused(torch.randn(8, 8), torch.randn(4, 8)) is None
     assert P.linear_relu_grad_input_fused(torch.randn(8, 4), torch.randn(8, 4), torch.randn(4, 8)) is None
 
@@ -237,3 +382,98 @@ def test_layer_with_the_kernels_switched_on(monkeypatch):
     for a, b in zip(out[2], out[0]):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,fin,fout", FIX_SHAPES + [(232965, 128, 128), (100003, 64, 64)])
+def test_fixup_loader_kernel(n, fin, fout):
+    """pgcn_fixup_linear_f32 on the GPU: bit-identical to the ordered sums followed by the product kernel, S written out exactly,
+    mask epilogue exact; both slot-list forms."""
+    P = pkg("PGCN")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    if n > 5000:                                       # (the host-side reference sum of _random_deferred is a Python loop)
+        g0 = torch.Generator().manual_seed(3)
+        cnt = torch.randint(0, 7, (n,), generator=g0)
+        cnt[::97] = 19
+        direct = torch.rand(n, generator=g0) < 0.1
+        cnt[direct] = 0
+        total = int(cnt.sum())
+        ws = torch.randn(total + 3, fin, generator=g0).to(dev)
+        slot_ids = torch.randperm(total + 3, generator=g0)[:total].to(torch.int32).to(dev)
+        begin = (torch.cumsum(cnt, 0) - cnt)
+        base = torch.randn(n, fin, generator=g0).to(dev)
+        row_fix = torch.stack([begin, torch.where(direct, torch.full_like(cnt, -1), cnt)], 1).to(torch.int32).contiguous().to(dev)
+        # the ordered sums by the library's own fix-up kernel (csrc): the route the folded loader replaces
+        K = pkg("kernels").HipKernels(dev)
+        rows = torch.nonzero(~direct).reshape(-1)
+        fix = torch.stack([rows, begin[rows], cnt[rows], torch.zeros_like(rows)], 1).to(torch.int32).contiguous().to(dev)
+        S = base.clone()
+        lib = pkg("_lib")
+        lib.check(K.lib.pgcn_spmm_fixup_f32(fix.data_ptr(), fix.shape[0], slot_ids.data_ptr(), None, ws.data_ptr(), S.data_ptr(), fin, fin,
+                                            0, st), "pgcn_spmm_fixup_f32")
+        w = (torch.randn(fout, fin, generator=g0) / 8).to(dev)
+        y, _ = P.fixup_linear_call(P._dense_lib(), row_fix, slot_ids, ws, base, fin, w, True, P.EPI_RELU, None, False, st)
+        assert torch.equal(y, P.linear_relu_call(P._dense_lib(), S, w, True, st))
+        w2 = (torch.randn(fin, fout, generator=g0) / 8).to(dev)
+        m = torch.randn(n, fout, generator=g0).to(dev)
+        y2, S2 = P.fixup_linear_call(P._dense_lib(), row_fix, slot_ids, ws, base, fin, w2, False, P.EPI_MASK, m, True, st)
+        assert torch.equal(S2, S)
+        assert torch.equal(y2, P.linear_epilogue_call(P._dense_lib(), S, w2, False, P.EPI_MASK, m, st))
+        assert torch.equal(y2, torch.where(m > 0, P.linear_epilogue_call(P._dense_lib(), S, w2, False, P.EPI_NONE, None, st),
+                                           torch.zeros((), device=dev)))
+        torch.cuda.synchronize()
+        return
+    assert _check_fixup(P, P._dense_lib(), n, fin, fout, st, dev=dev) <= BOUND
+    assert _check_fixup(P, P._dense_lib(), n, fin, fout, st, dev=dev, ids=False) <= BOUND
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f", [128, 64])
+def test_fused_layer_on_the_engine(f, monkeypatch):
+    """tuning.layer_fused on the real engine (a graph with strips, bf16 blocks and a gather part): the forward is BIT-IDENTICAL to
+    PSpMM + the separate product (same partial rows, same order of the sums, same product kernel), the re-associated backward agrees
+    with it to fp32 rounding, twice the same bits, and the deferred sum can still be finished by the separate fix-up."""
+    P, tuning, partition, synth = pkg("PGCN"), pkg("tuning"), pkg("partition"), pkg("synth")
+    engine, kernels = pkg("engine"), pkg("kernels")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    n = 40000
+    _, row, col, val = synth.make_graph(n, 6_000_000, seed=3)
+    monkeypatch.setattr(partition, "CORE_MIN_NNZ", 0)
+    monkeypatch.setattr(partition, "DENSE3_MIN_BLOCKS", 0)
+    monkeypatch.setattr(partition, "STRIP_MIN_RECORDS", 0)
+    part = partition.build_partition(row, col, val, n, torch.zeros(n, dtype=torch.int64), 0, 1)
+    K = kernels.HipKernels(dev)
+    eng = engine.AggregationEngine(part, K, dev)
+    assert eng.A_loc.fix_all is not None, "the test graph should have tiled parts (a separate fix-up to fold)"
+    P.device, P.myrank, P.world_size = dev, 0, 1
+    P.init_stats()
+    torch.manual_seed(0)
+    H0 = torch.rand(n, f, device=dev)
+    d = eng.forward_deferred(H0)
+    assert isinstance(d, kernels.DeferredSum)
+    assert torch.equal(d.finish(), eng.forward(H0))                      # the deferred sum completed by the separate fix-up
+    l1, l2 = P.PGCN(eng, f, f).to(dev), P.PGCN(eng, f, f).to(dev)
+    coef = torch.randn(n, f, device=dev)
+    res = {}
+    for level in (0, 2, 2, 1):
+        monkeypatch.setattr(tuning.T, "layer_fused", level)
+        for l in (l1, l2):
+            l.linear.weight.grad = None
+        H = H0.clone().requires_grad_(True)
+        out = l2(l1(H))
+        (out * coef).sum().backward()
+        torch.cuda.synchronize()
+        got = (out.detach(), H.grad, l1.linear.weight.grad.clone(), l2.linear.weight.grad.clone())
+        if level in res:
+            for a, b in zip(got, res[level]):
+                assert torch.equal(a, b), "the fused layer is not reproducible"
+        res[level] = got
+    assert torch.equal(res[2][0], res[0][0]), "folding the fix-up into the product changed the forward's bits"
+    for a, b in zip(res[1], res[2]):
+        assert torch.equal(a, b), "the node with finished operands (level 1) and with the folded fix-up (level 2) differ"
+    for a, b in zip(res[2][1:], res[0][1:]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), float((a - b).abs().max()) / float(b.abs().max())
