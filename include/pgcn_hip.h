@@ -153,6 +153,14 @@ int pgcn_spmm_plan_host(const int64_t *rowptr_host, const int32_t *slice_cnt,
                         int32_t small_row, int32_t *tasks,
                         int64_t cap_tasks, int32_t *fix, int64_t cap_fix, int64_t *seg,
                         int64_t *ntasks, int64_t *nfix, int64_t *nslots);
+/* ... with rows of small_row < entries <= pair_row cut per PAIR of adjacent slices (nslices / 2 tasks, placed on the two
+ * segments of the pair alternately by row): half the partial rows for such rows.  pair_row = 0: exactly pgcn_spmm_plan_host. */
+int pgcn_spmm_plan_host_ex(const int64_t *rowptr_host, const int32_t *slice_cnt,
+                           const uint8_t *row_flags, int64_t nrows,
+                           int32_t nslices, int32_t ngroups, int32_t group_min_row, int32_t chunk,
+                           int32_t small_row, int32_t pair_row, int32_t *tasks,
+                           int64_t cap_tasks, int32_t *fix, int64_t cap_fix, int64_t *seg,
+                           int64_t *ntasks, int64_t *nfix, int64_t *nslots);
 
 /* ---- LDS-tiled dense core ------------------------------------------------------
  * Same product, for the entries that fall into DENSE 128 x 128 tiles of the block (after

@@ -74,6 +74,21 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
                                    int32_t *tasks, int64_t cap_tasks, int32_t *fix,
                                    int64_t cap_fix, int64_t *seg, int64_t *ntasks,
                                    int64_t *nfix, int64_t *nslots) {
+    return pgcn_spmm_plan_host_ex(rowptr, slice_cnt, row_flags, nrows, nslices, ngroups, group_min_row, chunk, small_row, 0, tasks,
+                                  cap_tasks, fix, cap_fix, seg, ntasks, nfix, nslots);
+}
+
+//   * pair_row > small_row (r05, even nslices, ngroups == 1): rows with small_row < entries <= pair_row are cut into nslices / 2
+//     tasks, one per PAIR of adjacent slices (2p, 2p + 1) -- adjacent in storage, so still one contiguous run of entries -- placed
+//     on segment 2p or 2p + 1 alternately by row: half the partial rows of such a row, at the price of an XCD also seeing the
+//     neighbouring slice's columns for those tasks.
+extern "C" int pgcn_spmm_plan_host_ex(const int64_t *rowptr, const int32_t *slice_cnt,
+                                      const uint8_t *row_flags, int64_t nrows, int32_t nslices,
+                                      int32_t ngroups, int32_t group_min_row, int32_t chunk,
+                                      int32_t small_row, int32_t pair_row,
+                                      int32_t *tasks, int64_t cap_tasks, int32_t *fix,
+                                      int64_t cap_fix, int64_t *seg, int64_t *ntasks,
+                                      int64_t *nfix, int64_t *nslots) {
     if (!rowptr || nrows < 0 || chunk <= 0 || small_row < 0 || !ntasks || !nfix || !nslots || !seg ||
         nslices < 1 || nslices > PGCN_MAX_SLICES || ngroups < 1 || ngroups > PGCN_MAX_COL_GROUPS ||
         (nslices * ngroups > 1 && !slice_cnt))
@@ -84,8 +99,13 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
     const int V = S * G;             // "virtual slices": entries of a row are grouped by v = s*G + g
     // rows shorter than group_min_row are cut per slice only: their column groups are merged
     // back (cutting a medium row 8*G ways would only multiply tiny tasks and partial sums)
+    const bool pairing = pair_row > small_row && G == 1 && S > 1 && S % 2 == 0;
+    auto paired = [&](int64_t len) -> bool { return pairing && len <= pair_row; };
+    // the segment (XCD) that runs piece v of row r
+    auto seg_of = [&](int64_t r, int64_t len, int v) -> int { return paired(len) ? v + (int)(r & 1) : v / G; };
     auto piece_len = [&](int64_t r, int64_t len, int v) -> int64_t {
         if (V == 1) return len;
+        if (paired(len)) return (v & 1) ? 0 : (int64_t)slice_cnt[r * V + v] + slice_cnt[r * V + v + 1];
         if (G == 1 || len >= group_min_row) return slice_cnt[r * V + v];
         if (v % G != 0) return 0;
         int64_t l = 0;
@@ -122,7 +142,7 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
         for (int v = 0; v < V; ++v) {
             const int64_t l = piece_len(r, len, v);
             const int64_t k = (l + chunk - 1) / chunk;
-            per_slice[v / G] += k;
+            per_slice[seg_of(r, len, v)] += k;
             row_tasks += k;
         }
         nt += row_tasks;
@@ -174,8 +194,8 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
                 for (int64_t j = 0; j < k; ++j) {
                     const int64_t o = j * piece;
                     const int64_t ll = (o + piece <= l) ? piece : (l - o);
-                    rec[cur[v / G]++] = TaskRec{rowptr[r] + off + o, (int32_t)ll,
-                                                direct ? ~(int32_t)r : (int32_t)slot++, v % G};
+                    rec[cur[seg_of(r, len, v)]++] = TaskRec{rowptr[r] + off + o, (int32_t)ll,
+                                                            direct ? ~(int32_t)r : (int32_t)slot++, v % G};
                 }
             }
             off += l;

@@ -136,7 +136,7 @@ class DeviceCore:
 def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarray] = None,
                small_row: int = DEFAULT_SMALL_ROW, force: bool = False,
                row_flags: Optional[np.ndarray] = None, ngroups: int = 1,
-               group_min_row: int = GROUP_MIN_ROW):
+               group_min_row: int = GROUP_MIN_ROW, pair_row: Optional[int] = None):
     """Host-side task list (pgcn_spmm_plan_host).  Returns (tasks, fix, nslots, seg) with
     numpy int32 arrays; tasks is None when the plan is trivial (unsliced and no row
     exceeds ``chunk``): the one-task-per-row kernel path needs no plan."""
@@ -157,16 +157,17 @@ def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarr
         force = True
     seg = (ctypes.c_int64 * (S + 1))()
     nt, nf, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row, None, 0,
-                                     None, 0, seg, ctypes.byref(nt), ctypes.byref(nf), ctypes.byref(ns)),
+    pair_row = int(_T.spmm_pair_row) if pair_row is None else int(pair_row)
+    _lib.check(L.pgcn_spmm_plan_host_ex(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row, pair_row,
+                                        None, 0, None, 0, seg, ctypes.byref(nt), ctypes.byref(nf), ctypes.byref(ns)),
                "pgcn_spmm_plan_host")
     if nf.value == 0 and S == 1 and not force:
         return None, None, 0, None
     tasks = np.empty((nt.value, 4), dtype=np.int32)
     fix = np.empty((max(nf.value, 1), 4), dtype=np.int32)
-    _lib.check(L.pgcn_spmm_plan_host(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row,
-                                     tasks.ctypes.data, nt.value, fix.ctypes.data, nf.value, seg, ctypes.byref(nt),
-                                     ctypes.byref(nf), ctypes.byref(ns)), "pgcn_spmm_plan_host")
+    _lib.check(L.pgcn_spmm_plan_host_ex(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row, pair_row,
+                                        tasks.ctypes.data, nt.value, fix.ctypes.data, nf.value, seg, ctypes.byref(nt),
+                                        ctypes.byref(nf), ctypes.byref(ns)), "pgcn_spmm_plan_host")
     return tasks, fix[:nf.value], int(ns.value), seg
 
 
@@ -204,7 +205,7 @@ class HipKernels:
         self.adaptive_chunk = _T.spmm_adaptive_chunk
 
     # -- data placement -------------------------------------------------
-    def prepare(self, csr: HostCSR, pattern_only: bool = False) -> DeviceCSR:
+    def prepare(self, csr: HostCSR, pattern_only: bool = False, pair_row: Optional[int] = None) -> DeviceCSR:
         dev = self.device
         rowptr_host = csr.rowptr.detach().cpu().numpy()
         sc = None if csr.slice_cnt is None else csr.slice_cnt.detach().cpu().numpy()
@@ -218,7 +219,8 @@ class HipKernels:
             chunk = min(self.chunk, max(64, 1 << max(e.bit_length() - 1, 0)))
         tasks, fix, nslots, seg = build_plan(rowptr_host, chunk, sc, self.small_row,
                                              force=csr.row_map is not None, row_flags=rf,
-                                             ngroups=csr.ngroups)
+                                             ngroups=csr.ngroups,
+                                             pair_row=getattr(self, "pair_row", None) if pair_row is None else pair_row)
         d = DeviceCSR(
             nrows=csr.nrows, ncols=csr.ncols, nnz=csr.nnz,
             rowptr=csr.rowptr.to(dev, torch.int64).contiguous(),
@@ -495,7 +497,7 @@ class HipKernels:
         head through ``with_values``."""
         if csr.core is not None or csr.row_map is not None:
             raise _lib.PgcnError("GAT structures are plain (sliced) CSR blocks")
-        d = self.prepare(csr, pattern_only=True)
+        d = self.prepare(csr, pattern_only=True, pair_row=0)        # (the attention kernels walk (row, slice) pieces)
         d.rows_wave = rows_wave.to(self.device, torch.int32).contiguous()
         d.rows_block = rows_block.to(self.device, torch.int32).contiguous()
         if csr.nslices == 8 and csr.slice_cnt is not None and csr.ngroups == 1:

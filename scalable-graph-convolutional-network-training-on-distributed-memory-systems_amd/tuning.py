@@ -22,6 +22,8 @@ class Tuning:
     spmm_chunk: int = 1024           # entries per task of a long row ...
     spmm_adaptive_chunk: bool = True # ... shrunk on small blocks (entries / 8192, >= 64): a task is a latency chain
     spmm_small_row: int = 96         # rows up to this many entries are ONE unsliced task
+    spmm_pair_row: int = 0           # r05: rows with small_row < entries <= this are cut per PAIR of adjacent XCD slices (4 tasks and
+                                     # 4 partial rows instead of 8); 0 = off.  Measured: profiles/r05_pair_rows.txt
     group_min_row: int = 4096        # column groups (explicit `ngroups` only) cut rows at least this long
     fpass: str = "auto"              # 64-feature passes of the gather part: auto (whole graphs, f > 64) | 64 | 0
     xcd_swizzle: bool = True         # unsliced plans: one contiguous row range per XCD

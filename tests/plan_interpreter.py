@@ -18,16 +18,17 @@ PKG = "scalable-graph-convolutional-network-training-on-distributed-memory-syste
 class HostPlanner:
     """The host half of ``HipKernels`` (plan building, slot lists), tensors left on the CPU."""
 
-    def __init__(self, chunk=None, small_row=None, adaptive_chunk=None):
+    def __init__(self, chunk=None, small_row=None, adaptive_chunk=None, pair_row=None):
         k = importlib.import_module(PKG + ".kernels")
         self.device = torch.device("cpu")
         self.chunk = k.DEFAULT_CHUNK if chunk is None else chunk
         self.small_row = k.DEFAULT_SMALL_ROW if small_row is None else small_row
         self.adaptive_chunk = k._T.spmm_adaptive_chunk if adaptive_chunk is None else adaptive_chunk
         self._k = k
+        self.pair_row = pair_row
 
-    def prepare(self, csr, pattern_only=False):
-        return self._k.HipKernels.prepare(self, csr, pattern_only)
+    def prepare(self, csr, pattern_only=False, pair_row=None):
+        return self._k.HipKernels.prepare(self, csr, pattern_only, pair_row)
 
     def prepare_gat(self, csr, rows_wave, rows_block):
         return self._k.HipKernels.prepare_gat(self, csr, rows_wave, rows_block)
@@ -40,7 +41,7 @@ def _np(t):
     return None if t is None else t.detach().cpu().numpy()
 
 
-def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None):
+def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None, pair_row=0):
     """C (+)= A . B by walking the device-side arrays of ``d`` (a DeviceCSR whose tensors live on the CPU).
     Returns (C, info); rows nobody wrote stay NaN when ``accumulate`` is False (the caller decides what they must be).
     ``slice_of(cols)``: the slice of a column when the block was built with range slices (default col % nslices)."""
@@ -88,7 +89,12 @@ def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None):
                     assert rows[0] == rows[-1], "a task spans two rows"
                     if d.nslices > 1:       # a task of segment s stays inside slice s of its row -- or is a whole short row
                         whole = k0 == rowptr[rows[0]] and k0 + length == rowptr[rows[0] + 1]
-                        assert whole or ((col[sl] % d.nslices if slice_of is None else slice_of(col[sl])) == s).all()
+                        sls = col[sl] % d.nslices if slice_of is None else slice_of(col[sl])
+                        rowlen = rowptr[rows[0] + 1] - rowptr[rows[0]]
+                        if pair_row and rowlen <= pair_row:   # (tuning.spmm_pair_row: a task of a PAIR of adjacent slices, on either's segment)
+                            assert whole or ((sls // 2 == s // 2).all() and s == 2 * (s // 2) + (rows[0] & 1))
+                        else:
+                            assert whole or (sls == s).all()
                 acc = (val[sl, None] * B[col[sl]]).sum(0)
                 if dst >= 0:
                     assert np.isnan(ws[dst]).all(), "two tasks share a partial-sum slot"

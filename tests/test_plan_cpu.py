@@ -42,6 +42,9 @@ VARIANTS = {
     "gather_sliced_short_tasks": (dict(nslices=8, core=False), dict(chunk=64, small_row=16, adaptive_chunk=False), ()),
     "gather_unsliced_long_rows": (dict(nslices=1, core=False), dict(chunk=128, adaptive_chunk=False), ()),
     "gather_column_groups": (dict(nslices=8, core=False, ngroups=4), {}, ()),
+    "gather_slice_pairs": (dict(nslices=8, core=False), dict(small_row=16, pair_row=200, adaptive_chunk=False), ()),
+    "strips+bf16x3+slice_pairs": (dict(nslices=8, core=True, strip=True, strip_min=64, dense3_tau=0.12), dict(small_row=8, pair_row=120, adaptive_chunk=False),
+                                  ("strip", "dense3")),
     "range_slices": (dict(core=True, strip=True, strip_min=64, dense3_tau=0.15, slice_bounds=[0, 40, 100, 250, 600, 1100, 1700, 2400, 3000]), {},
                      ("strip", "dense3")),
 }
@@ -64,8 +67,16 @@ def test_launch_group_plan_reproduces_the_product(name):
     if "slice_bounds" in kw:        # range slices: a task's slice is the column range it falls in, not col % 8
         inner = np.asarray(kw["slice_bounds"][1:-1])
         slice_of = lambda cols: np.searchsorted(inner, cols, side="right")      # noqa: E731
-    C, info = run_plan(d, B, slice_of=slice_of)
+    C, info = run_plan(d, B, slice_of=slice_of, pair_row=pk.get("pair_row", 0))
     assert not np.isnan(C).any(), "rows nobody wrote"
+    if "slice_pairs" in name:     # rows in (small_row, pair_row] have 4 tasks (fewer if a pair is empty), never 8
+        ln = np.diff(d.rowptr.numpy())
+        t = d.tasks.numpy().astype(np.int64)
+        k0 = (t[:, 0] & 0xffffffff) | (t[:, 1] << 32)
+        trow = np.searchsorted(d.rowptr.numpy(), k0[t[:, 2] > 0], side="right") - 1
+        per_row = np.bincount(trow, minlength=d.nrows)
+        mid = (ln > pk["small_row"]) & (ln <= pk["pair_row"])
+        assert mid.sum() > 20 and per_row[mid].max() <= 4 and (not (ln > pk["pair_row"]).any() or per_row[ln > pk["pair_row"]].max() > 4)
     assert np.abs(C - ref).max() < TOL
     assert info["entries_gather"] == h.col.numel()
     assert info["entries_strip"] == (h.strip.nnz if h.strip is not None else 0)
@@ -74,12 +85,12 @@ def test_launch_group_plan_reproduces_the_product(name):
         assert d.nfix > 100                                   # many rows are cut into several tasks
     # accumulate: C0 + A . B through the same plan
     C0 = rng.standard_normal((n, 6))
-    C2, _ = run_plan(d, B, C0=C0, accumulate=True, slice_of=slice_of)
+    C2, _ = run_plan(d, B, C0=C0, accumulate=True, slice_of=slice_of, pair_row=pk.get("pair_row", 0))
     assert np.abs(C2 - (C0 + ref)).max() < TOL
     # pattern-only upload (the unpack matrices of the backward exchange): all values one
     if not parts:
         dp = HostPlanner(**pk).prepare(h, pattern_only=True)
-        Cp, _ = run_plan(dp, B)
+        Cp, _ = run_plan(dp, B, pair_row=pk.get("pair_row", 0))
         ones = sp.csr_matrix((np.ones(A.nnz), A.indices, A.indptr), shape=A.shape)
         assert np.abs(Cp - ones @ B).max() < TOL
 
