@@ -155,6 +155,7 @@ int pgcn_spmm_plan_host(const int64_t *rowptr_host, const int32_t *slice_cnt,
                         int64_t *ntasks, int64_t *nfix, int64_t *nslots);
 /* ... with rows of small_row < entries <= pair_row cut per PAIR of adjacent slices (nslices / 2 tasks, placed on the two
  * segments of the pair alternately by row): half the partial rows for such rows.  pair_row = 0: exactly pgcn_spmm_plan_host. */
+#define PGCN_PLAN_AFFINE_SMALL 0x40000000   /* OR-ed into pair_row: an unsliced row's task runs on the segment (XCD) of its fullest slice */
 int pgcn_spmm_plan_host_ex(const int64_t *rowptr_host, const int32_t *slice_cnt,
                            const uint8_t *row_flags, int64_t nrows,
                            int32_t nslices, int32_t ngroups, int32_t group_min_row, int32_t chunk,

@@ -99,7 +99,23 @@ extern "C" int pgcn_spmm_plan_host_ex(const int64_t *rowptr, const int32_t *slic
     const int V = S * G;             // "virtual slices": entries of a row are grouped by v = s*G + g
     // rows shorter than group_min_row are cut per slice only: their column groups are merged
     // back (cutting a medium row 8*G ways would only multiply tiny tasks and partial sums)
+    const bool affine = (pair_row & PGCN_PLAN_AFFINE_SMALL) != 0 && V > 1;   // unsliced rows go to the segment of their fullest slice
+    pair_row &= ~PGCN_PLAN_AFFINE_SMALL;
     const bool pairing = pair_row > small_row && G == 1 && S > 1 && S % 2 == 0;
+    // the segment of an UNSLICED row: round-robin, or (affine) the XCD whose slice holds most of its entries -- those reads then
+    // meet the rows of B that XCD's sliced tasks keep in its L2 (ties and empty rows: round-robin)
+    auto small_seg = [&](int64_t r) -> int {
+        if (!affine) return (int)(r % S);
+        int best = (int)(r % S);
+        int64_t most = 0;
+        for (int g = 0; g < G; ++g) most += slice_cnt[r * V + best * G + g];
+        for (int q = 0; q < S; ++q) {
+            int64_t c = 0;
+            for (int g = 0; g < G; ++g) c += slice_cnt[r * V + q * G + g];
+            if (c > most) { most = c; best = q; }
+        }
+        return best;
+    };
     auto paired = [&](int64_t len) -> bool { return pairing && len <= pair_row; };
     // the segment (XCD) that runs piece v of row r
     auto seg_of = [&](int64_t r, int64_t len, int v) -> int { return paired(len) ? v + (int)(r & 1) : v / G; };
@@ -133,7 +149,7 @@ extern "C" int pgcn_spmm_plan_host_ex(const int64_t *rowptr, const int32_t *slic
         const bool shared = row_flags && row_flags[r];   // other kernels add into this row
         if (shared && len == 0) continue;                // nothing of ours to add
         if (len <= small_row || (V == 1 && len <= chunk)) {   // one unsliced task (also: empty row)
-            per_slice[r % S] += 1;
+            per_slice[small_seg(r)] += 1;
             nt += 1;
             if (shared) { ns += 1; ++nf; }
             continue;
@@ -169,9 +185,9 @@ extern "C" int pgcn_spmm_plan_host_ex(const int64_t *rowptr, const int32_t *slic
             if (shared) {
                 int32_t *x = fix + 4 * fi++;
                 x[0] = (int32_t)r; x[1] = (int32_t)slot; x[2] = 1; x[3] = 0;
-                rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, (int32_t)slot++, 0};
+                rec[cur[small_seg(r)]++] = TaskRec{rowptr[r], (int32_t)len, (int32_t)slot++, 0};
             } else {
-                rec[cur[r % S]++] = TaskRec{rowptr[r], (int32_t)len, ~(int32_t)r, 0};
+                rec[cur[small_seg(r)]++] = TaskRec{rowptr[r], (int32_t)len, ~(int32_t)r, 0};
             }
             continue;
         }

@@ -158,6 +158,8 @@ def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarr
     seg = (ctypes.c_int64 * (S + 1))()
     nt, nf, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
     pair_row = int(_T.spmm_pair_row) if pair_row is None else int(pair_row)
+    if _T.spmm_affine_small and slice_cnt is not None:
+        pair_row |= 0x40000000          # PGCN_PLAN_AFFINE_SMALL
     _lib.check(L.pgcn_spmm_plan_host_ex(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row, pair_row,
                                         None, 0, None, 0, seg, ctypes.byref(nt), ctypes.byref(nf), ctypes.byref(ns)),
                "pgcn_spmm_plan_host")

@@ -24,6 +24,10 @@ class Tuning:
     spmm_small_row: int = 96         # rows up to this many entries are ONE unsliced task
     spmm_pair_row: int = 0           # r05: rows with small_row < entries <= this are cut per PAIR of adjacent XCD slices (4 tasks and
                                      # 4 partial rows instead of 8); 0 = off.  Measured: profiles/r05_pair_rows.txt
+    spmm_affine_small: bool = True   # r05: an unsliced short row's task runs on the XCD of its FULLEST col % 8 slice instead of
+                                     # round-robin (those reads meet the rows that XCD's sliced tasks keep in its L2).  Gather part, kernels one
+                                     # after the other: Reddit shape 703-706 -> 696 us, SBM 1 975 -> 1 963, products 4 788 -> 4 743
+                                     # (profiles/r05_affine_small.txt): ~1 %, the same sign on all three graphs
     group_min_row: int = 4096        # column groups (explicit `ngroups` only) cut rows at least this long
     fpass: str = "auto"              # 64-feature passes of the gather part: auto (whole graphs, f > 64) | 64 | 0
     xcd_swizzle: bool = True         # unsliced plans: one contiguous row range per XCD
