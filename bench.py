@@ -690,7 +690,7 @@ def bench_gat(args, rank, world, dev, backend, stage):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.on = dtimer.on = not args.no_kernel_timing
+    timer.on = not args.no_kernel_timing
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -699,7 +699,7 @@ def bench_gat(args, rank, world, dev, backend, stage):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.on = dtimer.on = False
+    timer.on = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         pkg("PGCN")._all_reduce(t, dist.ReduceOp.MAX)

@@ -32,6 +32,14 @@ pmc reddit_sbm  reddit sbm 1 128 random loc --generator sbm
 python tools/make_shards.py --workload papers --ranks 8 --only-rank 0 --device cuda --out /tmp/papers > $out/papers_make_shards.txt 2>&1
 pmc papers_r8l  papers rmat 0/8 64 block loc   --workload papers --shards /tmp/papers --emulate-rank 0/8 --features 64 --block loc
 pmc papers_r8h0 papers rmat 0/8 64 block halo0 --workload papers --shards /tmp/papers --emulate-rank 0/8 --features 64 --block halo0
+# BASELINE config 5: the dominant pass of the GAT epoch (the fused transposed product + edge gradient), counters over the bench command itself
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  t=$(echo "$set" | tr ' ' '+')
+  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm_heads" --output-format csv -d $out/pmc_gat/$t -- python bench.py --workload reddit-gat --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/pmc_gat_$t.log 2>&1
+done
+python tools/pmc_summary.py $out/pmc_gat spmm_heads > $out/pmc_summary_gat.txt
+python tools/make_pmc_traffic.py $out/pmc_summary_gat.txt $out/pmc_traffic.json profiles/${tag}_pmc_gat.txt reddit-gat rmat 1 256 random gat_grad "spmm_heads_kernel<4, true, true, false>"
+rm -rf $out/pmc_gat
 cp $out/pmc_traffic.json profiles/pmc_traffic.json      # (bench.py reads it from there for the lines below)
 else python tools/make_shards.py --workload papers --ranks 8 --only-rank 0 --device cuda --out /tmp/papers > $out/papers_make_shards.txt 2>&1; fi
 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1200 $out/bench.json; echo
