@@ -1042,10 +1042,12 @@ def main():
                    "mfma_tile_fill_min": (partition.DENSE_TAU if partition.DENSE_ON and not partition.DENSE3_ON else None),
                    "bf16x3_block_fill_min": partition.DENSE3_TAU if partition.DENSE3_ON else None,
                    "exchange_rounds": part.rounds, "vertex_order": part.order_info,
-                   "dense_gemm": ("stock rocBLAS GEMMs launched by the solution index recorded in tunableop/gfx950.csv (x.W^T, g.W); "
-                                  "dW: PyTorch's default pick" if not partition._T.gemm_tunableop else
-                                  "stock rocBLAS / hipBLASLt via PyTorch, kernel per shape picked by TunableOp in set-up") if gemm_tuned
-                                 else "stock rocBLAS / hipBLASLt via PyTorch (default pick)",
+                   "dense_gemm": ("x.W^T and g.W: the package's own matrix-core kernels (see dense_fused); dW = Gm^T.AH: PyTorch's batched "
+                                  "product over 64 row slabs + their sum" if int(partition._T.dense_fused) >= 2 and f <= 128 and f % 4 == 0 else
+                                  ("stock rocBLAS GEMMs launched by the solution index recorded in tunableop/gfx950.csv (x.W^T, g.W); "
+                                   "dW: PyTorch's default pick" if not partition._T.gemm_tunableop else
+                                   "stock rocBLAS / hipBLASLt via PyTorch, kernel per shape picked by TunableOp in set-up") if gemm_tuned
+                                  else "stock rocBLAS / hipBLASLt via PyTorch (default pick)"),
                    "dense_fused": {0: "off (library GEMM + clamp / mask passes)",
                                    1: "relu(x.W^T) by gemm/pgcn_dense.hip (bf16-split MFMA, fp32 accuracy)",
                                    2: "relu(x.W^T) and (g (.) mask).W by gemm/pgcn_dense.hip (bf16-split MFMA, fp32 accuracy)"

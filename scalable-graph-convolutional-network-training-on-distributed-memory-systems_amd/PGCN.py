@@ -644,6 +644,10 @@ def tune_dense_gemms(n_rows, f, dev):
     from .tuning import T as _T
     if not _T.gemm_tuning or dev.type != "cuda" or n_rows * f < (1 << 24) or (n_rows, f) in _gemm_tuned_shapes:
         return False
+    if int(_T.dense_fused) >= 2 and f <= 128 and f % 4 == 0:
+        # r05: both n x f x f products of a layer run as the package's own kernels (gemm/pgcn_dense.hip); the library kernels of these
+        # shapes are not launched in a step, so their code objects are not loaded during set-up either (1.5 s on a cold box)
+        return False
     if not _T.gemm_tunableop:
         # r04 default: no TunableOp in the process at all -- the recorded rocBLAS kernels of this shape are launched by index
         # (mm_nt / mm_nn above); one launch each here, so that the kernel file is read during set-up, not in the first step
