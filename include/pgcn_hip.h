@@ -382,6 +382,13 @@ int pgcn_csr_row_sums_f32(const int64_t *rowptr, const int64_t *perm, int64_t nr
                           const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
                           int64_t nrows_block, const float *src, int32_t planes, float *out,
                           int64_t ldo, pgcn_stream_t stream);
+
+/* The per-row, per-head dot products of the GAT backward in ONE pass (r05): t[i][k] = <dOut_i, out_i> over head k's d columns
+ * (the softmax backward of GPU/PGAT.py:147-148 needs it per row), and, with VC = [V | C] (n x (heads*d + heads), ldv: the second
+ * accumulator of pgcn_spmm_heads_forward2_f32), ds1[i][k] = <dOut_i, V_i>_k - t[i][k] * C[i][k]; VC == NULL: t only.  t, ds1:
+ * n x heads, contiguous.  PGCN_EUNSUPPORTED unless heads * d <= 256, d / 4 a power of two, 16-byte rows. */
+int pgcn_gat_row_dots_f32(const float *dOut, int64_t ldo, const float *out, int64_t ldout, const float *VC, int64_t ldv,
+                          int64_t n, int32_t heads, int32_t d, float *t, float *ds1, pgcn_stream_t stream);
 int pgcn_csr_permute_f32(const float *src, const int64_t *perm, int64_t nnz, int32_t planes,
                          float *dst, pgcn_stream_t stream);
 

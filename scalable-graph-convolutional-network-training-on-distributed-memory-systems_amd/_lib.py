@@ -84,6 +84,7 @@ SIGNATURES = {
                                                     _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, ctypes.c_float, _i32,
                                                     _vp, _vp, _vp, _i64, _i64, _vp]),
     "pgcn_csr_row_sums_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
+    "pgcn_gat_row_dots_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "pgcn_csr_permute_f32": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "pgcn_nll_rows_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "pgcn_nll_rows_backward_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _i64, _vp]),

@@ -851,6 +851,59 @@ extern "C" int pgcn_gat_edge_weights_t_f32(const int64_t *rowptr_t, const int32_
     return PGCN_OK;
 }
 
+// ---- per-row, per-head dot products of the backward (r05) -------------------------------------------------------------------------
+// t[i][k] = <dOut_i, out_i> over head k (PGAT.py's softmax backward needs it per row), and -- with the forward pass's second
+// accumulator VC = [V | C] -- ds1[i][k] = <dOut_i, V_i>_k - t[i][k] * C[i][k].  One wave per row, a lane holds 4 consecutive
+// features, a head = d / 4 consecutive lanes (a power of two): ONE pass over dOut, out and V instead of the four element-wise /
+// reduction kernels the tensor expressions launch (2 x 239 MB written and read back as temporaries at the benchmark shape).
+namespace {
+__global__ __launch_bounds__(256) void gat_row_dots_kernel(const float *__restrict__ dOut, int64_t ldo, const float *__restrict__ out,
+                                                           int64_t ldout, const float *__restrict__ VC, int64_t ldv, int64_t n,
+                                                           int heads, int d, float *__restrict__ t, float *__restrict__ ds1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int F = heads * d, hl = d >> 2;             // lanes per head
+    const int f0 = lane * 4;
+    float a = 0.f, b = 0.f;
+    if (f0 < F) {
+        const float4 g = *reinterpret_cast<const float4 *>(dOut + row * ldo + f0);
+        const float4 o = *reinterpret_cast<const float4 *>(out + row * ldout + f0);
+        a = ((g.x * o.x + g.y * o.y) + g.z * o.z) + g.w * o.w;
+        if (VC) {
+            const float4 v = *reinterpret_cast<const float4 *>(VC + row * ldv + f0);
+            b = ((g.x * v.x + g.y * v.y) + g.z * v.z) + g.w * v.w;
+        }
+    }
+    for (int o = hl >> 1; o > 0; o >>= 1) {           // butterfly inside a head's lanes: every lane ends with the head's sum
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    if (f0 < F && (lane & (hl - 1)) == 0) {
+        const int k = lane / hl;
+        t[row * heads + k] = a;
+        if (VC) ds1[row * heads + k] = b - a * VC[row * ldv + F + k];
+    }
+}
+}  // namespace
+
+extern "C" int pgcn_gat_row_dots_f32(const float *dOut, int64_t ldo, const float *out, int64_t ldout, const float *VC, int64_t ldv,
+                                     int64_t n, int32_t heads, int32_t d, float *t, float *ds1, pgcn_stream_t stream) {
+    const char *who = "pgcn_gat_row_dots_f32";
+    const int hl = d / 4;
+    if (n < 0 || heads < 1 || d < 4 || d % 4 || (hl & (hl - 1)) || heads * d > 256 || ldo < heads * d || ldout < heads * d ||
+        (VC && ldv < heads * d + heads))
+        return pgcn_set_error2(PGCN_EUNSUPPORTED, who, "heads * d <= 256, d / 4 a power of two");
+    if (n == 0) return PGCN_OK;
+    if (!dOut || !out || !t || (VC && !ds1)) return pgcn_set_error2(PGCN_EINVAL, who, "null pointer");
+    if ((uintptr_t)dOut % 16 || (uintptr_t)out % 16 || ldo % 4 || ldout % 4 || (VC && ((uintptr_t)VC % 16 || ldv % 4)))
+        return pgcn_set_error2(PGCN_EUNSUPPORTED, who, "rows must be 16-byte pieces");
+    hipLaunchKernelGGL(gat_row_dots_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dOut, ldo, out, ldout, VC,
+                       ldv, n, heads, d, t, ds1);
+    PGCN_HIP_CHECK(hipGetLastError());
+    return PGCN_OK;
+}
+
 extern "C" int pgcn_csr_row_sums_f32(const int64_t *rowptr, const int64_t *perm, int64_t nrows, int64_t nnz,
                                      const int32_t *rows_wave, int64_t nrows_wave, const int32_t *rows_block,
                                      int64_t nrows_block, const float *src, int32_t planes, float *out, int64_t ldo,

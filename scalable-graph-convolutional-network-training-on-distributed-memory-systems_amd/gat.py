@@ -237,21 +237,27 @@ class GatEngine(BoundaryExchange):
         return out
 
     # -- backward --------------------------------------------------------
-    def backward(self, st: GatLayerState, dOut: torch.Tensor):
-        """Returns (dZ, ds1, ds2) for the owned rows."""
+    def backward(self, st: GatLayerState, dOut: torch.Tensor, pack: Optional[torch.Tensor] = None):
+        """Returns (dZ, ds1, ds2) for the owned rows; with ``pack`` (n_local x (F + 2K)) they are written there as
+        [dZ | ds2 | ds1] instead (the gradient of PGAT's packed projection [Z | s2 | s1]) and ``pack`` is returned."""
         K, d = st.heads, st.d
         F = K * d
         n_p, n_h = self.n_local, self.n_halo
         Fp = st.Zc.shape[1]
         dOut = dOut.contiguous()
-        t = (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
+        dots = None
+        if hasattr(self.k, "gat_row_dots") and dOut.stride(1) == 1 and st.out.stride(1) == 1:
+            # t and (fused forward) ds1 in ONE pass over dOut, out and V (r05) instead of four element-wise / reduction launches
+            dots = self.k.gat_row_dots(dOut, st.out, st.V if st.fused else None, K, d)
+        t = dots[0] if dots is not None else (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
         dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
         if st.fused:
             # one gather pass: dZc = A_alpha^T . dOut and ds2 = the row sums of the edge gradient, which is not stored:
             # ds1 = its column sums = <dOut_i, V_i> - t_i C_i from the forward pass's second accumulator
             if self.k.spmm_heads_grad(self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, st.Zc, t, dZc, None, K, d):
-                ds1 = (dOut.view(n_p, K, d) * st.V[:, :F].view(n_p, K, d)).sum(-1) - t * st.V[:, F:F + K]
-                return self._finish_backward(st, dOut, dZc, ds1)
+                ds1 = dots[1] if dots is not None and dots[1] is not None else \
+                    (dOut.view(n_p, K, d) * st.V[:, :F].view(n_p, K, d)).sum(-1) - t * st.V[:, F:F + K]
+                return self._finish_backward(st, dOut, dZc, ds1, pack)
             # the fused kernel refused operands its forward twin took (an alignment / stride of dOut or the work-space that
             # `covers` does not model): the unfused passes need the alpha planes the fused forward never wrote -- build them now
             self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,
@@ -265,7 +271,7 @@ class GatEngine(BoundaryExchange):
             if self.k.spmm_heads_grad(self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, st.Zc, t, dZc, de_t, K, d):
                 ds1 = torch.empty((n_p, K), dtype=torch.float32, device=self.device)
                 self.k.csr_row_sums(self.fwd, self.inv_perm, de_t, K, ds1)
-                return self._finish_backward(st, dOut, dZc, ds1)
+                return self._finish_backward(st, dOut, dZc, ds1, pack)
         de = self._scratch.get(("de", K))          # the edge gradient, ENTRY-major [nnz, K] (read once, through perm)
         if de is None:
             de = self._scratch[("de", K)] = torch.empty((max(self.nnz, 1), K), dtype=torch.float32, device=self.device)
@@ -299,9 +305,10 @@ class GatEngine(BoundaryExchange):
                 for k in range(K):
                     self.k.spmm(bwd_heads[k], dOut[:, k * d:(k + 1) * d], dZc[:, k * d:(k + 1) * d])
         self.k.csr_row_sums(self.bwd, self.perm, de, K, dZc[:, F:F + K])
-        return self._finish_backward(st, dOut, dZc, ds1)
+        return self._finish_backward(st, dOut, dZc, ds1, pack)
 
-    def _finish_backward(self, st: GatLayerState, dOut: torch.Tensor, dZc: torch.Tensor, ds1: torch.Tensor):
+    def _finish_backward(self, st: GatLayerState, dOut: torch.Tensor, dZc: torch.Tensor, ds1: torch.Tensor,
+                         pack: Optional[torch.Tensor] = None):
         """Halo rows of [dZ | ds2] back to their owners (added), then the owned rows."""
         K, d = st.heads, st.d
         F = K * d
@@ -315,12 +322,17 @@ class GatEngine(BoundaryExchange):
             for r in range(self.rounds):
                 waits[r]()
                 self.k.spmm(self.unpack[r], back, dZc[:n_p], accumulate=True)
-        dZ = dZc[:n_p, :F].clone()
-        ds2 = dZc[:n_p, F:F + K].clone()
+        if pack is not None:                                # one copy of [dZ | ds2] out of the slab + the K columns of ds1
+            pack[:, :F + K].copy_(dZc[:n_p, :F + K])
+            pack[:, F + K:F + 2 * K].copy_(ds1)
+            dZ, ds2 = pack[:, :F], None
+        else:
+            dZ = dZc[:n_p, :F].clone()
+            ds2 = dZc[:n_p, F:F + K].clone()
         if self.mode_id == 1:                               # every Z_j also feeds every row through beta_i
             g = self._allreduce((st.beta.view(n_p, K, 1) * dOut.view(n_p, K, d)).sum(0).reshape(F))
             dZ += g
-        return dZ, ds1, ds2
+        return pack if pack is not None else (dZ, ds1, ds2)
 
 
 class GatAggregate(torch.autograd.Function):
@@ -333,10 +345,45 @@ class GatAggregate(torch.autograd.Function):
                                "use a fresh state (GatEngine.new_layer_state) for a second forward")
         ctx.engine, ctx.state = engine, state
         state.busy = any(ctx.needs_input_grad)
-        return engine.forward(state, Z.contiguous(), s1, s2)
+        return engine.forward(state, Z, s1, s2)           # (Z may be a column slice: it is copied into the panel [Z | s2] anyway)
 
     @staticmethod
     def backward(ctx, grad_output):
         dZ, ds1, ds2 = ctx.engine.backward(ctx.state, grad_output)
         ctx.state.busy = False
         return None, None, dZ, ds1, ds2
+
+
+class GatAggregatePacked(torch.autograd.Function):
+    """The same aggregation on the PACKED projection ZS = [Z | s2 | s1] (n x (F + 2K)): PGAT computes Z and both attention
+    projections as ONE product H . [W^T | W^T a2 | W^T a1] (r05: the two per-head `einsum`s of PGAT.py:141-142 ran as skinny
+    batched GEMMs of 1.09 ms each at the benchmark shape).  One gradient comes back, written in place as [dZ | ds2 | ds1]."""
+
+    @staticmethod
+    def forward(ctx, engine: GatEngine, state: GatLayerState, ZS):
+        if state.busy:
+            raise RuntimeError("GAT layer state is still owned by a forward whose backward has not run; "
+                               "use a fresh state (GatEngine.new_layer_state) for a second forward")
+        K, F = state.heads, state.heads * state.d
+        if ZS.dim() != 2 or ZS.shape[1] != F + 2 * K:
+            raise ValueError("packed projection must be n x (F + 2K)")
+        ctx.engine, ctx.state = engine, state
+        state.busy = any(ctx.needs_input_grad)
+        return engine.forward(state, ZS[:, :F], ZS[:, F + K:F + 2 * K], ZS[:, F:F + K])
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        st = ctx.state
+        K, F = st.heads, st.heads * st.d
+        pack = torch.empty((grad_output.shape[0], F + 2 * K), dtype=torch.float32, device=grad_output.device)
+        out = ctx.engine.backward(st, grad_output, pack) if _takes_pack(ctx.engine) else None
+        if out is None:
+            dZ, ds1, ds2 = ctx.engine.backward(st, grad_output)
+            pack[:, :F].copy_(dZ); pack[:, F:F + K].copy_(ds2); pack[:, F + K:].copy_(ds1)
+        st.busy = False
+        return None, None, pack
+
+
+def _takes_pack(engine) -> bool:
+    import inspect
+    return "pack" in inspect.signature(engine.backward).parameters

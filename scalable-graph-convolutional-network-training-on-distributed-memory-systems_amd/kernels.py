@@ -786,6 +786,19 @@ class HipKernels:
         _lib.check(rc, "pgcn_gat_edge_grad_tasks_f32")
         return True
 
+    def gat_row_dots(self, dOut: torch.Tensor, out: torch.Tensor, VC: Optional[torch.Tensor], heads: int, d: int):
+        """(t, ds1) of the GAT backward in one pass (pgcn_gat_row_dots_f32); ds1 is None without VC; None when the kernel does not
+        take the shapes (the caller keeps its tensor expressions)."""
+        n = dOut.shape[0]
+        t = torch.empty((n, heads), dtype=torch.float32, device=self.device)
+        ds1 = torch.empty((n, heads), dtype=torch.float32, device=self.device) if VC is not None else None
+        rc = self.lib.pgcn_gat_row_dots_f32(dOut.data_ptr(), dOut.stride(0), out.data_ptr(), out.stride(0), _ptr(VC),
+                                            VC.stride(0) if VC is not None else 0, n, heads, d, t.data_ptr(), _ptr(ds1), self._stream())
+        if rc == _lib.PGCN_EUNSUPPORTED:
+            return None
+        _lib.check(rc, "pgcn_gat_row_dots_f32")
+        return t, ds1
+
     def csr_row_sums(self, A: DeviceCSR, perm: Optional[torch.Tensor], src: torch.Tensor, planes: int,
                      out: torch.Tensor) -> None:
         self._check_rows(out, A.nrows, planes, "out")

@@ -721,3 +721,30 @@ def test_full_size_gat_shard_rank_of_four(K, dev):
         scale = max(float(accZ.abs().max()), 1e-12)
         assert float((got[:F].double().view(heads, d) - accZ).abs().max()) < 2e-5 * scale + 1e-7, j
         assert float((got[F:F + heads].double() - accS).abs().max()) < 5e-5 * max(float(accS.abs().max()), magS) + 1e-7, j
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,K,d", [(1000, 4, 64), (777, 1, 256), (513, 8, 32), (64, 2, 64), (5, 4, 32)])
+def test_row_dots_of_the_backward(n, K, d):
+    """pgcn_gat_row_dots_f32 (r05): t = <dOut, out> per row and head, ds1 = <dOut, V> - t C, one pass instead of the tensor expressions
+    gat.GatEngine.backward used to launch; against those expressions in float64."""
+    kernels = pkg("kernels")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    k = kernels.HipKernels(dev)
+    g0 = torch.Generator().manual_seed(n + K)
+    F = K * d
+    dOut, out = torch.randn(n, F, generator=g0).to(dev), torch.randn(n, F, generator=g0).to(dev)
+    VC = torch.randn(n, F + (K + 3) // 4 * 4, generator=g0).to(dev)
+    got = k.gat_row_dots(dOut, out, VC, K, d)
+    assert got is not None
+    t, ds1 = got
+    wt = (dOut.double().view(n, K, d) * out.double().view(n, K, d)).sum(-1)
+    wd = (dOut.double().view(n, K, d) * VC[:, :F].double().view(n, K, d)).sum(-1) - wt * VC[:, F:F + K].double()
+    scale_t = (dOut.double().abs().view(n, K, d) * out.double().abs().view(n, K, d)).sum(-1)
+    scale_d = (dOut.double().abs().view(n, K, d) * VC[:, :F].double().abs().view(n, K, d)).sum(-1) + (wt * VC[:, F:F + K].double()).abs()
+    assert float(((t.double() - wt).abs() / scale_t).max()) < 1e-6
+    assert float(((ds1.double() - wd).abs() / scale_d).max()) < 1e-6
+    t2, none = k.gat_row_dots(dOut, out, None, K, d)
+    assert none is None and torch.equal(t2, t)
+    assert k.gat_row_dots(dOut[:, :F - 4], out[:, :F - 4], None, K, d - 1) is None      # a head width the kernel does not take
