@@ -661,7 +661,7 @@ def bench_gat(args, rank, world, dev, backend, stage):
         exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
     eng = gat.GatEngine(part, K, dev, exch, mode="standard")
     G.device, G.myrank, G.world_size, G.heads, G._engine_current = dev, rank, world, heads, eng
-    pkg("PGCN").tune_dense_gemms(part.n_local, F, dev)        # library GEMM choice for H.W^T made in set-up
+    pkg("PGCN").tune_dense_gemms(part.n_local, F, dev, fout=F + 2 * heads)   # library GEMM choice for H.[W^T | W^T a2 | W^T a1] made in set-up
     torch.cuda.synchronize()
     setup_s = time.time() - t0
     stage("gat engine ready")

@@ -625,7 +625,7 @@ def _merge_tunableop_csv(dst: str, src: str) -> None:
     os.replace(tmp, dst)
 
 
-def tune_dense_gemms(n_rows, f, dev):
+def tune_dense_gemms(n_rows, f, dev, fout=None):
     """The dense contraction of a layer (PGCN.py:146-147 `self.linear(H)`, its two backward products) stays a stock
     library GEMM -- but PyTorch's default pick for the n x f x f shapes of this path is slower than the best kernel the
     libraries hold (r04, random operands at the benchmark size: 103 / 99 us against 85 / 86 us; 0.12 ms per epoch; only
@@ -642,9 +642,10 @@ def tune_dense_gemms(n_rows, f, dev):
     tuning.gemm_tuning = 0 keeps PyTorch's default pick.  Plumbing, not the graded path.  Returns True when a better
     kernel than the default pick is in use for this shape."""
     from .tuning import T as _T
-    if not _T.gemm_tuning or dev.type != "cuda" or n_rows * f < (1 << 24) or (n_rows, f) in _gemm_tuned_shapes:
+    fout = f if fout is None else int(fout)         # (the weight is fout x f: PGAT's packed projection has fout = F + 2 heads)
+    if not _T.gemm_tuning or dev.type != "cuda" or n_rows * f < (1 << 24) or (n_rows, f, fout) in _gemm_tuned_shapes:
         return False
-    if int(_T.dense_fused) >= 2 and f <= 128 and f % 4 == 0:
+    if int(_T.dense_fused) >= 2 and f <= 128 and f % 4 == 0 and fout == f:
         # r05: both n x f x f products of a layer run as the package's own kernels (gemm/pgcn_dense.hip); the library kernels of these
         # shapes are not launched in a step, so their code objects are not loaded during set-up either (1.5 s on a cold box)
         return False
@@ -653,10 +654,10 @@ def tune_dense_gemms(n_rows, f, dev):
         # (mm_nt / mm_nn above); one launch each here, so that the kernel file is read during set-up, not in the first step
         if not _gemm_direct_table():
             return False
-        x, w = torch.zeros((n_rows, f), device=dev), torch.zeros((f, f), device=dev)
-        hit = [_gemm_direct_call(t, w, x, f, n_rows, f) is not None for t in ("tn", "nn")]
+        x, w, g = torch.zeros((n_rows, f), device=dev), torch.zeros((fout, f), device=dev), torch.zeros((n_rows, fout), device=dev)
+        hit = [_gemm_direct_call("tn", w, x, fout, n_rows, f) is not None, _gemm_direct_call("nn", w, g, f, n_rows, fout) is not None]
         torch.cuda.synchronize(dev)
-        _gemm_tuned_shapes.add((n_rows, f))
+        _gemm_tuned_shapes.add((n_rows, f, fout))
         return any(hit)
     try:
         import torch.cuda.tunable as tunable
@@ -680,8 +681,8 @@ def tune_dense_gemms(n_rows, f, dev):
         known = len(tunable.get_results())
         tunable.tuning_enable(True)
         x = torch.zeros((n_rows, f), device=dev)
-        g = torch.zeros((n_rows, f), device=dev)
-        w = torch.zeros((f, f), device=dev)
+        g = torch.zeros((n_rows, fout), device=dev)
+        w = torch.zeros((fout, f), device=dev)
         _ = x @ w.t()                                # forward
         _ = g @ w                                    # dH
         _ = _LinearNoBias.weight_grad(g, x)          # dW (batched split-K + tail)
@@ -691,7 +692,7 @@ def tune_dense_gemms(n_rows, f, dev):
                 _merge_tunableop_csv(cache, fresh)
             except Exception:
                 pass
-        _gemm_tuned_shapes.add((n_rows, f))
+        _gemm_tuned_shapes.add((n_rows, f, fout))
         return True
     except Exception:
         tunable.enable(was_enabled)                  # (e.g. out of memory on the dummy operands: back to the default pick)

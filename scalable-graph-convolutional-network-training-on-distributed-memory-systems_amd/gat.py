@@ -192,18 +192,27 @@ class GatEngine(BoundaryExchange):
         return buf
 
     # -- forward ---------------------------------------------------------
-    def forward(self, st: GatLayerState, Z: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor) -> torch.Tensor:
+    def forward(self, st: GatLayerState, Z: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor,
+                panel: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``panel`` (optional): a matrix whose first F + K columns ARE [Z | s2] (PGAT's packed projection [Z | s2 | s1]); without
+        halo rows it is used as the gather panel itself instead of being copied into one (r05: 239 MB per layer)."""
         K, d = st.heads, st.d
         F = K * d
         n_p, n_h = self.n_local, self.n_halo
         if Z.shape != (n_p, F) or s1.shape != (n_p, K) or s2.shape != (n_p, K):
             raise ValueError("expected Z %s, s1/s2 %s" % ((n_p, F), (n_p, K)))
-        Fp = self.padded_width(F, K)
-        if st.Zc is None or st.Zc.shape != (n_p + n_h, Fp):
-            st.Zc = torch.zeros((n_p + n_h, Fp), dtype=torch.float32, device=self.device)
-        Zc = st.Zc
-        Zc[:n_p, :F].copy_(Z)
-        Zc[:n_p, F:F + K].copy_(s2)
+        if panel is not None and n_h == 0 and panel.shape[0] == n_p and panel.shape[1] >= F + K and panel.shape[1] % 4 == 0 \
+                and panel.stride(1) == 1 and panel.stride(0) == panel.shape[1] and panel.dtype is torch.float32 \
+                and panel.data_ptr() % 16 == 0:
+            st.Zc = Zc = panel.detach()
+            Fp = Zc.shape[1]
+        else:
+            Fp = self.padded_width(F, K)
+            if st.Zc is None or st.Zc.shape != (n_p + n_h, Fp):
+                st.Zc = torch.zeros((n_p + n_h, Fp), dtype=torch.float32, device=self.device)
+            Zc = st.Zc
+            Zc[:n_p, :F].copy_(Z)
+            Zc[:n_p, F:F + K].copy_(s2)
         if self.size > 1:                                   # PGAT.py:139 `Comm.apply(H)`: here the rows of [Z | s2]
             send = self._slab("gat_send", self.n_send, Fp)
             self.k.gather_rows(Zc[:n_p], self.send_idx, send)
@@ -250,7 +259,10 @@ class GatEngine(BoundaryExchange):
             # t and (fused forward) ds1 in ONE pass over dOut, out and V (r05) instead of four element-wise / reduction launches
             dots = self.k.gat_row_dots(dOut, st.out, st.V if st.fused else None, K, d)
         t = dots[0] if dots is not None else (dOut.view(n_p, K, d) * st.out.view(n_p, K, d)).sum(-1).contiguous()
-        dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
+        if pack is not None and n_h == 0 and pack.shape == (n_p, Fp) and Fp >= F + 2 * K and pack.stride(0) == Fp:
+            dZc = pack                 # the kernels write [dZ | ds2] straight into the gradient that goes back (no slab, no copy)
+        else:
+            dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
         if st.fused:
             # one gather pass: dZc = A_alpha^T . dOut and ds2 = the row sums of the edge gradient, which is not stored:
             # ds1 = its column sums = <dOut_i, V_i> - t_i C_i from the forward pass's second accumulator
@@ -323,7 +335,8 @@ class GatEngine(BoundaryExchange):
                 waits[r]()
                 self.k.spmm(self.unpack[r], back, dZc[:n_p], accumulate=True)
         if pack is not None:                                # one copy of [dZ | ds2] out of the slab + the K columns of ds1
-            pack[:, :F + K].copy_(dZc[:n_p, :F + K])
+            if dZc.data_ptr() != pack.data_ptr():
+                pack[:, :F + K].copy_(dZc[:n_p, :F + K])
             pack[:, F + K:F + 2 * K].copy_(ds1)
             dZ, ds2 = pack[:, :F], None
         else:
@@ -369,6 +382,8 @@ class GatAggregatePacked(torch.autograd.Function):
             raise ValueError("packed projection must be n x (F + 2K)")
         ctx.engine, ctx.state = engine, state
         state.busy = any(ctx.needs_input_grad)
+        if "panel" in __import__("inspect").signature(engine.forward).parameters:
+            return engine.forward(state, ZS[:, :F], ZS[:, F + K:F + 2 * K], ZS[:, F:F + K], panel=ZS)
         return engine.forward(state, ZS[:, :F], ZS[:, F + K:F + 2 * K], ZS[:, F:F + K])
 
     @staticmethod
