@@ -155,6 +155,33 @@ __global__ __launch_bounds__(kThreads) void gat_softmax_heads_kernel(
             r[k] = MODE == 0 ? (x > 0.f ? x : x * slope) : x;
         }
     };
+    if (!alpha) {
+        // statistics only (r05): ONE pass over the row -- every lane keeps a running maximum and the sum of exponentials relative
+        // to it (rescaled when the maximum moves), the lanes' pairs are merged at the end: half the column reads and s2 gathers of
+        // the max-then-sum passes below, the same maximum, the sum to fp32 rounding.  Fixed order: deterministic.
+        auto push = [&](float &mk, float &sk, float r) {
+            const float hi = fmaxf(mk, r), e1 = expf(fminf(mk, r) - hi);       // exp(-|r - m|); exp(-inf) = 0 on the first entry
+            sk = r > mk ? sk * e1 + 1.f : sk + e1;
+            mk = hi;
+        };
+        for (int64_t p = b + lane; p < e; p += 2 * TPR) {
+            float r0[KH], r1[KH];
+            const bool two = p + TPR < e;
+            scores(p, r0);
+            scores(two ? p + TPR : p, r1);
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                push(m[k], sum[k], r0[k]);
+                if (two) push(m[k], sum[k], r1[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            const float ml = m[k];
+            m[k] = group_reduce<TPR, true>(ml, red);
+            sum[k] = (ml == -INFINITY || sum[k] == 0.f) ? 0.f : sum[k] * expf(ml - m[k]);   // a lane without entries adds nothing
+        }
+    } else {
     for (int64_t p = b + lane; p < e; p += 2 * TPR) {
         float r0[KH], r1[KH];
         const bool two = p + TPR < e;
@@ -172,6 +199,7 @@ __global__ __launch_bounds__(kThreads) void gat_softmax_heads_kernel(
         scores(two ? p + TPR : p, r1);
 #pragma unroll
         for (int k = 0; k < KH; ++k) sum[k] += expf(r0[k] - m[k]) + (two ? expf(r1[k] - m[k]) : 0.f);
+    }
     }
     float em[KH], inv[KH];
 #pragma unroll

@@ -586,7 +586,9 @@ def test_forward_product_with_recomputed_weights_and_second_accumulator(K, dev, 
     K.gat_edge_softmax(dA, s1, s2, heads, 0.2, mode_id, 1000, alpha, beta, rowstat)
     beta2, rowstat2 = torch.zeros_like(beta), torch.empty_like(rowstat)
     K.gat_edge_softmax(dA, s1, s2, heads, 0.2, mode_id, 1000, None, beta2, rowstat2)     # statistics only
-    assert torch.equal(rowstat, rowstat2) and torch.equal(beta, beta2)
+    # (r05: statistics-only runs ONE online pass -- same s1, maximum and exp(-m) exactly, the sum of exponentials to fp32 rounding)
+    assert torch.equal(rowstat[..., :2], rowstat2[..., :2]) and torch.equal(rowstat[..., 3], rowstat2[..., 3])
+    assert torch.allclose(rowstat[..., 2], rowstat2[..., 2], rtol=3e-6, atol=0) and torch.allclose(beta, beta2, rtol=3e-6, atol=0)
     if mode == "standard":
         beta.zero_()
     ref = torch.full((n, F), float("nan"), device=dev)
