@@ -62,6 +62,7 @@ def test_bench_single_gpu_line_small_workload():
     assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["value"] > 0
     assert rec["roofline"] and rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
     assert rec["cpu_baseline"] and rec["cpu_baseline"]["value"] > 0
+    assert rec["config"]["timed_region"].startswith("3 eagerly launched") and "graph_replay" not in rec    # (N = 1: --graph auto is off)
     assert np.isfinite(rec["loss"])
 
 
@@ -77,6 +78,10 @@ def test_bench_self_launch_n_ranks_share_the_gpu(N):
     rec = _json_line(out.stdout)
     assert rec["n_gpus"] == N and rec["value"] > 0 and rec["scaling"] == "strong"
     assert rec["config"]["partition"] != "none" and rec["exchange_rows_total"] > 0
+    # N > 1: the graph replay is attempted automatically (r05); over gloo the exchange stages through the host and cannot be
+    # captured, so every rank agrees not to replay and the eager steps stay the line's value
+    assert "graph_replay" in rec and (rec["graph_replay"].get("captured") is False or "eager" in rec)
+    assert ("eager" in rec) == rec["config"]["timed_region"].startswith("3 replays")
     assert np.isfinite(rec["loss"])
 
 
