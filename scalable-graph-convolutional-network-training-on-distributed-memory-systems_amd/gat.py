@@ -38,6 +38,12 @@ from .partition import HostCSR, Partition, csr_from_coo, pick_nslices
 from .tuning import T as _T
 
 LONG_ROW = _T.gat_long_row   # rows above this get a 256-thread workgroup
+# The gather plan of the attention structures (r05).  A partial row here is heads x d = 1 KB wide, twice the GCN path's, and every
+# task of a split row leaves one: rows are sliced over the XCDs from 193 entries on (GCN: 97) and long rows are cut into pieces of
+# 4 096 entries (GCN: 1 024).  Reddit shape, 4 heads x 64, ms per epoch: 96 / 1 024 58.7; 192 / 1 024 55.5; 384 / 1 024 56.4;
+# 128 / 2 048 55.6; 192 / 2 048 54.2; 256 / 2 048 54.2; 192 / 4 096 53.2; 256 / 4 096 53.2 (tools/probes_r05/p20_gat_plan.sh).
+GAT_SMALL_ROW = 192
+GAT_CHUNK = 4096
 MODES = {"standard": 0, "reference": 1}
 
 
@@ -134,8 +140,17 @@ class GatEngine(BoundaryExchange):
         g = build_gat_graph(part, positive_only=(mode == "reference"), long_row=long_row)
         self.graph = g
         self.nnz = g.nnz
-        self.fwd = kernels.prepare_gat(g.fwd, g.fwd_wave, g.fwd_block)
-        self.bwd = kernels.prepare_gat(g.bwd, g.bwd_wave, g.bwd_block)
+        plan = {k: getattr(kernels, k) for k in ("chunk", "small_row") if hasattr(kernels, k)}
+        try:                                   # (the provider's plan parameters are the GCN path's: the attention structures get their own)
+            if "chunk" in plan:
+                kernels.chunk = max(kernels.chunk, GAT_CHUNK)
+            if "small_row" in plan:
+                kernels.small_row = max(kernels.small_row, GAT_SMALL_ROW)
+            self.fwd = kernels.prepare_gat(g.fwd, g.fwd_wave, g.fwd_block)
+            self.bwd = kernels.prepare_gat(g.bwd, g.bwd_wave, g.bwd_block)
+        finally:
+            for k, v in plan.items():
+                setattr(kernels, k, v)
         self.perm = g.perm.to(self.device)
         self._inv_perm = None              # forward entry -> its position in the transposed structure (built on demand)
         self._scratch = {}
