@@ -40,10 +40,11 @@ from .tuning import T as _T
 LONG_ROW = _T.gat_long_row   # rows above this get a 256-thread workgroup
 # The gather plan of the attention structures (r05).  A partial row here is heads x d = 1 KB wide, twice the GCN path's, and every
 # task of a split row leaves one: rows are sliced over the XCDs from 193 entries on (GCN: 97) and long rows are cut into pieces of
-# 4 096 entries (GCN: 1 024).  Reddit shape, 4 heads x 64, ms per epoch: 96 / 1 024 58.7; 192 / 1 024 55.5; 384 / 1 024 56.4;
-# 128 / 2 048 55.6; 192 / 2 048 54.2; 256 / 2 048 54.2; 192 / 4 096 53.2; 256 / 4 096 53.2 (tools/probes_r05/p20_gat_plan.sh).
+# 8 192 entries (GCN: 1 024).  Reddit shape, 4 heads x 64, ms per epoch: 96 / 1 024 58.7; 192 / 1 024 55.5; 384 / 1 024 56.4;
+# 128 / 2 048 55.6; 192 / 2 048 54.2; 256 / 2 048 54.2; 192 / 4 096 53.2; 256 / 4 096 53.2; 192 / 8 192 52.8; 192 / 16 384 52.8;
+# 320 / 8 192 52.9 (tools/probes_r05/p20_gat_plan.sh; tuning.gat_long_row 256 / 4 096: no change).
 GAT_SMALL_ROW = 192
-GAT_CHUNK = 4096
+GAT_CHUNK = 8192
 MODES = {"standard": 0, "reference": 1}
 
 
