@@ -82,65 +82,6 @@ class KernelTimer:
         return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
 
 
-class DeferredTimer:
-    """tuning.layer_fused: the aggregation's PRODUCERS run through HipKernels.spmm_deferred and its fix-up inside the consumer
-    (PGCN.fixup_linear_call -> pgcn_fixup_linear_f32).  HIP events around both, on the launch stream, inside the timed region; what
-    the fix-up costs inside the consumer is charged to the launch group as (consumer - the plain product kernel on a finished
-    operand of the same shape), the latter timed after the region."""
-
-    def __init__(self, kernels, P, device):
-        self.k, self.P, self.device, self.on = kernels, P, device, False
-        self.produce, self.consume = [], []
-        self._deferred = getattr(kernels, "spmm_deferred", None)
-        if self._deferred is not None:
-            kernels.spmm_deferred = self.spmm_deferred
-        self._consumer = P.fixup_linear_call
-        P.fixup_linear_call = self.fixup_linear_call
-
-    def _timed(self, fn, store, tag, *a):
-        if not self.on:
-            return fn(*a)
-        s = torch.cuda.current_stream(self.device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(s)
-        out = fn(*a)
-        e1.record(s)
-        if out is not None:
-            store.append(tag + (e0, e1))
-        return out
-
-    def spmm_deferred(self, A, B, C):
-        return self._timed(self._deferred, self.produce, (id(A), B.shape[1]), A, B, C)
-
-    def fixup_linear_call(self, L, row_fix, slot_ids, ws, base, f, weight, transposed, *rest):
-        return self._timed(self._consumer, self.consume, (bool(transposed), f), L, row_fix, slot_ids, ws, base, f, weight, transposed, *rest)
-
-    def producers_ms(self, key_id, f):
-        ts = [e0.elapsed_time(e1) for (i, ff, e0, e1) in self.produce if i == key_id and ff == f]
-        return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
-
-    def consumer_ms(self, transposed, f):
-        ts = [e0.elapsed_time(e1) for (t, ff, e0, e1) in self.consume if t == transposed and ff == f]
-        return sum(ts) / len(ts) if ts else None
-
-    def plain_product_ms(self, n, f, transposed, reps=7):
-        """The product kernel alone on a finished n x f operand (what the consumer would cost without the folded fix-up)."""
-        P, dev = self.P, self.device
-        x, w = torch.rand((n, f), device=dev), torch.rand((f, f), device=dev)
-        L, st = P._dense_lib(), P._dense_stream(x)
-        ts = []
-        for _ in range(reps + 2):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = P.linear_relu_call(L, x, w, True, st) if transposed else P.linear_epilogue_call(L, x, w, False, P.EPI_MASK, x, st)
-            e1.record()
-            torch.cuda.synchronize()
-            if y is None:
-                return None
-            ts.append(e0.elapsed_time(e1))
-        return float(np.median(ts[2:]))
-
-
 def kernel_source_stamp():
     """sha256 over the kernel sources and the layout code: what a PMC traffic figure is valid for."""
     import glob
@@ -900,7 +841,6 @@ def main():
         return loss
 
     timer = KernelTimer(K, dev)
-    dtimer = DeferredTimer(K, P, dev)
     for _ in range(args.warmup):
         loss = step()
         stage("warm-up step done")
@@ -908,7 +848,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.on = dtimer.on = not args.no_kernel_timing
+    timer.on = not args.no_kernel_timing
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -917,7 +857,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.on = dtimer.on = False
+    timer.on = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         P._all_reduce(t, dist.ReduceOp.MAX)
@@ -932,22 +872,6 @@ def main():
     # ---- roofline of the dominant kernel (local-block forward SpMM) -----------------
     roofline = None
     avg_ms, launches = timer.summary(id(eng.A_loc), f)
-    folded = None
-    if not avg_ms:          # tuning.layer_fused: producers through spmm_deferred, the fix-up inside the consumer
-        prod_ms, launches = dtimer.producers_ms(id(eng.A_loc), f)
-        if prod_ms:
-            cons_ms, plain_ms = dtimer.consumer_ms(True, f), dtimer.plain_product_ms(part.n_local, f, True)
-            extra = max(0.0, cons_ms - plain_ms) if (cons_ms and plain_ms) else None
-            if extra is not None:
-                avg_ms = prod_ms + extra
-                folded = {"producers_ms": prod_ms, "consumer_ms": cons_ms, "plain_product_ms": plain_ms, "fixup_share_ms": extra,
-                          "what": "the fix-up runs inside the dense product (pgcn_fixup_linear_f32): launch group = producers + "
-                                  "(consumer - the product kernel alone on a finished operand, timed after the region)"}
-                bprod, _ = dtimer.producers_ms(id(eng.A_loc_T), f)
-                bcons, bplain = dtimer.consumer_ms(False, f), dtimer.plain_product_ms(part.n_local, f, False)
-                if bprod and bcons and bplain:
-                    folded["backward_AT"] = {"producers_ms": bprod, "consumer_ms": bcons, "plain_product_ms": bplain,
-                                             "fixup_share_ms": max(0.0, bcons - bplain)}
     if avg_ms:
         alg = eng.A_loc.alg_bytes(f)
         achieved = alg / (avg_ms * 1e-3)
@@ -963,13 +887,10 @@ def main():
         if eng.A_loc.core is not None:
             kname += " + spmm_core_kernel<4> (LDS-tiled dense core, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.core.nnz / max(eng.A_loc.nnz, 1))
-        if getattr(eng.A_loc, "dense", None) is not None:
-            kname += " + spmm_dense_kernel<4> (fp32-MFMA tiles, %.0f%% of the entries)" % (
-                100.0 * eng.A_loc.dense.nnz / max(eng.A_loc.nnz, 1))
         if getattr(eng.A_loc, "dense3", None) is not None:
             kname += " + spmm_split_panels_kernel + spmm_dense3_kernel<4> (512x128 blocks on the bf16 matrix cores, three-plane split at fp32 accuracy, %.0f%% of the entries)" % (
                 100.0 * eng.A_loc.dense3.nnz / max(eng.A_loc.nnz, 1))
-        fx = "the fix-up folded into the dense product that consumes A.H (its share timed inside that kernel)" if folded else "fix-up"
+        fx = "fix-up"
         if partition._T.lanes and eng.A_loc.nnz >= partition._T.lanes_min_nnz and "/" in partition._T.lanes:
             kname += " + %s; one launch group on two streams (lanes %s), timed as a whole" % (fx, partition._T.lanes)
         else:
@@ -984,10 +905,6 @@ def main():
         bavg, bl = timer.summary(id(eng.A_loc_T), f)
         if bavg:
             roofline["avg_launch_ms_backward_AT"] = bavg
-        if folded:
-            roofline["fixup_folded_into_consumer"] = folded
-            if "backward_AT" in folded:
-                roofline["avg_launch_ms_backward_AT"] = folded["backward_AT"]["producers_ms"] + folded["backward_AT"]["fixup_share_ms"]
         # per-kernel split of the launch group: a few extra forward launches OUTSIDE the timed region
         real_lib, real_lane = K.lib, K.single_lane
         try:
@@ -1039,7 +956,6 @@ def main():
                    "exchange": exch.name if exch else "none",
                    "xcd_slices": eng.A_loc.nslices, "chunk": K.chunk,
                    "core_tile_fill_min": partition.CORE_TAU,
-                   "mfma_tile_fill_min": (partition.DENSE_TAU if partition.DENSE_ON and not partition.DENSE3_ON else None),
                    "bf16x3_block_fill_min": partition.DENSE3_TAU if partition.DENSE3_ON else None,
                    "exchange_rounds": part.rounds, "vertex_order": part.order_info,
                    "dense_gemm": ("x.W^T and g.W: the package's own matrix-core kernels (see dense_fused); dW = Gm^T.AH: PyTorch's batched "
@@ -1052,7 +968,6 @@ def main():
                                    1: "relu(x.W^T) by gemm/pgcn_dense.hip (bf16-split MFMA, fp32 accuracy)",
                                    2: "relu(x.W^T) and (g (.) mask).W by gemm/pgcn_dense.hip (bf16-split MFMA, fp32 accuracy)"
                                    }.get(int(partition._T.dense_fused), str(partition._T.dense_fused)),
-                   "layer_fused": bool(int(partition._T.layer_fused) and int(partition._T.dense_fused) >= 2),
                    "strip_tiles": {"min_entries": partition.STRIP_MIN, "layer_min": partition.STRIP_LAYER_MIN,
                                    "whole_graphs_from_nnz": partition._T.strip_big_nnz, "min_entries_big": partition._T.strip_min_big,
                                    "layer_min_big": partition._T.strip_layer_min_big}

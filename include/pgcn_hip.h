@@ -153,13 +153,12 @@ int pgcn_spmm_plan_host(const int64_t *rowptr_host, const int32_t *slice_cnt,
                         int32_t small_row, int32_t *tasks,
                         int64_t cap_tasks, int32_t *fix, int64_t cap_fix, int64_t *seg,
                         int64_t *ntasks, int64_t *nfix, int64_t *nslots);
-/* ... with rows of small_row < entries <= pair_row cut per PAIR of adjacent slices (nslices / 2 tasks, placed on the two
- * segments of the pair alternately by row): half the partial rows for such rows.  pair_row = 0: exactly pgcn_spmm_plan_host. */
-#define PGCN_PLAN_AFFINE_SMALL 0x40000000   /* OR-ed into pair_row: an unsliced row's task runs on the segment (XCD) of its fullest slice */
+/* ... with placement options.  plan_flags = 0: exactly pgcn_spmm_plan_host. */
+#define PGCN_PLAN_AFFINE_SMALL 0x40000000   /* plan_flags: an unsliced row's task runs on the segment (XCD) of its fullest slice */
 int pgcn_spmm_plan_host_ex(const int64_t *rowptr_host, const int32_t *slice_cnt,
                            const uint8_t *row_flags, int64_t nrows,
                            int32_t nslices, int32_t ngroups, int32_t group_min_row, int32_t chunk,
-                           int32_t small_row, int32_t pair_row, int32_t *tasks,
+                           int32_t small_row, int32_t plan_flags, int32_t *tasks,
                            int64_t cap_tasks, int32_t *fix, int64_t cap_fix, int64_t *seg,
                            int64_t *ntasks, int64_t *nfix, int64_t *nslots);
 
@@ -238,21 +237,6 @@ int pgcn_spmm_dense_bf16x3_f32(const int32_t *work, int64_t nwork, const int32_t
                                const int32_t *panel_list, int64_t npanels, const float *B, int64_t ldb, int64_t ncols,
                                int32_t f, void *image_ws, int64_t image_ws_bytes, float *partial_ws,
                                int64_t partial_ws_elems, int64_t nslots_total, pgcn_stream_t stream);
-
-/* The densest tiles through the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32, k-ordered
- * fmaf chains).  A tile is stored dense, pre-swizzled into the A-operand order:
- *   vals[tile][w][s4][lane][e] = A[32 w + (lane & 31)][2 (4 s4 + e) + (lane >> 5)]   (16 384 fp32 per tile)
- * work: 4 x int32 per piece {tile row, first tile, number of tiles, first slot}; a piece leaves a
- * 128 x f block of partial sums in partial_ws (slot rows of f floats) for pgcn_spmm_fixup_f32.
- * tile_panel[t]: the tile multiplies B rows [128 p, 128 p + 128) (rows >= ncols read as zero).
- * Zeros of a dense tile are structural: a panel holding Inf / NaN takes an exact (slow) path that
- * multiplies only where A != 0.  Any f (128 feature columns per workgroup); the panel is staged with
- * 16-byte loads when f % 4 == 0, ldb % 4 == 0 and B is 16-byte aligned, scalar loads otherwise.   */
-int pgcn_spmm_dense_f32(const int32_t *work, int64_t nwork, const int32_t *tile_panel,
-                        const float *vals, const float *B, int64_t ldb, int64_t ncols, int32_t f,
-                        float *partial_ws, int64_t partial_ws_elems, int64_t nslots_total,
-                        pgcn_stream_t stream);
-
 
 /* C[row] (+)= sum of the partial-sum slots listed for the row, in list order.
  * fix: 4 x int32 per row {row, begin, count, 0}; slot_ids (optional): the row's slots are

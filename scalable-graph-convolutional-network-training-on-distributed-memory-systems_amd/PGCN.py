@@ -33,7 +33,6 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.utils.weak import WeakIdKeyDictionary
 
 from . import engine as _engine
 from . import ingest as _ingest
@@ -301,14 +300,18 @@ def bind_dense_library(path):
     L = ctypes.CDLL(path)
     i32, i64, ptr = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
     L.pgcn_linear_relu_f32.restype = ctypes.c_int
-    L.pgcn_linear_relu_f32.argtypes = [ptr, i64, i64, i32, ptr, i64, i32, ptr, i64, i32, ptr]
+    L.pgcn_linear_relu_f32.argtypes = [ptr, i64, i64, i32, ptr, i64, i32, ptr, i64, i32, ptr, ptr]
     L.pgcn_linear_relu_grad_input_f32.restype = ctypes.c_int
-    L.pgcn_linear_relu_grad_input_f32.argtypes = [ptr, i64, ptr, i64, ptr, i64, i64, i32, ptr, i64, i32, ptr, i64, ptr]
+    L.pgcn_linear_relu_grad_input_f32.argtypes = [ptr, i64, ptr, ptr, i64, i64, i32, ptr, i64, i32, ptr, i64, ptr]
+    L.pgcn_sign_mask_f32.restype = ctypes.c_int
+    L.pgcn_sign_mask_f32.argtypes = [ptr, i64, i64, i32, ptr, ptr]
     L.pgcn_dense_last_error.restype = ctypes.c_char_p
-    L.pgcn_linear_epilogue_f32.restype = ctypes.c_int
-    L.pgcn_linear_epilogue_f32.argtypes = [ptr, i64, i64, i32, ptr, i64, i32, i32, i32, ptr, i64, ptr, i64, i32, ptr]
-    L.pgcn_fixup_linear_f32.restype = ctypes.c_int
-    L.pgcn_fixup_linear_f32.argtypes = [ptr, ptr, ptr, i64, ptr, i64, i64, i32, ptr, i64, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i32, ptr]
+    if hasattr(L, "pgcn_linear_weight_grad_f32"):          # (the host emulation has no weight-gradient entry point)
+        L.pgcn_linear_weight_grad_f32.restype = ctypes.c_int
+        L.pgcn_linear_weight_grad_f32.argtypes = [ptr, i64, ptr, i64, i64, i32, i32, ptr, i64, ptr, i64, ptr]
+        L.pgcn_linear_weight_grad_ws_elems.restype = ctypes.c_int64
+        L.pgcn_linear_weight_grad_ws_elems.argtypes = []
+        L.pgcn_wgrad_last_error.restype = ctypes.c_char_p
     return L
 
 
@@ -331,32 +334,60 @@ def _dense_stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def linear_relu_call(L, x, weight, relu, stream):
+def mask_words(width):
+    """int32 words per row of the sign mask of an n x width matrix (include/pgcn_gemm.h)."""
+    return (int(width) + 31) // 32
+
+
+def unpack_sign_mask(mask, width):
+    """bool [n, width] from the int32 sign-mask words (plain tensor ops: tests and the rare fall-back of the backward)."""
+    bits = (mask.to(torch.int64).unsqueeze(-1) >> torch.arange(32, device=mask.device)) & 1
+    return bits.reshape(mask.shape[0], -1)[:, :width].bool()
+
+
+def linear_relu_call(L, x, weight, relu, stream, want_mask=False):
     """[relu](x . weight^T) through pgcn_linear_relu_f32 of `L` on `stream`, or None when the entry point does not take the
-    operands (-2).  x: n x fin, weight: fout x fin, unit inner strides."""
+    operands (-2).  x: n x fin, weight: fout x fin, unit inner strides.  want_mask: returns (y, sign mask of y) -- n x
+    ceil(fout / 32) int32 words, bit b of word [row][w] = (y[row][32 w + b] > 0)."""
     if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1] or x.stride(1) != 1 or weight.stride(1) != 1 or \
             x.dtype is not torch.float32 or weight.dtype is not torch.float32:
         return None
     y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
+    mask = torch.empty((x.shape[0], mask_words(weight.shape[0])), dtype=torch.int32, device=x.device) if want_mask else None
     rc = L.pgcn_linear_relu_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], weight.data_ptr(), weight.stride(0),
-                                weight.shape[0], y.data_ptr(), y.stride(0), 1 if relu else 0, stream)
+                                weight.shape[0], y.data_ptr(), y.stride(0), 1 if relu else 0,
+                                mask.data_ptr() if want_mask else None, stream)
     if rc == -2:
         return None
     if rc != 0:
         raise RuntimeError("pgcn_linear_relu_f32: %s" % L.pgcn_dense_last_error().decode())
-    return y
+    return (y, mask) if want_mask else y
 
 
-def linear_relu_grad_input_call(L, g, y, weight, stream):
-    """(g (.) [y > 0], that . weight) through pgcn_linear_relu_grad_input_f32 of `L`, or None (-2).  g, y: n x fout,
-    weight: fout x fin."""
-    if g.dim() != 2 or g.shape != y.shape or weight.dim() != 2 or g.shape[1] != weight.shape[0] or \
-            g.stride(1) != 1 or y.stride(1) != 1 or weight.stride(1) != 1 or \
-            not (g.dtype is y.dtype is weight.dtype is torch.float32):
+def sign_mask_call(L, y, stream):
+    """The sign mask of an existing matrix y (pgcn_sign_mask_f32): what the input gradient takes instead of y."""
+    if y.dim() != 2 or y.stride(1) != 1 or y.dtype is not torch.float32:
         return None
-    gm = torch.empty_like(g, memory_format=torch.contiguous_format)
+    mask = torch.empty((y.shape[0], mask_words(y.shape[1])), dtype=torch.int32, device=y.device)
+    rc = L.pgcn_sign_mask_f32(y.data_ptr(), y.stride(0), y.shape[0], y.shape[1], mask.data_ptr(), stream)
+    if rc != 0:
+        raise RuntimeError("pgcn_sign_mask_f32: %s" % L.pgcn_dense_last_error().decode())
+    return mask
+
+
+def linear_relu_grad_input_call(L, g, mask, weight, stream, want_gm=True):
+    """(g where the mask says y > 0, that . weight) through pgcn_linear_relu_grad_input_f32 of `L`, or None (-2).  g: n x fout,
+    mask: the forward's sign mask (n x ceil(fout / 32) int32) or None (no mask), weight: fout x fin."""
+    if g.dim() != 2 or weight.dim() != 2 or g.shape[1] != weight.shape[0] or g.stride(1) != 1 or weight.stride(1) != 1 or \
+            not (g.dtype is weight.dtype is torch.float32):
+        return None
+    if mask is not None and (mask.shape != (g.shape[0], mask_words(g.shape[1])) or mask.dtype is not torch.int32 or
+                             not mask.is_contiguous()):
+        return None
+    gm = torch.empty_like(g, memory_format=torch.contiguous_format) if want_gm else None
     gx = torch.empty((g.shape[0], weight.shape[1]), dtype=torch.float32, device=g.device)
-    rc = L.pgcn_linear_relu_grad_input_f32(g.data_ptr(), g.stride(0), y.data_ptr(), y.stride(0), gm.data_ptr(), gm.stride(0),
+    rc = L.pgcn_linear_relu_grad_input_f32(g.data_ptr(), g.stride(0), mask.data_ptr() if mask is not None else None,
+                                           gm.data_ptr() if want_gm else None, gm.stride(0) if want_gm else 0,
                                            g.shape[0], g.shape[1], weight.data_ptr(), weight.stride(0), weight.shape[1],
                                            gx.data_ptr(), gx.stride(0), stream)
     if rc == -2:
@@ -366,68 +397,49 @@ def linear_relu_grad_input_call(L, g, y, weight, stream):
     return gm, gx
 
 
-EPI_NONE, EPI_RELU, EPI_MASK = 0, 1, 2
+_wgrad_ws = {}
 
 
-def linear_epilogue_call(L, x, weight, transposed, epilogue, mask, stream):
-    """epi(x . weight^T) (transposed) or epi(x . weight) through pgcn_linear_epilogue_f32 of `L`; epilogue EPI_MASK keeps the product
-    where ``mask`` > 0.  None when the entry point does not take the operands (-2)."""
-    k = x.shape[1]
-    if x.dim() != 2 or weight.dim() != 2 or (weight.shape[1] if transposed else weight.shape[0]) != k or x.stride(1) != 1 or \
-            weight.stride(1) != 1 or x.dtype is not torch.float32 or weight.dtype is not torch.float32:
+def weight_grad_call(L, gm, x, stream):
+    """gm^T . x (fout x fin) through pgcn_linear_weight_grad_f32 of `L`, or None (-2 / no such entry point).  gm: n x fout, x: n x fin."""
+    if not hasattr(L, "pgcn_linear_weight_grad_f32") or gm.dim() != 2 or x.dim() != 2 or gm.shape[0] != x.shape[0] or \
+            gm.stride(1) != 1 or x.stride(1) != 1 or not (gm.dtype is x.dtype is torch.float32):
         return None
-    n_out = weight.shape[0] if transposed else weight.shape[1]
-    if epilogue == EPI_MASK and (mask is None or mask.shape != (x.shape[0], n_out) or mask.stride(1) != 1 or mask.dtype is not torch.float32):
-        return None
-    y = torch.empty((x.shape[0], n_out), dtype=torch.float32, device=x.device)
-    rc = L.pgcn_linear_epilogue_f32(x.data_ptr(), x.stride(0), x.shape[0], k, weight.data_ptr(), weight.stride(0), weight.shape[0],
-                                    weight.shape[1], 1 if transposed else 0, mask.data_ptr() if epilogue == EPI_MASK else None,
-                                    mask.stride(0) if epilogue == EPI_MASK else 0, y.data_ptr(), y.stride(0), epilogue, stream)
+    key = (gm.device, stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None:        # one work-space per (device, stream): partial matrices of one product (64 MB; set-up, not a training step)
+        ws = _wgrad_ws[key] = torch.empty(int(L.pgcn_linear_weight_grad_ws_elems()), dtype=torch.float32, device=gm.device)
+    dw = torch.empty((gm.shape[1], x.shape[1]), dtype=torch.float32, device=gm.device)
+    rc = L.pgcn_linear_weight_grad_f32(gm.data_ptr(), gm.stride(0), x.data_ptr(), x.stride(0), gm.shape[0], gm.shape[1], x.shape[1],
+                                       dw.data_ptr(), dw.stride(0), ws.data_ptr(), ws.numel(), stream)
     if rc == -2:
         return None
     if rc != 0:
-        raise RuntimeError("pgcn_linear_epilogue_f32: %s" % L.pgcn_dense_last_error().decode())
-    return y
+        raise RuntimeError("pgcn_linear_weight_grad_f32: %s" % L.pgcn_wgrad_last_error().decode())
+    return dw
 
 
-def fixup_linear_call(L, row_fix, slot_ids, ws, base, f, weight, transposed, epilogue, mask, want_sum, stream):
-    """epi(S . weight^T | S . weight) with S = the ordered per-row sums of a deferred aggregation (kernels.DeferredSum: row_fix,
-    slot_ids, ws, base; rows f floats apart) through pgcn_fixup_linear_f32 of `L`.  Returns (product, S or None), or None (-2)."""
-    n = row_fix.shape[0]
-    if weight.dim() != 2 or (weight.shape[1] if transposed else weight.shape[0]) != f or weight.stride(1) != 1 or \
-            weight.dtype is not torch.float32 or base.shape != (n, f) or base.stride(1) != 1:
-        return None
-    n_out = weight.shape[0] if transposed else weight.shape[1]
-    if epilogue == EPI_MASK and (mask is None or mask.shape != (n, n_out) or mask.stride(1) != 1 or mask.dtype is not torch.float32):
-        return None
-    y = torch.empty((n, n_out), dtype=torch.float32, device=base.device)
-    S = torch.empty((n, f), dtype=torch.float32, device=base.device) if want_sum else None
-    rc = L.pgcn_fixup_linear_f32(row_fix.data_ptr(), slot_ids.data_ptr() if slot_ids is not None else None,
-                                 ws.data_ptr() if ws is not None else None, f, base.data_ptr(), base.stride(0), n, f, weight.data_ptr(),
-                                 weight.stride(0), weight.shape[0], weight.shape[1], 1 if transposed else 0,
-                                 S.data_ptr() if want_sum else None, f, mask.data_ptr() if epilogue == EPI_MASK else None,
-                                 mask.stride(0) if epilogue == EPI_MASK else 0, y.data_ptr(), y.stride(0), epilogue, stream)
-    if rc == -2:
-        return None
-    if rc != 0:
-        raise RuntimeError("pgcn_fixup_linear_f32: %s" % L.pgcn_dense_last_error().decode())
-    return y, S
-
-
-def linear_relu_fused(x, weight, relu=True):
+def linear_relu_fused(x, weight, relu=True, want_mask=False):
     """[relu](x . weight^T) (PGCN.py:146-147) by the package's matrix-core kernel on the current stream, or None when it
     does not take the operands (widths above 128, rows that are not 16-byte pieces, CPU tensors): the caller runs the
     library product."""
     if not _dense_operand_ok(x, weight):
         return None
-    return linear_relu_call(_dense_lib(), x, weight, relu, _dense_stream(x))
+    return linear_relu_call(_dense_lib(), x, weight, relu, _dense_stream(x), want_mask)
 
 
-def linear_relu_grad_input_fused(g, y, weight):
-    """(g (.) [y > 0], that . weight): the ReLU mask and the input gradient of relu(x . weight^T) in one pass, or None."""
-    if not _dense_operand_ok(g, y, weight):
+def linear_relu_grad_input_fused(g, mask, weight):
+    """(g where mask, that . weight): the ReLU mask and the input gradient of relu(x . weight^T) in one pass, or None."""
+    if not _dense_operand_ok(g, weight):
         return None
-    return linear_relu_grad_input_call(_dense_lib(), g, y, weight, _dense_stream(g))
+    return linear_relu_grad_input_call(_dense_lib(), g, mask, weight, _dense_stream(g))
+
+
+def weight_grad_fused(gm, x):
+    """gm^T . x by the package's matrix-core kernel (gemm/pgcn_wgrad.hip) on the current stream, or None."""
+    if not _dense_operand_ok(gm, x):
+        return None
+    return weight_grad_call(_dense_lib(), gm, x, _dense_stream(gm))
 
 
 def _dense_fused_level():
@@ -456,7 +468,9 @@ class _LinearNoBias(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = mm_nn(g, weight)
         if ctx.needs_input_grad[1]:
-            gw = _LinearNoBias.weight_grad(g, x)
+            gw = (weight_grad_fused(g.contiguous(), x) if _dense_fused_level() >= 3 else None)
+            if gw is None:
+                gw = _LinearNoBias.weight_grad(g, x)
         return gx, gw
 
     @staticmethod
@@ -472,113 +486,51 @@ class _LinearNoBias(torch.autograd.Function):
 
 
 class _LinearReluNoBias(torch.autograd.Function):
-    """relu(x . W^T) as one autograd node (PGCN.py:146-147): the ReLU is applied in place on the GEMM output and
-    its backward is ONE masked copy (threshold_backward) instead of the compare + multiply pair autograd records
-    for F.relu here (0.7 ms of a 13 ms epoch at the benchmark size).  Same arithmetic, relu'(0) = 0."""
+    """relu(x . W^T) as one autograd node (PGCN.py:146-147).  With the package's own kernels (tuning.dense_fused; default 3) the
+    forward is ONE kernel that also leaves the sign mask of its output (1 bit per element), the backward two: the mask applied to
+    the gradient + the input gradient, and the weight gradient.  Levels: 0 library GEMMs + clamp / threshold passes; 1 forward
+    only; 2 + input gradient; 3 + weight gradient.  Same arithmetic class, relu'(0) = 0."""
 
     @staticmethod
     def forward(ctx, x, weight):
-        y = linear_relu_fused(x, weight) if _dense_fused_level() >= 1 else None       # (None: not CUDA / not its shapes)
-        if y is None:
+        level = _dense_fused_level()
+        out = linear_relu_fused(x, weight, True, want_mask=level >= 2) if level >= 1 else None   # (None: not CUDA / not its shapes)
+        mask = None
+        if out is None:
             y = mm_nt(x, weight).clamp_min_(0.0)
-        ctx.save_for_backward(x, weight, y)
+        elif level >= 2:
+            y, mask = out
+        else:
+            y = out
+        ctx.has_mask = mask is not None
+        if mask is not None:
+            ctx.save_for_backward(x, weight, mask)           # (y itself is not kept by this node: the mask is all the backward needs)
+        else:
+            ctx.save_for_backward(x, weight, y)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, weight, y = ctx.saved_tensors
+        x, weight, ym = ctx.saved_tensors
         gx = gw = None
         both = None
-        if ctx.needs_input_grad[0] and _dense_fused_level() >= 2:
-            both = linear_relu_grad_input_fused(g.contiguous(), y, weight)       # the mask and g . W in one pass
+        level = _dense_fused_level()
+        if ctx.has_mask and level >= 2:
+            both = linear_relu_grad_input_fused(g.contiguous(), ym, weight)       # the mask and g . W in one pass
         if both is not None:
             g, gx = both
         else:
-            g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
+            if ctx.has_mask:                  # (the level was lowered between forward and backward, or the kernel refused the gradient)
+                g = torch.where(unpack_sign_mask(ym, g.shape[1]), g, torch.zeros((), dtype=g.dtype, device=g.device))
+            else:
+                g = torch.ops.aten.threshold_backward(g.contiguous(), ym, 0.0)
             if ctx.needs_input_grad[0]:
                 gx = mm_nn(g, weight)
         if ctx.needs_input_grad[1]:
-            gw = _LinearNoBias.weight_grad(g, x)       # (the package's own kernel for this product lost 7 x: tools/experiments)
+            gw = weight_grad_fused(g, x) if level >= 3 else None
+            if gw is None:
+                gw = _LinearNoBias.weight_grad(g, x)
         return gx, gw
-
-
-# ---- one PGCN layer as ONE autograd node (r05, tuning.layer_fused) --------------------------------------------------------------
-# relu((A.H).W^T), PGCN.py:144-147, with the aggregation's fix-up folded into the dense product (forward AND backward) and the
-# backward re-associated:  T = A^T.Gm  (Gm = dY (.) [Y > 0]),  dH = T.W,  dW = T^T.H  -- the same products as autograd's
-# dAH = Gm.W, dH = A^T.dAH, dW = Gm^T.AH by associativity, but A.H is never needed again after the forward, so it is never
-# written: the forward's loader sums the producers' partial rows itself (gemm/pgcn_dense.hip, pgcn_fixup_linear_f32), and so does
-# the backward's, which also writes T (for dW) and applies the layer BELOW's ReLU mask to dH when its input is that layer's
-# output (threshold_backward by H = relu(...) is idempotent: the layer below may skip its own mask pass when it gets the very
-# tensor this node returned, and re-applies it otherwise -- correct either way).
-# (keyed by tensor IDENTITY: a plain WeakSet / WeakKeyDictionary would compare tensors with ==)
-_relu_outputs = WeakIdKeyDictionary()      # outputs of fused layers (their consumers may pre-mask the gradient they return)
-_premasked = WeakIdKeyDictionary()         # gradient tensor -> data_ptr of the relu output it was masked with
-
-
-def _layer_fused_level():
-    from .tuning import T as _T
-    return int(_T.layer_fused) if int(_T.dense_fused) >= 2 else 0
-
-
-def _layer_fused_on():
-    return _layer_fused_level() >= 1
-
-
-def _layer_fused_ok(A, H, weight):
-    return (_layer_fused_on() and hasattr(A, "forward_deferred") and H.is_cuda and weight.is_cuda and H.dim() == 2 and
-            H.dtype is torch.float32 and H.shape[1] % 4 == 0 and max(weight.shape) <= 128 and weight.shape[1] == H.shape[1] and
-            weight.shape[0] % 4 == 0 and H.device.index == torch.cuda.current_device() and H.device == weight.device)
-
-
-class _AggLinearRelu(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, H, weight, A, input_is_relu):
-        from .kernels import DeferredSum
-        L, stream = _dense_lib(), _dense_stream(H)
-        d = A.forward_deferred(H) if _layer_fused_level() >= 2 else A.forward(H)
-        y = None
-        if isinstance(d, DeferredSum):
-            out = fixup_linear_call(L, d.row_fix, d.slot_ids, d.ws, d.base, d.f, weight, True, EPI_RELU, None, False, stream)
-            if out is None:
-                d = d.finish()
-            else:
-                y = out[0]
-        if y is None:
-            y = linear_relu_call(L, d, weight, True, stream)
-            if y is None:
-                y = mm_nt(d, weight).clamp_min_(0.0)
-        ctx.A, ctx.input_is_relu = A, bool(input_is_relu)
-        ctx.save_for_backward(H, weight, y)
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        from .kernels import DeferredSum
-        H, weight, y = ctx.saved_tensors
-        L, stream = _dense_lib(), _dense_stream(y)
-        if _premasked.pop(g, None) != y.data_ptr():
-            g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
-        need_h = ctx.needs_input_grad[0]
-        epi = EPI_MASK if (ctx.input_is_relu and need_h) else EPI_NONE
-        d = ctx.A.backward_deferred(g) if _layer_fused_level() >= 2 else ctx.A.backward(g)
-        gh = T = None
-        if isinstance(d, DeferredSum):
-            out = fixup_linear_call(L, d.row_fix, d.slot_ids, d.ws, d.base, d.f, weight, False, epi, H, True, stream) if need_h else None
-            if out is None:
-                d = d.finish()
-            else:
-                gh, T = out
-        if T is None:
-            T = d
-            if need_h:
-                gh = linear_epilogue_call(L, T, weight, False, epi, H, stream)
-                if gh is None:
-                    gh = mm_nn(T, weight)
-                    epi = EPI_NONE
-        if gh is not None and epi == EPI_MASK:
-            _premasked[gh] = H.data_ptr()
-        gw = _LinearNoBias.weight_grad(T, H) if ctx.needs_input_grad[1] else None
-        return gh, gw, None, None
 
 
 _gemm_tuned_shapes = set()
@@ -713,10 +665,6 @@ class PGCN(nn.Module):
         self.recv_map = recv_map
 
     def forward(self, H):
-        if _layer_fused_ok(self.A, H, self.linear.weight):
-            Y = _AggLinearRelu.apply(H, self.linear.weight, self.A, H in _relu_outputs)
-            _relu_outputs[Y] = True
-            return Y
         H = PSpMM.apply(self.A, H)
         return _LinearReluNoBias.apply(H, self.linear.weight)      # == F.relu(self.linear(H)), PGCN.py:146-147
 

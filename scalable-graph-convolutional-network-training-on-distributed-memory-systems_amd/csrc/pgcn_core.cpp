@@ -78,14 +78,13 @@ extern "C" int pgcn_spmm_plan_host(const int64_t *rowptr, const int32_t *slice_c
                                   cap_tasks, fix, cap_fix, seg, ntasks, nfix, nslots);
 }
 
-//   * pair_row > small_row (r05, even nslices, ngroups == 1): rows with small_row < entries <= pair_row are cut into nslices / 2
-//     tasks, one per PAIR of adjacent slices (2p, 2p + 1) -- adjacent in storage, so still one contiguous run of entries -- placed
-//     on segment 2p or 2p + 1 alternately by row: half the partial rows of such a row, at the price of an XCD also seeing the
-//     neighbouring slice's columns for those tasks.
+//   * plan_flags & PGCN_PLAN_AFFINE_SMALL (r05): an unsliced short row's task runs on the segment (XCD) of its fullest slice.
+//     (r05 also measured rows of small_row < entries <= pair_row cut per PAIR of adjacent slices: slower on all three benchmark
+//     graphs, removed in r06 -- profiles/r05_pair_rows.txt, HISTORY.md section 10.)
 extern "C" int pgcn_spmm_plan_host_ex(const int64_t *rowptr, const int32_t *slice_cnt,
                                       const uint8_t *row_flags, int64_t nrows, int32_t nslices,
                                       int32_t ngroups, int32_t group_min_row, int32_t chunk,
-                                      int32_t small_row, int32_t pair_row,
+                                      int32_t small_row, int32_t plan_flags,
                                       int32_t *tasks, int64_t cap_tasks, int32_t *fix,
                                       int64_t cap_fix, int64_t *seg, int64_t *ntasks,
                                       int64_t *nfix, int64_t *nslots) {
@@ -99,9 +98,7 @@ extern "C" int pgcn_spmm_plan_host_ex(const int64_t *rowptr, const int32_t *slic
     const int V = S * G;             // "virtual slices": entries of a row are grouped by v = s*G + g
     // rows shorter than group_min_row are cut per slice only: their column groups are merged
     // back (cutting a medium row 8*G ways would only multiply tiny tasks and partial sums)
-    const bool affine = (pair_row & PGCN_PLAN_AFFINE_SMALL) != 0 && V > 1;   // unsliced rows go to the segment of their fullest slice
-    pair_row &= ~PGCN_PLAN_AFFINE_SMALL;
-    const bool pairing = pair_row > small_row && G == 1 && S > 1 && S % 2 == 0;
+    const bool affine = (plan_flags & PGCN_PLAN_AFFINE_SMALL) != 0 && V > 1;   // unsliced rows go to the segment of their fullest slice
     // the segment of an UNSLICED row: round-robin, or (affine) the XCD whose slice holds most of its entries -- those reads then
     // meet the rows of B that XCD's sliced tasks keep in its L2 (ties and empty rows: round-robin)
     auto small_seg = [&](int64_t r) -> int {
@@ -116,12 +113,10 @@ extern "C" int pgcn_spmm_plan_host_ex(const int64_t *rowptr, const int32_t *slic
         }
         return best;
     };
-    auto paired = [&](int64_t len) -> bool { return pairing && len <= pair_row; };
     // the segment (XCD) that runs piece v of row r
-    auto seg_of = [&](int64_t r, int64_t len, int v) -> int { return paired(len) ? v + (int)(r & 1) : v / G; };
+    auto seg_of = [&](int64_t, int64_t, int v) -> int { return v / G; };
     auto piece_len = [&](int64_t r, int64_t len, int v) -> int64_t {
         if (V == 1) return len;
-        if (paired(len)) return (v & 1) ? 0 : (int64_t)slice_cnt[r * V + v] + slice_cnt[r * V + v + 1];
         if (G == 1 || len >= group_min_row) return slice_cnt[r * V + v];
         if (v % G != 0) return 0;
         int64_t l = 0;

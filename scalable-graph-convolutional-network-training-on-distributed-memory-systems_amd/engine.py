@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import dataclasses
 from typing import Dict, List, Optional
 
 import torch
@@ -321,7 +322,14 @@ class AggregationEngine(BoundaryExchange):
         super().__init__(part, kernels, device, exchanger, overlap)
         self.A_loc = kernels.prepare(part.A_loc)
         self.A_halo = [kernels.prepare(a) for a in part.A_halo]
-        self.A_loc_T = kernels.prepare(part.A_loc_T) if part.A_loc_T is not None else None
+        if part.A_loc_T is part.A_loc:
+            # one rank, symmetric A (partition._finish_partition checked it bit for bit): the SAME device structures serve the backward;
+            # a second handle (own bindings and work-space, shared index / value / tile arrays) keeps forward and backward launches apart
+            # for whoever times them by operand
+            self.A_loc_T = dataclasses.replace(self.A_loc, ws=None, retired_ws=[], launch_cache={}) \
+                if dataclasses.is_dataclass(self.A_loc) else self.A_loc
+        else:
+            self.A_loc_T = kernels.prepare(part.A_loc_T) if part.A_loc_T is not None else None
         self.A_halo_T = [kernels.prepare(a) for a in part.A_halo_T]
 
     # ------------------------------------------------------------------
@@ -343,29 +351,6 @@ class AggregationEngine(BoundaryExchange):
             waits[r]()
             self.k.spmm(self.A_halo[r], halo, C, accumulate=True)   # main.c:295; overlaps round r+1
         return C
-
-    def forward_deferred(self, H: torch.Tensor):
-        """``forward`` with the last fix-up left to the consumer where that is possible (one rank, a tiled block, a kernel
-        provider that can): a kernels.DeferredSum, else the finished AH tensor."""
-        if self.size == 1 and hasattr(self.k, "spmm_deferred"):
-            if H.shape[0] != self.n_local:
-                raise ValueError("H must hold exactly the %d owned rows" % self.n_local)
-            H = H.contiguous()
-            C = torch.empty((self.n_local, H.shape[1]), dtype=torch.float32, device=self.device)
-            d = self.k.spmm_deferred(self.A_loc, H, C)
-            return d if d is not None else self.k.spmm(self.A_loc, H, C)
-        return self.forward(H)
-
-    def backward_deferred(self, G: torch.Tensor):
-        """``backward`` likewise."""
-        if self.size == 1 and hasattr(self.k, "spmm_deferred"):
-            if self.A_loc_T is None:
-                raise RuntimeError("partition was built without the transposed pieces")
-            G = G.contiguous()
-            dH = torch.empty((self.n_local, G.shape[1]), dtype=torch.float32, device=self.device)
-            d = self.k.spmm_deferred(self.A_loc_T, G, dH)
-            return d if d is not None else self.k.spmm(self.A_loc_T, G, dH)
-        return self.backward(G)
 
     def backward(self, G: torch.Tensor) -> torch.Tensor:
         """dH = (A^T . G)[owned rows], partial sums returned to their owners and ADDED."""

@@ -38,13 +38,6 @@ from .partition import HostCSR, Partition, csr_from_coo, pick_nslices
 from .tuning import T as _T
 
 LONG_ROW = _T.gat_long_row   # rows above this get a 256-thread workgroup
-# The gather plan of the attention structures (r05).  A partial row here is heads x d = 1 KB wide, twice the GCN path's, and every
-# task of a split row leaves one: rows are sliced over the XCDs from 193 entries on (GCN: 97) and long rows are cut into pieces of
-# 8 192 entries (GCN: 1 024).  Reddit shape, 4 heads x 64, ms per epoch: 96 / 1 024 58.7; 192 / 1 024 55.5; 384 / 1 024 56.4;
-# 128 / 2 048 55.6; 192 / 2 048 54.2; 256 / 2 048 54.2; 192 / 4 096 53.2; 256 / 4 096 53.2; 192 / 8 192 52.8; 192 / 16 384 52.8;
-# 320 / 8 192 52.9 (tools/probes_r05/p20_gat_plan.sh; tuning.gat_long_row 256 / 4 096: no change).
-GAT_SMALL_ROW = 192
-GAT_CHUNK = 8192
 MODES = {"standard": 0, "reference": 1}
 
 
@@ -122,6 +115,7 @@ class GatLayerState:
     V: Optional[torch.Tensor] = None     # [n_local, F + heads (+pad)]: V_i | C_i of the two-accumulator forward product
     fused: bool = False                  # the last forward ran pgcn_spmm_heads_forward2_f32 (no alpha planes, no de)
     Zc: Optional[torch.Tensor] = None    # [(n_local + n_halo), Fp] = [Z | s2 | pad] of local and halo rows
+    Zc_borrowed: bool = False            # Zc aliases the caller's packed projection (N = 1): a later copy-in forward must reallocate
     s2c: Optional[torch.Tensor] = None   # [(n_local + n_halo), heads] s2 of local and halo rows, compact (L2 resident)
     s1: Optional[torch.Tensor] = None
     out: Optional[torch.Tensor] = None
@@ -141,17 +135,12 @@ class GatEngine(BoundaryExchange):
         g = build_gat_graph(part, positive_only=(mode == "reference"), long_row=long_row)
         self.graph = g
         self.nnz = g.nnz
-        plan = {k: getattr(kernels, k) for k in ("chunk", "small_row") if hasattr(kernels, k)}
-        try:                                   # (the provider's plan parameters are the GCN path's: the attention structures get their own)
-            if "chunk" in plan:
-                kernels.chunk = max(kernels.chunk, GAT_CHUNK)
-            if "small_row" in plan:
-                kernels.small_row = max(kernels.small_row, GAT_SMALL_ROW)
-            self.fwd = kernels.prepare_gat(g.fwd, g.fwd_wave, g.fwd_block)
-            self.bwd = kernels.prepare_gat(g.bwd, g.bwd_wave, g.bwd_block)
-        finally:
-            for k, v in plan.items():
-                setattr(kernels, k, v)
+        # the provider's plan parameters are the GCN path's: the attention structures get their own (tuning.gat_chunk / gat_small_row),
+        # passed as arguments -- nothing of the shared provider is touched
+        chunk = max(int(getattr(kernels, "chunk", 0)), int(_T.gat_chunk))
+        small = max(int(getattr(kernels, "small_row", 0)), int(_T.gat_small_row))
+        self.fwd = kernels.prepare_gat(g.fwd, g.fwd_wave, g.fwd_block, chunk=chunk, small_row=small)
+        self.bwd = kernels.prepare_gat(g.bwd, g.bwd_wave, g.bwd_block, chunk=chunk, small_row=small)
         self.perm = g.perm.to(self.device)
         self._inv_perm = None              # forward entry -> its position in the transposed structure (built on demand)
         self._scratch = {}
@@ -221,11 +210,13 @@ class GatEngine(BoundaryExchange):
                 and panel.stride(1) == 1 and panel.stride(0) == panel.shape[1] and panel.dtype is torch.float32 \
                 and panel.data_ptr() % 16 == 0:
             st.Zc = Zc = panel.detach()
+            st.Zc_borrowed = True              # an alias of the caller's (autograd-owned) projection: never written through
             Fp = Zc.shape[1]
         else:
             Fp = self.padded_width(F, K)
-            if st.Zc is None or st.Zc.shape != (n_p + n_h, Fp):
+            if st.Zc is None or st.Zc_borrowed or st.Zc.shape != (n_p + n_h, Fp):
                 st.Zc = torch.zeros((n_p + n_h, Fp), dtype=torch.float32, device=self.device)
+                st.Zc_borrowed = False
             Zc = st.Zc
             Zc[:n_p, :F].copy_(Z)
             Zc[:n_p, F:F + K].copy_(s2)

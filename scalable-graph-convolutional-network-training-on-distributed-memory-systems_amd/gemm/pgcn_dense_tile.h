@@ -1,14 +1,18 @@
 // pgcn_dense_tile.h -- the index arithmetic of gemm/pgcn_dense.hip: where a value of W lands in the LDS image of B operands,
-// which 16-byte pieces of a tile a lane loads, which element of C an accumulator register is, the argument checks.  Shared by
+// which 16-byte pieces of a tile a lane loads, which element of C an accumulator register is, where a row's sign-mask words
+// live, the argument checks.  Shared by
 //   * gemm/pgcn_dense.hip (device build: PG_HD = __device__ __forceinline__), and
 //   * tests/native/pgcn_dense_emu.cpp (host build, -DPGCN_DENSE_HOST_EMU: the same functions run lane by lane around an
-//     emulated v_mfma_f32_32x32x16_bf16, so that slots, operand lanes and the accumulator layout are checked on the CPU).
+//     emulated v_mfma_f32_32x32x16_bf16, so that slots, operand lanes, the accumulator layout and the mask bits are checked on the
+//     CPU).
 // Included INSIDE namespace pgcn_dense; PG_HD comes from the including file.
 //
-// Loads and stores of tiles that lie inside the matrices (all but a wave's last tile of a full-width operand) take an
-// unpredicated path off ONE address (r05, tools/probes_r05: the guarded pieces cost ~12 instructions with three quarter-rate
-// 64-bit multiplies per 4-byte store; forward 75.7 -> 65.3 us at n = 232 965, f = 128), stores of C carry the non-temporal hint
-// (C is not read again by this kernel: 65.3 -> 63.3 us, input gradient 119.9 -> 116.8 us).
+// r06 layout of the work (the kernel file has the schedule): a tile is handled PIECE by piece (k step ks: the lane's two 16-byte
+// loads of row lo, columns 16 ks + 8 hi .. + 8) and its product column BLOCK by column block (nb: 16 accumulator registers =
+// rows (r & 3) + 8 (r >> 2) + 4 hi, column 32 nb + lo), so that loads, splits and stores can be spread between the MFMAs.
+// Rows beyond n are never predicated: every streamed matrix is addressed through a WINDOW that starts at the tile's first row and
+// ends with the matrix (a buffer descriptor on the device): loads beyond it read zero, stores beyond it are dropped.  Widths that do not fill the instance (K < 16 NKS, N < 32 NBLK) take the RAGGED
+// instantiations: pieces beyond K read as zero, columns beyond N are not stored.
 constexpr int kRows = 32;                 // rows of a wave's tile = M of the MFMA
 constexpr int kMaxF = 128;                // K and N of a product
 constexpr int kThreads = 512;
@@ -25,11 +29,22 @@ PG_HD int image_offset(int plane, int ks, int nb, int lane) { return plane * kPl
 // Slot s (0 .. kSlotsPerPlane) of the image, all three planes: the eight values Bm[16 ks + 8 hi + j][32 nb + lo].
 // transposed = 1: Bm = W^T (W is N x K, row-major, ldw); 0: Bm = W (W is K x N).  Outside K x N: zeros.
 // In two steps, so that a thread's loads of all its slots are in flight together (branch-free: clamped addresses, the value
-// dropped afterwards).
-PG_HD void slot_load(const float *__restrict__ W, int64_t ldw, int transposed, int K, int N, int s, float (&v)[8]) {
+// dropped afterwards).  `vec` (uniform: transposed, K % 8 == 0, ldw % 4 == 0, W 16-byte aligned): the eight values are eight
+// consecutive floats of one row of W -- two 16-byte loads instead of eight dwords that each touch 32 cache lines per wave (r06: the
+// image build of a workgroup drops from ~8 k to ~2 k line look-ups).
+PG_HD void slot_load(const float *__restrict__ W, int64_t ldw, int transposed, int K, int N, int s, float (&v)[8], bool vec = false) {
     const int lane = s & 63, nb = (s >> 6) & 3, ks = s >> 8;
     const int col = 32 * nb + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
     const int colc = col < N ? col : N - 1;
+    if (vec) {                                            // (uniform) transposed: W[col][k0 .. k0 + 8)
+        const bool in = k0 + 8 <= K;
+        const float *p = W + (int64_t)colc * ldw + (in ? k0 : 0);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
+        const bool ok = in && col < N;
+        v[0] = ok ? a.x : 0.f; v[1] = ok ? a.y : 0.f; v[2] = ok ? a.z : 0.f; v[3] = ok ? a.w : 0.f;
+        v[4] = ok ? b.x : 0.f; v[5] = ok ? b.y : 0.f; v[6] = ok ? b.z : 0.f; v[7] = ok ? b.w : 0.f;
+        return;
+    }
     const int64_t sk = transposed ? 1 : ldw, sc = transposed ? ldw : 1;      // (one address, one load: no branch on the mode)
     float x[8];
 #pragma unroll
@@ -40,6 +55,10 @@ PG_HD void slot_load(const float *__restrict__ W, int64_t ldw, int transposed, i
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (k0 + j < K && col < N) ? x[j] : 0.f;
 }
+// the vector form of slot_load applies (uniform per launch)
+inline bool slot_vec_ok(const void *W, int64_t ldw, int transposed, int K) {
+    return transposed && K % 8 == 0 && ldw % 4 == 0 && (uintptr_t)W % 16 == 0;
+}
 PG_HD void slot_store(char *image, int s, const float (&v)[8]) {
     const int lane = s & 63, nb = (s >> 6) & 3, ks = s >> 8;
     u32x4 p[3];
@@ -49,18 +68,121 @@ PG_HD void slot_store(char *image, int s, const float (&v)[8]) {
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(image + image_offset(pl, ks, nb, lane)) = p[pl];
 }
 
-// A lane's 16-byte pieces of a tile: piece (ks, h) = A[row0 + lo][16 ks + 8 hi + 4 h .. + 4]; zeros outside n x K (K % 4 == 0).
-struct Piece {
-    int64_t off;      // element offset from the matrix base (valid only when ok)
-    bool ok;
+// ---- windows: the rows of a matrix from a tile's first row on, addressed as (window, lane offset, scalar offset) -----------------------
+// On the device a window is a buffer descriptor (base = the tile's first row, size = the bytes from there to the end of the matrix):
+// a lane's byte offset inside the tile never changes, the scalar offset picks the row of an accumulator register, and an access
+// beyond the last row of the matrix is dropped (stores) or reads as zero (loads) by the hardware's bounds check -- no row predicates,
+// no 64-bit address arithmetic in the loop.  The host build checks the same bounds in software.
+#ifndef PGCN_DENSE_HOST_EMU
+using window_t = __amdgpu_buffer_rsrc_t;
+// (every argument wave-uniform; the caller passes values it made uniform with readfirstlane)
+PG_HD window_t make_window(const void *base, int64_t bytes) {
+    const uint32_t nb = bytes <= 0 ? 0u : (bytes > 0xfffff000LL ? 0xfffff000u : (uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)nb, 0x00020000);
+}
+PG_HD f32x4 win_load16(window_t w, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w, (int)voff, (int)soff, 0));
+}
+PG_HD uint32_t win_load4u(window_t w, uint32_t voff, uint32_t soff) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(w, (int)voff, (int)soff, 0);
+}
+PG_HD void win_store16(window_t w, uint32_t voff, uint32_t soff, const f32x4 &v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), w, (int)voff, (int)soff, 0);
+}
+PG_HD void win_store4(window_t w, uint32_t voff, uint32_t soff, float v) {           // non-temporal: C is not read again by this kernel
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), w, (int)voff, (int)soff, 2);
+}
+PG_HD void win_store4u(window_t w, uint32_t voff, uint32_t soff, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, w, (int)voff, (int)soff, 0);
+}
+#else
+struct window_t {
+    char *base;
+    int64_t bytes;
 };
-PG_HD Piece piece_of(int64_t row0, int64_t n, int K, int64_t ld, int lane, int ks, int h) {
-    const int64_t row = row0 + (lane & 31);
-    const int k = 16 * ks + 8 * (lane >> 5) + 4 * h;
-    Piece p;
-    p.ok = row < n && k < K;
-    p.off = row * ld + k;
-    return p;
+PG_HD window_t make_window(const void *base, int64_t bytes) {
+    return window_t{const_cast<char *>(static_cast<const char *>(base)), bytes <= 0 ? 0 : (bytes > 0xfffff000LL ? 0xfffff000LL : bytes)};
+}
+PG_HD f32x4 win_load16(window_t w, uint32_t voff, uint32_t soff) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int64_t o = (int64_t)voff + soff;
+    if (o + 16 <= w.bytes) memcpy(&v, w.base + o, 16);
+    return v;
+}
+PG_HD uint32_t win_load4u(window_t w, uint32_t voff, uint32_t soff) {
+    uint32_t v = 0;
+    const int64_t o = (int64_t)voff + soff;
+    if (o + 4 <= w.bytes) memcpy(&v, w.base + o, 4);
+    return v;
+}
+PG_HD void win_store16(window_t w, uint32_t voff, uint32_t soff, const f32x4 &v) {
+    const int64_t o = (int64_t)voff + soff;
+    if (o + 16 <= w.bytes) memcpy(w.base + o, &v, 16);
+}
+PG_HD void win_store4(window_t w, uint32_t voff, uint32_t soff, float v) {
+    const int64_t o = (int64_t)voff + soff;
+    if (o + 4 <= w.bytes) memcpy(w.base + o, &v, 4);
+}
+PG_HD void win_store4u(window_t w, uint32_t voff, uint32_t soff, uint32_t v) {
+    const int64_t o = (int64_t)voff + soff;
+    if (o + 4 <= w.bytes) memcpy(w.base + o, &v, 4);
+}
+#endif
+// the window of a row-major matrix M (rows `ld` elements apart, n rows) from row `row0` on; elem = bytes per element
+PG_HD window_t tile_window(const void *M, int64_t ld, int64_t n, int64_t row0, int width, int elem = 4) {
+    // the last row ends at its width, not at the next row's start (the matrix may sit at the very end of an allocation)
+    const int64_t rows = n - row0;
+    return make_window(static_cast<const char *>(M) + row0 * ld * elem, rows <= 0 ? 0 : ((rows - 1) * ld + width) * elem);
+}
+
+// ---- a lane's pieces of a tile ----------------------------------------------------------------------------------------------
+// byte offset of the lane's row inside a tile's window, at the lane's first column of a k step: row lo, column 8 hi
+PG_HD uint32_t piece_lane_offset(int64_t ld, int lane) { return (uint32_t)(((int64_t)(lane & 31) * ld + 8 * (lane >> 5)) * 4); }
+// piece ks of the lane's row: A[row][16 ks + 8 hi + 4 h .. + 4], h = 0, 1.  RAGGED: pieces at or beyond K are zero (K % 4 == 0: a piece
+// lies inside or outside the width as a whole).  Rows beyond the matrix read as zero (the window's bounds).
+template <bool RAGGED>
+PG_HD void load_piece(f32x4 (&v)[2], window_t w, uint32_t lane_off, int ks, int K, int lane) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if constexpr (!RAGGED) {
+            v[h] = win_load16(w, lane_off + (uint32_t)(64 * ks + 16 * h), 0);
+        } else {
+            const bool ok = 16 * ks + 8 * (lane >> 5) + 4 * h < K;
+            const f32x4 x = win_load16(w, ok ? lane_off + (uint32_t)(64 * ks + 16 * h) : lane_off - (uint32_t)(32 * (lane >> 5)), 0);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            v[h] = ok ? x : z;
+        }
+    }
+}
+// the same piece written back (Gm of the input gradient): rows beyond the matrix are dropped by the window, RAGGED: pieces beyond K by
+// the lane
+template <bool RAGGED>
+PG_HD void store_piece(const f32x4 (&v)[2], window_t w, uint32_t lane_off, int ks, int K, int lane) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (!RAGGED || 16 * ks + 8 * (lane >> 5) + 4 * h < K) win_store16(w, lane_off + (uint32_t)(64 * ks + 16 * h), 0, v[h]);
+    }
+}
+
+// ---- the sign mask of the forward's output (r06) -----------------------------------------------------------------------------------
+// mask[row * mw + w] bit b = (Y[row][32 w + b] > 0), mw = words per row (mask_words(N)): what the input gradient needs of Y -- 4 bytes
+// per row and 32 columns instead of 128 (the backward reads 3.7 MB instead of 119 MB at the benchmark layer, and holds 4 registers of it
+// per tile instead of 64).
+PG_HD int mask_words(int N) { return (N + 31) / 32; }
+// The lane that assembles the mask word of a tile row for a column block: accumulator register r of half wave h holds row
+// (r & 3) + 8 (r >> 2) + 4 h; the ballot of (acc[r] > 0) has that row's 32 column bits of half h in bits 32 h .. 32 h + 31.
+// The word of (r, h) is collected in lane 16 h + r: mask_row_of_lane(L) is the tile row whose word lane L (< 32) holds.
+PG_HD int mask_row_of_lane(int L) {
+    const int r = L & 15, h = L >> 4;
+    return (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+// threshold_backward by the mask bits: piece (ks, h) of a row covers columns 16 ks + 8 hi + 4 h .. + 4 = bits (16 (ks & 1) + 8 hi + 4 h) ..
+// of word ks >> 1
+PG_HD f32x4 mask4_bits(const f32x4 &g, uint32_t word, int ks, int h, int lane) {
+    const uint32_t sh = word >> (16 * (ks & 1) + 8 * (lane >> 5) + 4 * h);
+    f32x4 r;
+    r.x = (sh & 1u) ? g.x : 0.f; r.y = (sh & 2u) ? g.y : 0.f; r.z = (sh & 4u) ? g.z : 0.f; r.w = (sh & 8u) ? g.w : 0.f;
+    return r;
 }
 // threshold_backward(g, y, 0): the gradient where y > 0 (NaN in y keeps it, like ATen's `y <= 0 ? 0 : g`)
 PG_HD f32x4 mask4(const f32x4 &g, const f32x4 &y) {
@@ -68,37 +190,23 @@ PG_HD f32x4 mask4(const f32x4 &g, const f32x4 &y) {
     r.x = y.x <= 0.f ? 0.f : g.x; r.y = y.y <= 0.f ? 0.f : g.y; r.z = y.z <= 0.f ? 0.f : g.z; r.w = y.w <= 0.f ? 0.f : g.w;
     return r;
 }
+// (the mask's convention for NaN: `!(y <= 0)`, the same predicate as mask4)
+PG_HD bool mask_bit_of(float y) { return !(y <= 0.f); }
 PG_HD float relu1(float x) { return x < 0.f ? 0.f : x; }                      // clamp_min(0): NaN stays NaN
 
-PG_HD void store1(float *p, float x) {
-#ifndef PGCN_DENSE_HOST_EMU
-    __builtin_nontemporal_store(x, p);
-#else
-    *p = x;
-#endif
-}
-// accumulator register r of lane (lo, hi), column block nb -> element (row0 + (r & 3) + 8 (r >> 2) + 4 hi, 32 nb + lo) of C
-PG_HD void store_c(const f32x16 *acc, int nblk, float *C, int64_t ldc, int64_t row0, int64_t n, int N, int lane, int relu) {
-    const int hi = lane >> 5, lo = lane & 31;
-    if (row0 + kRows <= n && 32 * nblk == N) {        // (wave-uniform) the tile lies inside C: no predicates
-        float *base = C + (row0 + 4 * hi) * ldc + lo;
+// byte offset of a lane's first accumulator row inside a tile's window of C: row 4 hi, column lo
+PG_HD uint32_t acc_lane_offset(int64_t ldc, int lane) { return (uint32_t)(((int64_t)(4 * (lane >> 5)) * ldc + (lane & 31)) * 4); }
+// registers [r0, r0 + cnt) of column block nb: accumulator register r of lane (lo, hi) -> element (row0 + (r & 3) + 8 (r >> 2) + 4 hi,
+// 32 nb + lo) of C = window of the tile, lane offset + 128 nb, scalar offset ((r & 3) + 8 (r >> 2)) rows.  Rows beyond the matrix are
+// dropped by the window; RAGGED: columns beyond N by the lane.
+template <bool RAGGED>
+PG_HD void store_regs(const f32x16 &acc, int r0, int cnt, int nb, window_t wc, uint32_t lane_off, uint32_t row_bytes, int N, int lane,
+                      int relu) {
+    if (RAGGED && 32 * nb + (lane & 31) >= N) return;
 #pragma unroll
-        for (int nb = 0; nb < nblk; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                store1(base + (int64_t)((r & 3) + 8 * (r >> 2)) * ldc + 32 * nb, relu ? relu1(acc[nb][r]) : acc[nb][r]);
-        return;
-    }
-#pragma unroll
-    for (int nb = 0; nb < nblk; ++nb) {
-        const int col = 32 * nb + lo;
-        if (col >= N) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (row < n) store1(&C[row * ldc + col], relu ? relu1(acc[nb][r]) : acc[nb][r]);
-        }
-    }
+    for (int r = 0; r < 16; ++r)
+        if (r >= r0 && r < r0 + cnt)
+            win_store4(wc, lane_off + (uint32_t)(128 * nb), (uint32_t)((r & 3) + 8 * (r >> 2)) * row_bytes, relu ? relu1(acc[r]) : acc[r]);
 }
 
 // ---- argument checks and the error string ---------------------------------------------------------------------------------
@@ -115,230 +223,5 @@ inline int check(const void *A, int64_t lda, int64_t n, int K, int N, const void
     if (K % 4 || lda % 4 || (uintptr_t)A % 16) return fail(-2, "pgcn_dense: rows of the left operand must be 16-byte pieces");
     if (lda < K || ldc < N || ldw < wcols || wrows <= 0) return fail(-1, "pgcn_dense: leading dimension below the width");
     if (n > ((int64_t)1 << 40)) return fail(-1, "pgcn_dense: n out of range");
-    return 0;
-}
-
-// ---- a wave's operand tiles -----------------------------------------------------------------------------------------------------
-template <int NKS>
-struct TileA {
-    f32x4 v[NKS][2];
-};
-
-template <int NKS>
-PG_HD void load_tile(TileA<NKS> &t, const float *__restrict__ A, int64_t lda, int64_t row0, int64_t n, int K, int lane) {
-    if (row0 + kRows <= n && 16 * NKS == K) {         // (wave-uniform) the tile lies inside A: 16 loads off one address
-        const float *base = A + (row0 + (lane & 31)) * lda + 8 * (lane >> 5);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) t.v[ks][h] = *reinterpret_cast<const f32x4 *>(base + 16 * ks + 4 * h);
-        return;
-    }
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const Piece p = piece_of(row0, n, K, lda, lane, ks, h);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            t.v[ks][h] = p.ok ? *reinterpret_cast<const f32x4 *>(A + p.off) : z;
-        }
-}
-
-// ---- the masked operand as a stream of HALF tiles (k steps [ks0, ks0 + CNT) of a tile) ----------------------------------------
-// G and Y of a half are 2 x CNT x 2 loads of 16 bytes; while one half is multiplied the next one (the second half of the tile,
-// or the first half of the wave's next tile) is in flight: 32 + 64 + 64 registers instead of the 128 + 64 a whole tile of
-// G and Y would hold beside the accumulators.
-template <int CNT>
-struct HalfRaw {
-    f32x4 g[CNT][2], y[CNT][2];
-};
-template <int CNT>
-PG_HD void load_half(HalfRaw<CNT> &r, const float *__restrict__ G, int64_t ldg, const float *__restrict__ Y, int64_t ldy,
-                     int64_t row0, int64_t n, int K, int lane, int ks0) {
-    if (row0 + kRows <= n && 32 * CNT == K) {         // (wave-uniform) inside the matrix: no predicates
-        const int64_t at = 8 * (lane >> 5) + 16 * ks0;
-        const float *gb = G + (row0 + (lane & 31)) * ldg + at, *yb = Y + (row0 + (lane & 31)) * ldy + at;
-#pragma unroll
-        for (int i = 0; i < CNT; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                r.g[i][h] = *reinterpret_cast<const f32x4 *>(gb + 16 * i + 4 * h);
-                r.y[i][h] = *reinterpret_cast<const f32x4 *>(yb + 16 * i + 4 * h);
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < CNT; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const Piece pg = piece_of(row0, n, K, ldg, lane, ks0 + i, h);
-            const Piece py = piece_of(row0, n, K, ldy, lane, ks0 + i, h);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            r.g[i][h] = pg.ok ? *reinterpret_cast<const f32x4 *>(G + pg.off) : z;
-            r.y[i][h] = py.ok ? *reinterpret_cast<const f32x4 *>(Y + py.off) : z;
-        }
-}
-// G (.) [Y > 0] of a half, written out as Gm (when asked for) on the way
-template <int CNT>
-PG_HD void mask_half(f32x4 (&v)[CNT][2], const HalfRaw<CNT> &r, float *__restrict__ Gm, int64_t ldgm, int64_t row0, int64_t n, int K,
-                     int lane, int ks0) {
-    if (row0 + kRows <= n && 32 * CNT == K) {
-        float *mb = Gm ? Gm + (row0 + (lane & 31)) * ldgm + 8 * (lane >> 5) + 16 * ks0 : nullptr;
-#pragma unroll
-        for (int i = 0; i < CNT; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                v[i][h] = mask4(r.g[i][h], r.y[i][h]);
-                if (mb) *reinterpret_cast<f32x4 *>(mb + 16 * i + 4 * h) = v[i][h];
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < CNT; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            v[i][h] = mask4(r.g[i][h], r.y[i][h]);
-            if (Gm) {
-                const Piece pm = piece_of(row0, n, K, ldgm, lane, ks0 + i, h);
-                if (pm.ok) *reinterpret_cast<f32x4 *>(Gm + pm.off) = v[i][h];
-            }
-        }
-}
-
-// ---- the operand as the SUM of a row's partial rows: the fix-up of the aggregation folded into its consumer (r05) ---------------
-// The producers of one aggregation (gather tasks, strips, bf16 blocks) leave partial rows in a work-space; csrc's
-// spmm_fixup_list_kernel adds a row's partial rows in list order and writes A.H, which the dense kernel then reads back.  Here
-// the dense kernel's loader does that sum itself, in the same order (bit-identical operand), so A.H is never written:
-//     row_fix[r] = {begin, count};  count >= 0:  S[r] = ((0 + P[id_0]) + P[id_1]) + ...,  id_t = slot_ids[begin + t]
-//                                                (id_t = begin + t when slot_ids == NULL),  P[i] = partial + i * ldp
-//                                   count <  0:  S[r] = base[r]   (a row some producer wrote directly)
-// A lane's 16-byte pieces are those of piece_of(); the ids of up to kIdChunk slots are fetched together, the pieces of slot
-// t + 1 are in flight while those of slot t are added.  Loads are unconditional (clamped ids, the sum kept by a select): a
-// branch per slot would fence the loads in flight.  `tmax` >= every lane's count (wave-uniform on the device).
-struct RowFix {
-    int32_t begin, count;
-};
-constexpr int kIdChunk = 8;
-
-template <int CNT>
-PG_HD void load_row_pieces(f32x4 (&x)[CNT][2], const float *__restrict__ rowp, int K, int lane, int ks0, bool full) {
-    // rowp = first element of the lane's row; pieces (ks0 + i, h) at 16 (ks0 + i) + 8 hi + 4 h
-    const float *p = rowp + 8 * (lane >> 5) + 16 * ks0;
-    if (full) {
-#pragma unroll
-        for (int i = 0; i < CNT; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) x[i][h] = *reinterpret_cast<const f32x4 *>(p + 16 * i + 4 * h);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < CNT; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = 16 * (ks0 + i) + 8 * (lane >> 5) + 4 * h;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            x[i][h] = k < K ? *reinterpret_cast<const f32x4 *>(p + 16 * i + 4 * h) : z;
-        }
-}
-
-template <int CNT>
-PG_HD void sum_half(f32x4 (&v)[CNT][2], const float *__restrict__ partial, int64_t ldp, const int32_t *__restrict__ slot_ids,
-                    const float *__restrict__ base, int64_t ldbase, int64_t row, RowFix rf, int tmax, int K, int lane, int ks0) {
-    const bool full = 16 * (ks0 + CNT) <= K;          // (uniform) every piece of this half lies inside the width
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < CNT; ++i) { v[i][0] = z; v[i][1] = z; }
-    if (rf.count < 0) load_row_pieces<CNT>(v, base + row * ldbase, K, lane, ks0, full);     // (rare: a branch)
-    for (int t0 = 0; t0 < tmax; t0 += kIdChunk) {
-        int32_t id[kIdChunk];
-#pragma unroll
-        for (int j = 0; j < kIdChunk; ++j) {
-            const int t = t0 + j;
-            const bool on = t < rf.count;
-            const int32_t at = on ? rf.begin + t : 0;
-            const int32_t got = slot_ids ? slot_ids[at] : at;
-            id[j] = on ? got : -1;
-        }
-        f32x4 x[2][CNT][2];
-        load_row_pieces<CNT>(x[0], partial + (int64_t)(id[0] < 0 ? 0 : id[0]) * ldp, K, lane, ks0, full);
-#pragma unroll
-        for (int j = 0; j < kIdChunk; ++j) {
-            if (t0 + j >= tmax) break;                // (uniform)
-            if (j + 1 < kIdChunk && t0 + j + 1 < tmax)
-                load_row_pieces<CNT>(x[(j + 1) & 1], partial + (int64_t)(id[j + 1] < 0 ? 0 : id[j + 1]) * ldp, K, lane, ks0, full);
-            const bool on = id[j] >= 0;
-#pragma unroll
-            for (int i = 0; i < CNT; ++i)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 s = v[i][h] + x[j & 1][i][h];
-                    v[i][h].x = on ? s.x : v[i][h].x; v[i][h].y = on ? s.y : v[i][h].y;
-                    v[i][h].z = on ? s.z : v[i][h].z; v[i][h].w = on ? s.w : v[i][h].w;
-                }
-        }
-    }
-}
-// the summed half written out (the operand of the weight gradient in the backward; the aggregation itself when a caller wants it)
-template <int CNT>
-PG_HD void store_half(const f32x4 (&v)[CNT][2], float *__restrict__ S, int64_t lds, int64_t row0, int64_t n, int K, int lane, int ks0) {
-    if (row0 + kRows <= n && 16 * (ks0 + CNT) <= K) {
-        float *sb = S + (row0 + (lane & 31)) * lds + 8 * (lane >> 5) + 16 * ks0;
-#pragma unroll
-        for (int i = 0; i < CNT; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4 *>(sb + 16 * i + 4 * h) = v[i][h];
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < CNT; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const Piece pm = piece_of(row0, n, K, lds, lane, ks0 + i, h);
-            if (pm.ok) *reinterpret_cast<f32x4 *>(S + pm.off) = v[i][h];
-        }
-}
-// C = the product where M > 0, else 0 (threshold_backward by the layer input M = relu(...) of the layer below: its mask pass
-// folded into this layer's input gradient); accumulator layout as in store_c
-PG_HD void store_c_masked(const f32x16 *acc, int nblk, float *C, int64_t ldc, const float *__restrict__ M, int64_t ldm, int64_t row0,
-                          int64_t n, int N, int lane) {
-    const int hi = lane >> 5, lo = lane & 31;
-    if (row0 + kRows <= n && 32 * nblk == N) {
-        float *base = C + (row0 + 4 * hi) * ldc + lo;
-        const float *mb = M + (row0 + 4 * hi) * ldm + lo;
-#pragma unroll
-        for (int nb = 0; nb < nblk; ++nb) {
-            float m[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m[r] = mb[(int64_t)((r & 3) + 8 * (r >> 2)) * ldm + 32 * nb];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                store1(base + (int64_t)((r & 3) + 8 * (r >> 2)) * ldc + 32 * nb, m[r] <= 0.f ? 0.f : acc[nb][r]);
-        }
-        return;
-    }
-#pragma unroll
-    for (int nb = 0; nb < nblk; ++nb) {
-        const int col = 32 * nb + lo;
-        if (col >= N) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (row < n) store1(&C[row * ldc + col], M[row * ldm + col] <= 0.f ? 0.f : acc[nb][r]);
-        }
-    }
-}
-
-inline int check_fixup(const void *row_fix, const void *partial, int64_t ldp, const void *base, int64_t ldbase, int64_t n, int K, int N,
-                       const void *W, int64_t ldw, int wcols, const void *S, int64_t lds, const void *M, int64_t ldm, const void *C,
-                       int64_t ldc, int epilogue) {
-    if (n < 0 || K <= 0 || N <= 0 || !W || (n > 0 && (!row_fix || !C)) || epilogue < 0 || epilogue > 2)
-        return fail(-1, "pgcn_fixup_linear_f32: bad argument");
-    if (K > kMaxF || N > kMaxF) return fail(-2, "pgcn_fixup_linear_f32: widths above 128 are left to the separate fix-up + library GEMM");
-    if (K % 4) return fail(-2, "pgcn_fixup_linear_f32: the width of the summed rows must be a multiple of 4");
-    if (partial && (ldp % 4 || (uintptr_t)partial % 16 || ldp < K)) return fail(-2, "pgcn_fixup_linear_f32: partial rows must be 16-byte pieces");
-    if (base && (ldbase % 4 || (uintptr_t)base % 16 || ldbase < K)) return fail(-2, "pgcn_fixup_linear_f32: base rows must be 16-byte pieces");
-    if (S && (lds % 4 || (uintptr_t)S % 16 || lds < K)) return fail(-2, "pgcn_fixup_linear_f32: rows of S must be 16-byte pieces");
-    if (epilogue == 2 && (!M || ldm < N)) return fail(-1, "pgcn_fixup_linear_f32: the mask epilogue needs M");
-    if (ldc < N || ldw < wcols) return fail(-1, "pgcn_fixup_linear_f32: leading dimension below the width");
     return 0;
 }

@@ -76,8 +76,27 @@ extern "C" int pgcn_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t 
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(-1, "hipGetDevice", 0);
     std::lock_guard<std::mutex> lock(g_mu);          // the table and the enqueue as one step
-    rocblas_handle h = handle_for(dev, stream);
+    // A stream that is being captured into a HIP graph (torch.cuda.graph captures on its own stream) must not see
+    // rocblas_create_handle: it allocates device memory, which is illegal under capture.  A product on such a stream borrows a
+    // handle this device already has (its stream is switched for the one call and restored) -- set-up ran at least one product
+    // on the default stream (PGCN.tune_dense_gemms), so one exists; only when none does is a handle created here.
+    rocblas_handle h = nullptr, borrowed = nullptr;
+    void *borrowed_stream = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    bool have = false;
+    for (int i = 0; i < g_nslots; ++i) have = have || (g_slots[i].dev == dev && g_slots[i].stream == stream);
+    if (!have && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) {
+        for (int i = 0; i < g_nslots && !borrowed; ++i)
+            if (g_slots[i].dev == dev) { borrowed = g_slots[i].h; borrowed_stream = g_slots[i].stream; }
+        if (borrowed && rocblas_set_stream(borrowed, (hipStream_t)stream) == rocblas_status_success) h = borrowed;
+        else borrowed = nullptr;
+    }
+    if (!h) h = handle_for(dev, stream);
     if (!h) return fail(-1, "rocblas_create_handle / rocblas_set_stream (or more than 256 (device, stream) pairs)", 0);
+    struct Restore {
+        rocblas_handle h; void *s;
+        ~Restore() { if (h) rocblas_set_stream(h, (hipStream_t)s); }
+    } restore{borrowed, borrowed_stream};
     rocblas_status st = rocblas_set_atomics_mode(h, g_atomics_allowed ? rocblas_atomics_allowed : rocblas_atomics_not_allowed);
     if (st != rocblas_status_success) return fail(-1, "rocblas_set_atomics_mode", (int)st);
     const float one = 1.0f, zero = 0.0f;

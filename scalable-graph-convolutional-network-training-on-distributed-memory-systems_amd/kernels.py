@@ -50,13 +50,10 @@ class DeviceCSR:
     ws: Optional[torch.Tensor] = None     # fp32 work-space for split rows (grown on demand)
     retired_ws: list = field(default_factory=list)   # outgrown work-spaces, kept allocated (see _bind_spmm)
     core: Optional["DeviceCore"] = None   # dense-tile part (LDS-tiled kernel)
-    dense: Optional["DeviceDense"] = None  # densest tiles (fp32 matrix cores)
     strip: Optional["DeviceStrip"] = None  # 512 x 128 strip tiles (LDS-staged, async pipeline)
     dense3: Optional["DeviceDense3"] = None  # densest 512 x 128 blocks (bf16 matrix cores, three planes)
     fix_all: Optional[torch.Tensor] = None    # int32 [nfix_all,4] combined fix list (core + gather slots)
     slot_ids: Optional[torch.Tensor] = None   # int32 slot lists of fix_all
-    row_fix: Optional[torch.Tensor] = None    # int32 [nrows, 2] (begin, count) per row, count < 0: no slots (DeferredSum), built on demand
-    fix_heavy: Optional[torch.Tensor] = None  # int32 [nheavy, 4]: the fix records of rows with more than tuning.layer_fused_cap slots
     nslots_total: int = 0
     rows_wave: Optional[torch.Tensor] = None   # GAT kernels: int32 rows handled by one wave each ...
     rows_block: Optional[torch.Tensor] = None  # ... and by one 256-thread workgroup each (hub rows)
@@ -74,29 +71,6 @@ class DeviceCSR:
         nc = self.ncols if n_cols_touched is None else n_cols_touched
         nr = self.nrows if n_rows_out is None else n_rows_out
         return 8 * self.nnz + 8 * (self.nrows + 1) + 4 * f * nc + 4 * f * nr
-
-
-@dataclass
-class DeviceDense:
-    work: torch.Tensor
-    tile_panel: torch.Tensor
-    vals: torch.Tensor
-    npieces: int
-    nnz: int
-
-
-@dataclass
-class DeferredSum:
-    """An aggregation whose producers have run but whose fix-up has NOT: row r of the result is the ordered sum of the partial rows
-    ``slot_ids[begin .. begin + count)`` of ``ws`` (``row_fix[r] = (begin, count)``), or ``base[r]`` where count < 0 (a row a producer
-    wrote directly).  Consumed by pgcn_fixup_linear_f32 (gemm/pgcn_dense.hip: the fix-up as the loader of the dense product) or
-    completed by ``HipKernels.finish``.  Valid until the next SpMM on the same matrix reuses its work-space (stream order)."""
-    row_fix: torch.Tensor        # int32 [nrows, 2]
-    slot_ids: torch.Tensor       # int32
-    ws: torch.Tensor             # fp32 work-space, rows f floats apart
-    base: torch.Tensor           # fp32 [nrows, f]: the rows with count < 0
-    f: int
-    finish: object               # callable: runs the separate fix-up into ``base`` and returns it
 
 
 @dataclass
@@ -136,7 +110,7 @@ class DeviceCore:
 def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarray] = None,
                small_row: int = DEFAULT_SMALL_ROW, force: bool = False,
                row_flags: Optional[np.ndarray] = None, ngroups: int = 1,
-               group_min_row: int = GROUP_MIN_ROW, pair_row: Optional[int] = None):
+               group_min_row: int = GROUP_MIN_ROW):
     """Host-side task list (pgcn_spmm_plan_host).  Returns (tasks, fix, nslots, seg) with
     numpy int32 arrays; tasks is None when the plan is trivial (unsliced and no row
     exceeds ``chunk``): the one-task-per-row kernel path needs no plan."""
@@ -157,17 +131,15 @@ def build_plan(rowptr_host: np.ndarray, chunk: int, slice_cnt: Optional[np.ndarr
         force = True
     seg = (ctypes.c_int64 * (S + 1))()
     nt, nf, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    pair_row = int(_T.spmm_pair_row) if pair_row is None else int(pair_row)
-    if _T.spmm_affine_small and slice_cnt is not None:
-        pair_row |= 0x40000000          # PGCN_PLAN_AFFINE_SMALL
-    _lib.check(L.pgcn_spmm_plan_host_ex(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row, pair_row,
+    plan_flags = 0x40000000 if (_T.spmm_affine_small and slice_cnt is not None) else 0     # PGCN_PLAN_AFFINE_SMALL
+    _lib.check(L.pgcn_spmm_plan_host_ex(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row, plan_flags,
                                         None, 0, None, 0, seg, ctypes.byref(nt), ctypes.byref(nf), ctypes.byref(ns)),
                "pgcn_spmm_plan_host")
     if nf.value == 0 and S == 1 and not force:
         return None, None, 0, None
     tasks = np.empty((nt.value, 4), dtype=np.int32)
     fix = np.empty((max(nf.value, 1), 4), dtype=np.int32)
-    _lib.check(L.pgcn_spmm_plan_host_ex(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row, pair_row,
+    _lib.check(L.pgcn_spmm_plan_host_ex(rowptr_host.ctypes.data, sc_ptr, rf_ptr, nrows, S, ngroups, group_min_row, chunk, small_row, plan_flags,
                                         tasks.ctypes.data, nt.value, fix.ctypes.data, nf.value, seg, ctypes.byref(nt),
                                         ctypes.byref(nf), ctypes.byref(ns)), "pgcn_spmm_plan_host")
     return tasks, fix[:nf.value], int(ns.value), seg
@@ -207,7 +179,10 @@ class HipKernels:
         self.adaptive_chunk = _T.spmm_adaptive_chunk
 
     # -- data placement -------------------------------------------------
-    def prepare(self, csr: HostCSR, pattern_only: bool = False, pair_row: Optional[int] = None) -> DeviceCSR:
+    def prepare(self, csr: HostCSR, pattern_only: bool = False, chunk: Optional[int] = None,
+                small_row: Optional[int] = None) -> DeviceCSR:
+        """``chunk`` / ``small_row``: plan parameters of THIS matrix when they differ from the provider's (the attention structures
+        of the GAT path: tuning.gat_chunk / gat_small_row); arguments, not provider state, so two engines can be built at once."""
         dev = self.device
         rowptr_host = csr.rowptr.detach().cpu().numpy()
         sc = None if csr.slice_cnt is None else csr.slice_cnt.detach().cpu().numpy()
@@ -215,14 +190,14 @@ class HipKernels:
         # a task is a latency chain of chunk / 8 gather batches (~0.7 us each): on a small block (a rank's shard of an
         # 8-way run) a 1 024-entry task outlasts the rest of the kernel, so the chunk shrinks with the block --
         # entries / 8 192, between 64 and the configured chunk (r03: tools/probes_r03, emulated ranks)
-        chunk = self.chunk
+        top = self.chunk if chunk is None else int(chunk)
+        chunk = top
         if self.adaptive_chunk:
             e = max(int(csr.col.numel()), 1) // 8192
-            chunk = min(self.chunk, max(64, 1 << max(e.bit_length() - 1, 0)))
-        tasks, fix, nslots, seg = build_plan(rowptr_host, chunk, sc, self.small_row,
+            chunk = min(top, max(64, 1 << max(e.bit_length() - 1, 0)))
+        tasks, fix, nslots, seg = build_plan(rowptr_host, chunk, sc, self.small_row if small_row is None else int(small_row),
                                              force=csr.row_map is not None, row_flags=rf,
-                                             ngroups=csr.ngroups,
-                                             pair_row=getattr(self, "pair_row", None) if pair_row is None else pair_row)
+                                             ngroups=csr.ngroups)
         d = DeviceCSR(
             nrows=csr.nrows, ncols=csr.ncols, nnz=csr.nnz,
             rowptr=csr.rowptr.to(dev, torch.int64).contiguous(),
@@ -235,7 +210,7 @@ class HipKernels:
             d.ntasks, d.nfix, d.nslots = tasks.shape[0], fix.shape[0], nslots
             d.nslices, d.seg = csr.nslices if sc is not None else 1, seg
         d.nslots_total = d.nslots
-        if csr.core is not None or csr.dense is not None or csr.strip is not None or csr.dense3 is not None:
+        if csr.core is not None or csr.strip is not None or csr.dense3 is not None:
             self._attach_core(d, csr, fix if tasks is not None else None)
         return d
 
@@ -244,7 +219,7 @@ class HipKernels:
         partial sums are its core pieces (in work order), its dense pieces, then its gather-kernel slots."""
         from .partition import CORE_TR, STRIP_TR
         dev = self.device
-        hc, hd, hs, h3 = csr.core, csr.dense, csr.strip, csr.dense3
+        hc, hs, h3 = csr.core, csr.strip, csr.dense3
         ns_rem = d.nslots
         pieces = []                                                # (first row, rows, first slot) of every piece
         ns_core = ns_strip = 0
@@ -265,16 +240,9 @@ class HipKernels:
             w64 = work.cpu().to(torch.int64)
             pieces.append(torch.stack([w64[:, 0] * CORE_TR, torch.full_like(w64[:, 0], CORE_TR), w64[:, 3]], 1))
             ns_core = hc.nslots
-        if hd is not None:
-            work = hd.work.clone()
-            work[:, 3] += ns_rem + ns_strip + ns_core              # ... and the MFMA pieces behind those
-            d.dense = DeviceDense(work.to(dev).contiguous(), hd.tile_panel.to(dev).contiguous(),
-                                  hd.vals.to(dev).contiguous(), hd.npieces, hd.nnz)
-            w64 = work.cpu().to(torch.int64)
-            pieces.append(torch.stack([w64[:, 0] * CORE_TR, torch.full_like(w64[:, 0], CORE_TR), w64[:, 3]], 1))
         if h3 is not None:
             work = h3.work.clone()
-            work[:, 3] += ns_rem + ns_strip + ns_core + (hd.nslots if hd is not None else 0)   # ... and the bf16 blocks last
+            work[:, 3] += ns_rem + ns_strip + ns_core              # ... and the bf16 blocks last
             d.dense3 = DeviceDense3(work.to(dev).contiguous(), h3.blk_img.to(dev).contiguous(), h3.vals3.to(dev).contiguous(),
                                     h3.panel_list.to(dev).contiguous(), h3.npieces, int(h3.panel_list.numel()), h3.nnz)
             w64 = work.cpu().to(torch.int64)
@@ -304,7 +272,7 @@ class HipKernels:
         fix_all = torch.stack([urows, begin, counts, torch.zeros_like(urows)], 1).to(torch.int32)
         d.fix_all = fix_all.to(dev).contiguous()
         d.slot_ids = slots.to(torch.int32).to(dev).contiguous()
-        d.nslots_total = ns_rem + ns_strip + ns_core + (hd.nslots if hd is not None else 0) + (h3.nslots if h3 is not None else 0)
+        d.nslots_total = ns_rem + ns_strip + ns_core + (h3.nslots if h3 is not None else 0)
         d.nnz = csr.nnz
 
     # -- kernels ----------------------------------------------------------
@@ -336,40 +304,6 @@ class HipKernels:
         fn(B, C)
         return C
 
-    def spmm_deferred(self, A: DeviceCSR, B: torch.Tensor, C: torch.Tensor):
-        """The producers of C = A.B without the fix-up: a DeferredSum for the consumer that does the sum itself, or None when this
-        matrix has no separate fix-up to defer (gather-only plans, row maps, widths the consumer does not take): the caller then
-        runs ``spmm``."""
-        f = B.shape[1]
-        if A.fix_all is None or A.slot_ids is None or A.row_map is not None or f % 4 or f > 128 or A.nrows == 0:
-            return None
-        key = (B.stride(0), C.stride(0), f, False, C.shape[1], B.stride(1), C.stride(1))
-        fn = A.launch_cache.get(key)
-        if fn is None:
-            fn = self._bind_spmm(A, B, C, False)
-            A.launch_cache[key] = fn
-        produce = getattr(fn, "produce", None)
-        if produce is None:
-            return None
-        if A.row_fix is None:
-            # rows with more partial rows than the consumer's loader keeps ids for in one go (hub rows: every strip piece, bf16 block
-            # and chunk of their row tile leaves one) are summed by the separate fix-up kernel into C and read from there: a wave's
-            # 32-row tile costs as many dependent round trips as its LONGEST list
-            cap = int(_T.layer_fused_cap)
-            light = A.fix_all[:, 2] <= cap
-            t = torch.zeros((A.nrows, 2), dtype=torch.int32, device=self.device)
-            t[:, 1] = -1
-            rows = A.fix_all[light, 0].long()
-            t[rows, 0] = A.fix_all[light, 1]
-            t[rows, 1] = A.fix_all[light, 2]
-            A.row_fix = t.contiguous()
-            A.fix_heavy = A.fix_all[~light].contiguous()
-        produce(B, C)
-        if A.fix_heavy.shape[0]:
-            _lib.check(self.lib.pgcn_spmm_fixup_f32(A.fix_heavy.data_ptr(), A.fix_heavy.shape[0], A.slot_ids.data_ptr(), None, A.ws.data_ptr(),
-                                                    C.data_ptr(), C.stride(0), f, 0, self._stream()), "pgcn_spmm_fixup_f32")
-        return DeferredSum(A.row_fix, A.slot_ids, A.ws, C, f, lambda: (fn.fixup(C), C)[1])
-
     def _bind_spmm(self, A: DeviceCSR, B: torch.Tensor, C: torch.Tensor, accumulate: bool):
         f = B.shape[1]
         self._check_dense(B, A.ncols, "B")
@@ -385,7 +319,7 @@ class HipKernels:
         lib, check, stream = self.lib, _lib.check, self._stream
         if A.nrows == 0:
             return lambda B, C: None
-        if A.nnz == 0 and A.core is None and A.dense is None and A.strip is None and A.dense3 is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
+        if A.nnz == 0 and A.core is None and A.strip is None and A.dense3 is None:   # nothing to launch: C = 0 (memset, plumbing) or C unchanged
             if accumulate:
                 return lambda B, C: None
             if A.row_map is None:
@@ -393,7 +327,7 @@ class HipKernels:
             rows = A.row_map.long()
             return lambda B, C: C.index_fill_(0, rows, 0.0)
         rowptr, col, val, rmap = A.rowptr.data_ptr(), A.col.data_ptr(), _ptr(A.val), _ptr(A.row_map)
-        if A.tasks is None and A.row_map is None and A.core is None and A.dense is None and A.strip is None and A.dense3 is None:
+        if A.tasks is None and A.row_map is None and A.core is None and A.strip is None and A.dense3 is None:
             nrows = A.nrows
             def simple(B, C):
                 check(lib.pgcn_spmm_csr_f32(rowptr, col, val, nrows, B.data_ptr(), ldb, C.data_ptr(), ldc, f,
@@ -408,7 +342,7 @@ class HipKernels:
         ws, ws_n = _ptr(A.ws), (0 if A.ws is None else A.ws.numel())
         tasks, ntasks, seg, nslices = _ptr(A.tasks), A.ntasks, A.seg, A.nslices
         nslots = A.nslots
-        if A.core is None and A.dense is None and A.strip is None and A.dense3 is None:
+        if A.core is None and A.strip is None and A.dense3 is None:
             fix, nfix = _ptr(A.fix), A.nfix
             def planned(B, C):
                 check(lib.pgcn_spmm_csr_plan_f32(rowptr, col, val, tasks, ntasks, seg, nslices, fix, nfix, rmap,
@@ -416,7 +350,7 @@ class HipKernels:
                                                  stream()), "pgcn_spmm_csr_plan_f32")
             return planned
         # gather part (partial sums stay in the work-space) + LDS-tiled core + MFMA tiles + one combined fix-up
-        co, de, st, d3 = A.core, A.dense, A.strip, A.dense3
+        co, st, d3 = A.core, A.strip, A.dense3
         if d3 is not None:
             need3 = int(lib.pgcn_dense_bf16x3_image_bytes(d3.npanels, f))
             if d3.image is None or d3.image.numel() < need3:
@@ -434,8 +368,6 @@ class HipKernels:
                                                  co.cval.data_ptr())
         else:
             cw = cn = ctp = ctb = cso = ccol = cval = None
-        if de is not None:
-            dw, dn, dtp, dvals = de.work.data_ptr(), de.npieces, de.tile_panel.data_ptr(), de.vals.data_ptr()
         ncols, nst = A.ncols, A.nslots_total
         fixp, nfa, slots = A.fix_all.data_ptr(), A.fix_all.shape[0], A.slot_ids.data_ptr()
         gflags, fflags = flags | _lib.SPMM_NO_FIXUP, flags & _lib.SPMM_ACCUMULATE
@@ -476,8 +408,6 @@ class HipKernels:
                         launch(name, b, c, o)
             for name in lanes[-1]:
                 launch(name, b, c, s)
-            if de is not None:
-                check(lib.pgcn_spmm_dense_f32(dw, dn, dtp, dvals, b, ldb, ncols, f, ws, ws_n, nst, s), "pgcn_spmm_dense_f32")
             if co is not None:
                 check(lib.pgcn_spmm_core_f32(cw, cn, ctp, ctb, cso, ccol, cval, b, ldb, ncols, f, ws, ws_n, nst, s),
                       "pgcn_spmm_core_f32")
@@ -490,16 +420,16 @@ class HipKernels:
         def hybrid(B, C):
             produce(B, C)
             fixup(C)
-        hybrid.produce, hybrid.fixup = produce, fixup        # (spmm_deferred: the producers alone, the fix-up left to the consumer)
         return hybrid
 
     # -- GAT path (pgcn_gat.hip) ---------------------------------------------
-    def prepare_gat(self, csr: HostCSR, rows_wave: torch.Tensor, rows_block: torch.Tensor) -> DeviceCSR:
+    def prepare_gat(self, csr: HostCSR, rows_wave: torch.Tensor, rows_block: torch.Tensor, chunk: Optional[int] = None,
+                    small_row: Optional[int] = None) -> DeviceCSR:
         """Pattern structure for the attention kernels + SpMM plan; the values come per layer and
         head through ``with_values``."""
         if csr.core is not None or csr.row_map is not None:
             raise _lib.PgcnError("GAT structures are plain (sliced) CSR blocks")
-        d = self.prepare(csr, pattern_only=True, pair_row=0)        # (the attention kernels walk (row, slice) pieces)
+        d = self.prepare(csr, pattern_only=True, chunk=chunk, small_row=small_row)        # (the attention kernels walk (row, slice) pieces)
         d.rows_wave = rows_wave.to(self.device, torch.int32).contiguous()
         d.rows_block = rows_block.to(self.device, torch.int32).contiguous()
         if csr.nslices == 8 and csr.slice_cnt is not None and csr.ngroups == 1:

@@ -44,7 +44,6 @@ class HostCSR:
     ngroups: int = 1                          # ... then by column group = col // group_width
     core: Optional["HostCore"] = None         # entries of dense tiles, stored for the LDS-tiled kernel
     row_flags: Optional[torch.Tensor] = None  # uint8 [nrows]: row also receives core partial sums
-    dense: Optional["HostDense"] = None       # the densest tiles, stored dense for the fp32 matrix cores
     strip: Optional["HostStrip"] = None       # entries of 512 x 128 strip tiles (LDS-staged, async pipeline)
     dense3: Optional["HostDense3"] = None     # the densest 512 x 128 blocks, stored dense for the bf16 matrix cores (three planes)
 
@@ -52,7 +51,7 @@ class HostCSR:
     def nnz(self) -> int:
         """Stored entries of the whole block (gather part + LDS core / strips + MFMA tiles)."""
         return int(self.col.numel()) + (self.core.nnz if self.core is not None else 0) + \
-            (self.dense.nnz if self.dense is not None else 0) + (self.strip.nnz if self.strip is not None else 0) + \
+            (self.strip.nnz if self.strip is not None else 0) + \
             (self.dense3.nnz if self.dense3 is not None else 0)
 
     def to_coo(self):
@@ -65,9 +64,6 @@ class HostCSR:
         if self.core is not None:
             cr, cc, cv = self.core.to_coo()
             r, c, v = torch.cat([r, cr]), torch.cat([c, cc]), torch.cat([v, cv])
-        if self.dense is not None:
-            dr, dc, dv = self.dense.coo
-            r, c, v = torch.cat([r, dr]), torch.cat([c, dc]), torch.cat([v, dv])
         if self.strip is not None:
             sr, sc, sv = self.strip.to_coo()
             r, c, v = torch.cat([r, sr]), torch.cat([c, sc]), torch.cat([v, sv])
@@ -100,10 +96,6 @@ CORE_EMAX = _T.core_emax          # entries per work piece; 0 = adaptive: ~1024 
 CORE_MIN_NNZ = _T.core_min_nnz    # smaller tiled parts are not worth two more launches
 CORE_MIN_FRAC = _T.core_min_frac
 DEGREE_SORT = _T.degree_sort
-DENSE_ON = _T.dense
-DENSE_TAU = _T.dense_tau          # tiles at least this full go to the matrix cores (0.20 before the r02 strips)
-DENSE_PIECE = _T.dense_piece      # tiles per work piece (one 128-row partial block each); 0 = adaptive: ~512 pieces,
-                                  # between 1 and 16 tiles
 
 
 @dataclass
@@ -143,61 +135,6 @@ class HostCore:
         panel = torch.repeat_interleave(self.tile_panel.to(torch.int64).repeat_interleave(CORE_TR), cnt)
         c = panel * CORE_TC + self.ccol.to(torch.int64)
         return r, c, self.cval
-
-
-@dataclass
-class HostDense:
-    """The densest tiles, stored DENSE and pre-swizzled into the A-operand order of
-    v_mfma_f32_32x32x2_f32 (pgcn_spmm_dense_f32):
-    vals[tile][w][s4][lane][e] = A[32 w + (lane & 31)][2 (4 s4 + e) + (lane >> 5)]."""
-    nrows: int
-    ncols: int
-    work: torch.Tensor        # int32 [npieces, 4] {tile row, first tile, number of tiles, first slot (local)}
-    tile_row: torch.Tensor    # int32 [ntiles]
-    tile_panel: torch.Tensor  # int32 [ntiles]
-    vals: torch.Tensor        # fp32 [ntiles, TR*TC]
-    coo: tuple                # (row, col, val) of the stored entries (host-side bookkeeping / checker)
-
-    @property
-    def nnz(self) -> int:
-        return int(self.coo[0].numel())
-
-    @property
-    def npieces(self) -> int:
-        return int(self.work.shape[0])
-
-    @property
-    def nslots(self) -> int:
-        return self.npieces * CORE_TR
-
-
-def build_dense(r64, c64, v, tkey_local, ntiles, tile_row, tile_panel, nrows, ncols, piece: int = None) -> HostDense:
-    """``tkey_local`` numbers the dense tiles 0..ntiles-1 in (tile row, panel) order."""
-    import numpy as np
-    TR, TC = CORE_TR, CORE_TC
-    piece = DENSE_PIECE if piece is None else piece
-    if piece <= 0:
-        # a piece pays ~3 us of exposed panel staging + a 128-row partial block whatever it holds (the matrix pipes of
-        # this kernel are 56 % busy, SQ_VALU_MFMA_BUSY_CYCLES, r03): ~512 pieces = one round of 2 workgroups x 256 CUs;
-        # small blocks get one tile per piece.  Measured r03 on the benchmark graph (3 162 tiles): 3 / 6 / 12 tiles per
-        # piece -> MFMA tiles 137 / 128 / 141 us, fix-up 160 / 146 / 143 us
-        piece = int(min(16, max(1, ntiles // 512)))
-    dev = r64.device
-    i, k = r64 % TR, c64 % TC
-    w, il, s, kh = i // 32, i % 32, k // 2, k % 2
-    idx = ((w * 16 + s // 4) * 64 + kh * 32 + il) * 4 + s % 4
-    vals = torch.zeros(ntiles * TR * TC, dtype=torch.float32, device=dev)
-    vals.index_add_(0, tkey_local * (TR * TC) + idx, v.to(torch.float32))       # duplicates add, like an uncoalesced COO
-    ttr = tile_row.cpu().numpy()
-    run_start = np.r_[True, ttr[1:] != ttr[:-1]]
-    pos_in_run = np.arange(ntiles) - np.maximum.accumulate(np.where(run_start, np.arange(ntiles), 0))
-    newp = run_start | (pos_in_run % max(piece, 1) == 0)
-    kbeg = np.nonzero(newp)[0]
-    kcnt = np.r_[kbeg[1:], ntiles] - kbeg
-    lpt = np.argsort(-kcnt, kind="stable")
-    work = np.stack([ttr[kbeg][lpt], kbeg[lpt], kcnt[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
-    return HostDense(nrows, ncols, torch.from_numpy(work).to(dev), tile_row, tile_panel, vals.view(ntiles, TR * TC),
-                     (r64, c64, v.to(torch.float32)))
 
 
 # ---- 512 x 128 blocks on the bf16 matrix cores (pgcn_spmm_dense_bf16x3_f32) -------------------------------------
@@ -498,34 +435,24 @@ def build_strips(r64: torch.Tensor, c64: torch.Tensor, v: torch.Tensor, nrows: i
 
 
 def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
-               tau: float = None, emax: int = None, dense_tau: float = None):
-    """Separate the entries of dense tiles.  Returns (keep_mask, HostCore or None, HostDense or None):
-    tiles at least ``dense_tau`` full are stored dense for the matrix cores, the other tiles at least
-    ``tau`` full go to the LDS-tiled kernel."""
+               tau: float = None, emax: int = None):
+    """Separate the entries of dense 128 x 128 tiles.  Returns (keep_mask, HostCore or None): tiles at least ``tau`` full go to
+    the LDS-tiled kernel.  (The fp32-MFMA form of the densest tiles, r02-r03, was replaced by the bf16 blocks in r04 and removed
+    in r06.)"""
     tau = CORE_TAU if tau is None else tau
     emax = CORE_EMAX if emax is None else emax
-    if dense_tau is None:
-        dense_tau = DENSE_TAU if DENSE_ON else 2.0
     TR, TC, NG, RW = CORE_TR, CORE_TC, CORE_NG, CORE_RW
     dev = r.device
     if r.numel() == 0:
-        return None, None, None
+        return None, None
     r64, c64 = r.to(torch.int64), c.to(torch.int64)
     ncp = (ncols + TC - 1) // TC
     tkey = (r64 // TR) * ncp + c64 // TC
     uniq, inv, cnt = torch.unique(tkey, return_inverse=True, return_counts=True)
-    mfma = cnt >= max(1, int(dense_tau * TR * TC)) if dense_tau <= 1.0 else torch.zeros_like(cnt, dtype=torch.bool)
-    hdense, is_dense = None, None
-    if int(mfma.sum()):
-        is_dense = mfma[inv]
-        dmap = torch.cumsum(mfma.to(torch.int64), 0) - 1
-        dk = uniq[mfma]
-        hdense = build_dense(r64[is_dense], c64[is_dense], v[is_dense], dmap[inv[is_dense]], int(mfma.sum()),
-                             (dk // ncp).to(torch.int32), (dk % ncp).to(torch.int32), nrows, ncols)
-    dense = (cnt >= max(1, int(tau * TR * TC))) & ~mfma
+    dense = cnt >= max(1, int(tau * TR * TC))
     ntiles = int(dense.sum())
     if ntiles == 0:
-        return (None if is_dense is None else ~is_dense), None, hdense
+        return None, None
     is_core = dense[inv]
     if not emax:   # enough pieces to fill 2 workgroups x 256 CUs twice over, but no confetti
         emax = int(min(32768, max(4096, int(cnt[dense].sum()) // 1024)))
@@ -561,7 +488,7 @@ def split_core(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, nc
     work = np.stack([ttr[kbeg][lpt], kbeg[lpt], kend[lpt], np.arange(len(kbeg)) * TR], 1).astype(np.int32)
     core = HostCore(nrows, ncols, torch.from_numpy(work).to(dev), tile_row, tile_panel, tile_base,
                     seg_off.contiguous(), ccol, cval)
-    return (~is_core if is_dense is None else ~(is_core | is_dense)), core, hdense
+    return ~is_core, core
 
 
 # XCD-sliced storage: above this many columns the dense panel no longer fits a 4 MiB L2
@@ -581,7 +508,7 @@ def pick_nslices(ncols: int) -> int:
 def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int,
                  compact_rows: bool = False, nslices: Optional[int] = None, core: bool = False,
                  tau: float = None, emax: int = None, ngroups: Optional[int] = None,
-                 dense_tau: float = None, slice_bounds: Optional[torch.Tensor] = None,
+                 slice_bounds: Optional[torch.Tensor] = None,
                  strip: Optional[bool] = None, strip_min: Optional[int] = None, dense3_tau: Optional[float] = None) -> HostCSR:
     """Sort by (row, slice, col) and build CSR.  Duplicate entries are kept as
     separate stored entries (an uncoalesced COO sums them, PGCN.py:63).  With ``core``
@@ -603,20 +530,17 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
         return torch.bucketize(c64, slice_bounds[1:-1], right=True)
     G = 1 if ngroups is None else (max(1, min(64, int(ngroups))) if S > 1 else 1)
     gw = max(1, -(-ncols // G))          # columns per group
-    hcore, hdense, hstrip, hdense3, row_flags = None, None, None, None, None
+    hcore, hstrip, hdense3, row_flags = None, None, None, None
     if core and not compact_rows and r.numel():
         use_strip = STRIP_ON if strip is None else strip
         r0, c0, v0 = r, c, v
-        # the bf16 three-plane blocks (512 x 128) replace the fp32-MFMA tiles (128 x 128) unless a caller asks for those
-        # by passing dense_tau; dense3_tau > 1 switches them off
-        use3 = (DENSE3_ON and dense_tau is None) if dense3_tau is None else dense3_tau <= 1.0
+        # the bf16 three-plane blocks (512 x 128); dense3_tau > 1 switches them off
+        use3 = DENSE3_ON if dense3_tau is None else dense3_tau <= 1.0
         if use3 and ncols >= CORE_TC:
             keep3, hdense3 = split_dense3(r, c, v, nrows, ncols, dense3_tau)
             if keep3 is not None:
                 r, c, v = r[keep3], c[keep3], v[keep3]
-            if dense_tau is None:
-                dense_tau = 2.0
-        keep, hcore, hdense = split_core(r, c, v, nrows, ncols, 2.0 if use_strip else tau, emax, dense_tau)
+        keep, hcore = split_core(r, c, v, nrows, ncols, 2.0 if use_strip else tau, emax)
         if keep is not None:
             r, c, v = r[keep], c[keep], v[keep]
         if use_strip:
@@ -626,19 +550,19 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
                 # pieces long enough to amortise their 512-row partial block -- the finer-grained 128 x 128 LDS core
                 # (two workgroups per CU, 128-row pieces) serves it better (measured: tools/rank_probe.py, r02)
                 skeep = hstrip = None
-                ckeep, hcore, _ = split_core(r, c, v, nrows, ncols, tau, emax, 2.0)
+                ckeep, hcore = split_core(r, c, v, nrows, ncols, tau, emax)
                 if ckeep is not None and hcore is not None:
                     r, c, v = r[ckeep], c[ckeep], v[ckeep]
             if skeep is not None:
                 r, c, v = r[skeep], c[skeep], v[skeep]
-        tiled = sum(h.nnz for h in (hcore, hdense, hstrip, hdense3) if h is not None)
+        tiled = sum(h.nnz for h in (hcore, hstrip, hdense3) if h is not None)
         if tiled and tau is None and strip_min is None and dense3_tau is None and \
                 (tiled < CORE_MIN_NNZ or tiled < CORE_MIN_FRAC * r0.numel()):
-            hcore = hdense = hstrip = hdense3 = None     # a small tiled part does not pay for the extra kernel + fix-up launches
+            hcore = hstrip = hdense3 = None     # a small tiled part does not pay for the extra kernel + fix-up launches
             r, c, v = r0, c0, v0
-        if hcore is not None or hdense is not None or hstrip is not None or hdense3 is not None:
+        if hcore is not None or hstrip is not None or hdense3 is not None:
             row_flags = torch.zeros(nrows, dtype=torch.uint8, device=dev)
-            for h, tr in ((hcore, CORE_TR), (hdense, CORE_TR), (hstrip, STRIP_TR), (hdense3, DENSE3_BR)):
+            for h, tr in ((hcore, CORE_TR), (hstrip, STRIP_TR), (hdense3, DENSE3_BR)):
                 if h is None:
                     continue
                 trs = torch.unique((h.work[:, 0] if (h is hstrip or h is hdense3) else h.tile_row).to(torch.int64))
@@ -671,18 +595,18 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     else:
         G = 1
     return HostCSR(nrows, ncols, rowptr, c.to(torch.int32).contiguous(),
-                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, G, hcore, row_flags, hdense, hstrip, hdense3)
+                   v.to(torch.float32).contiguous(), row_map, S, slice_cnt, G, hcore, row_flags, hstrip, hdense3)
 
 
 def csr_from_scipy(A, nslices: Optional[int] = None, core: bool = False, tau: float = None,
-                   emax: int = None, ngroups: Optional[int] = None, dense_tau: float = None,
+                   emax: int = None, ngroups: Optional[int] = None,
                    strip: Optional[bool] = None, strip_min: Optional[int] = None, dense3_tau: Optional[float] = None) -> HostCSR:
     """Convenience for tests / tools: a scipy sparse matrix -> HostCSR (optionally sliced)."""
     import numpy as np
     A = A.tocoo()
     return csr_from_coo(torch.from_numpy(A.row.astype(np.int64)), torch.from_numpy(A.col.astype(np.int64)),
                         torch.from_numpy(A.data.astype(np.float32)), A.shape[0], A.shape[1],
-                        nslices=nslices, core=core, tau=tau, emax=emax, ngroups=ngroups, dense_tau=dense_tau,
+                        nslices=nslices, core=core, tau=tau, emax=emax, ngroups=ngroups,
                         strip=strip, strip_min=strip_min, dense3_tau=dense3_tau)
 
 
@@ -993,6 +917,30 @@ def vertex_order(row: torch.Tensor, col: torch.Tensor, n: int, gdeg: Optional[to
     return gorder, grank, info
 
 
+def _coo_is_symmetric(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, n: int) -> bool:
+    """True when the COO block (r, c, v) of an n x n matrix equals its transpose as a multiset of (row, col, value bits):
+    duplicates included, values compared bit for bit."""
+    if r.numel() == 0:
+        return True
+    r64, c64 = r.to(torch.int64), c.to(torch.int64)
+    if int(r64.max()) >= n or int(c64.max()) >= n:
+        return False
+    bits = v.to(torch.float32).contiguous().view(torch.int32).to(torch.int64) & 0xffffffff
+    k1, k2 = r64 * n + c64, c64 * n + r64
+    o1, o2 = torch.argsort(k1, stable=True), torch.argsort(k2, stable=True)
+    if not torch.equal(k1[o1], k2[o2]):
+        return False
+    b1, b2 = bits[o1], bits[o2]
+    if torch.equal(b1, b2):
+        return True
+    # duplicates of one (row, col) may be stored in any order: compare (key, value bits) as multisets (rare path)
+    key1 = torch.stack([k1[o1], b1], 1)
+    key2 = torch.stack([k2[o2], b2], 1)
+    u1 = torch.unique(key1, dim=0, return_counts=True)
+    u2 = torch.unique(key2, dim=0, return_counts=True)
+    return u1[0].shape == u2[0].shape and torch.equal(u1[0], u2[0]) and torch.equal(u1[1], u2[1])
+
+
 def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Tensor, n: int, part: torch.Tensor,
                       rank: int, size: int, gorder: torch.Tensor, grank: torch.Tensor, suniq: torch.Tensor,
                       nnz_global: int, with_transpose: bool, rounds: Optional[int]) -> Partition:
@@ -1038,7 +986,13 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
 
     A_loc_T = None
     if with_transpose:
-        A_loc_T = csr_from_coo(g2l[c[loc]], r[loc], v[loc], n_p, n_p, core=CORE_ON)
+        rl, cl, vl = r[loc], g2l[c[loc]], v[loc]
+        if size == 1 and _coo_is_symmetric(rl, cl, vl, n_p):
+            # one rank, A = A^T entry for entry (every A_hat of `preprocess`; checked bit for bit, not assumed): the transposed block IS
+            # the block -- half the structure memory and half of the "partition built" stage (r06)
+            A_loc_T = A_loc
+        else:
+            A_loc_T = csr_from_coo(cl, rl, vl, n_p, n_p, core=CORE_ON)
 
     # rows of mine that other ranks need, in the peers' slab order (round, target rank, degree rank)
     s_order, _, round_send_off = _round_major(suniq // n, size, R)

@@ -22,8 +22,6 @@ class Tuning:
     spmm_chunk: int = 1024           # entries per task of a long row ...
     spmm_adaptive_chunk: bool = True # ... shrunk on small blocks (entries / 8192, >= 64): a task is a latency chain
     spmm_small_row: int = 96         # rows up to this many entries are ONE unsliced task
-    spmm_pair_row: int = 0           # r05: rows with small_row < entries <= this are cut per PAIR of adjacent XCD slices (4 tasks and
-                                     # 4 partial rows instead of 8); 0 = off.  Measured: profiles/r05_pair_rows.txt
     spmm_affine_small: bool = True   # r05: an unsliced short row's task runs on the XCD of its FULLEST col % 8 slice instead of
                                      # round-robin (those reads meet the rows that XCD's sliced tasks keep in its L2).  Gather part, kernels one
                                      # after the other: Reddit shape 703-706 -> 696 us, SBM 1 975 -> 1 963, products 4 788 -> 4 743
@@ -41,11 +39,6 @@ class Tuning:
     core_min_nnz: int = 2000000      # a smaller tiled part does not pay for its three extra launches (r03: the 1.7 M-entry
                                      # local block of an 8-way shard runs 0.067 ms gather-only, 0.099 ms tiled)
     core_min_frac: float = 0.1
-    dense: bool = True               # fp32-MFMA tiles (128 x 128).  IGNORED (like dense_tau / dense_piece) unless dense_bf16x3 = 0: with the
-                                     # bf16 blocks on, partition.csr_from_coo never builds fp32 tiles -- also for matrices that end up with
-                                     # no bf16 block at all (fewer than dense3_min_blocks: their entries go to the strips / the LDS core)
-    dense_tau: float = 0.30          # tiles at least this full go to the matrix cores
-    dense_piece: int = 0             # tiles per MFMA piece (0 = adaptive)
     dense_bf16x3: bool = True        # r04: 512 x 128 blocks on the bf16 matrix cores at fp32 accuracy (three-plane split, six
                                      # products) instead of the fp32-MFMA tiles
     dense3_tau: float = 0.20         # blocks at least this full (of 65 536) take that path (r04 sweep on the benchmark graph,
@@ -83,22 +76,19 @@ class Tuning:
     gemm_tuning: bool = True         # use the recorded kernel choices for the n x f x f GEMMs of a layer (tunableop/gfx950.csv + cache) ...
     gemm_tunableop: bool = False     # ... through PyTorch's TunableOp, which also TIMES shapes without a record (set-up: + 20-30 s on a
                                      # cold box) instead of replaying the rocBLAS records by solution index (r04 default)
-    dense_fused: int = 2             # relu(x . W^T) (1), also (g (.) mask) . W (2) as the package's own bf16-split MFMA kernels
-                                     # (gemm/pgcn_dense.hip, fp32 accuracy) instead of library GEMM + ReLU / mask passes; 0 = the library
-                                     # route.  r05 on the MI355X at n = 232 965, f = 128: forward 63.3 us against 85 + 35 us of rocBLAS +
-                                     # clamp, input gradient 116.8 us against 50 + 86 us (profiles/r05_dense_fused_variants.txt); epoch, three
-                                     # runs each on one box: 10.52 / 10.48 / 10.45 ms off, 10.46 / 10.42 / 10.46 forward only,
-                                     # 10.37 / 10.36 / 10.34 both (profiles/r05_dense_fused_epochs.txt) -> on since r05
-    layer_fused: int = 0             # r05, VERDICT r04 item 3 -- measured, NOT faster, off: a PGCN layer as ONE autograd node (PGCN._AggLinearRelu,
-                                     # needs dense_fused >= 2).  1: the backward re-associated (T = A^T.Gm, dH = T.W, dW = T^T.H: A.H is not kept
-                                     # for the backward) with the lower layer's ReLU mask folded into the input gradient; 2: + the aggregation's
-                                     # fix-up as the LOADER of both dense products (pgcn_fixup_linear_f32: A.H / T never round-trip), bit-identical
-                                     # forward.  Epochs on one MI355X (profiles/r05_layer_fused.txt): level 0 10.32-10.41 ms, level 1 10.35-10.43,
-                                     # level 2 10.33-10.42 (12.0 with every row through the folded loader: a wave's tile costs as many
-                                     # dependent round trips as its longest slot list, and the hub rows' lists have dozens of entries)
-    layer_fused_cap: int = 8         # level 2: rows with more partial rows than this go through the separate fix-up kernel
+    dense_fused: int = 3             # the dense products of a layer as the package's own bf16-split MFMA kernels (gemm/pgcn_dense.hip,
+                                     # pgcn_wgrad.hip; fp32 accuracy) instead of library GEMMs + ReLU / mask passes: 1 relu(x . W^T); 2 also
+                                     # (g (.) mask) . W, the mask travelling as 1 bit per element; 3 also the weight gradient gm^T . x (r06);
+                                     # 0 = the library route.  r05 on the MI355X at n = 232 965, f = 128: forward 63.3 us against 85 + 35 us
+                                     # of rocBLAS + clamp, input gradient 116.8 us against 50 + 86 us; epochs 10.52 / 10.48 / 10.45 ms off,
+                                     # 10.37 / 10.36 / 10.34 at level 2 (profiles/r05_dense_fused_epochs.txt); r06: DESIGN.md section 4
     # ---- GAT path -------------------------------------------------------------------------------------------
     gat_long_row: int = 1024         # rows above this get a 256-thread workgroup in the attention kernels
+    gat_small_row: int = 192         # gather plan of the attention structures (r05): a partial row there is heads x d = 1 KB wide, twice the GCN
+    gat_chunk: int = 8192            # path's, and every task of a split row leaves one: rows are sliced over the XCDs from 193 entries on (GCN: 97)
+                                     # and long rows cut into pieces of 8 192 (GCN: 1 024).  Reddit shape, 4 heads x 64, ms per epoch: 96 / 1 024
+                                     # 58.7; 192 / 1 024 55.5; 384 / 1 024 56.4; 192 / 2 048 54.2; 192 / 4 096 53.2; 192 / 8 192 52.8;
+                                     # 192 / 16 384 52.8; 320 / 8 192 52.9 (tools/probes_r05/p20_gat_plan.sh)
     gat_sliced: bool = True          # XCD-sliced edge gradient
     gat_task_grad: bool = True       # edge gradient over the SpMM plan's balanced tasks
     gat_multihead: bool = True       # all heads of attention @ Z in one launch

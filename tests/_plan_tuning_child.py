@@ -28,7 +28,7 @@ def main():
         C = np.nan_to_num(C)
         for a in pt.A_halo:
             C, _ = run_plan(K.prepare(a), H[hg], C0=C, accumulate=True)
-        parts = "".join(ch for ch, blk in (("s", "strip"), ("c", "core"), ("d", "dense"), ("3", "dense3"))
+        parts = "".join(ch for ch, blk in (("s", "strip"), ("c", "core"), ("3", "dense3"))
                         if any(getattr(b, blk) is not None for b in [pt.A_loc] + list(pt.A_halo)))
         print("P=%d parts=%s rounds=%d err=%.3e" % (P, parts or "-", pt.rounds, np.abs(C - AH[own]).max()))
 

@@ -1,8 +1,10 @@
 // pgcn_dense_emu.cpp -- TEST INFRASTRUCTURE: a host build of the index arithmetic of gemm/pgcn_dense.hip.
-// The kernel's own functions (gemm/pgcn_dense_tile.h: LDS image slots of W, a lane's 16-byte pieces of a tile, the accumulator
-// layout, the argument checks) are run lane by lane around an emulated v_mfma_f32_32x32x16_bf16 whose operand layout is the one
-// csrc/pgcn_spmm_dense3.hip runs on hardware; the same C entry points as the library (include/pgcn_gemm.h) on HOST pointers, the
-// stream argument ignored.  tests/test_zz_dense_fused.py compiles this file with clang++ and binds it like the library.
+// The kernel's own functions (gemm/pgcn_dense_tile.h: LDS image slots of W, a lane's 16-byte pieces of a tile and their window
+// offsets, the accumulator layout, the sign-mask words, the argument checks) are run lane by lane around an emulated
+// v_mfma_f32_32x32x16_bf16 whose operand layout is the one csrc/pgcn_spmm_dense3.hip runs on hardware; the same C entry points as
+// the library (include/pgcn_gemm.h) on HOST pointers, the stream argument ignored.  tests/test_zz_dense_fused.py compiles this file
+// with clang++ and binds it like the library.  (The schedule of the device kernel -- what is in flight when -- is not emulated: only
+// which bytes a lane reads and writes and what it multiplies.)
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -40,101 +42,102 @@ void mfma_emu(const u32x4 (&a)[64], const u32x4 (&b)[64], f32x16 (&acc)[64]) {
     }
 }
 
-// One launch with the kernel's template parameters: the image as the kernel fills it, every tile loaded by the kernel's own
-// loaders (forward: load_tile; backward: load_half + mask_half, the two halves of a tile), stored by its store_c.
-// mode 2 (the fix-up folded into the product): the operand tiles come from sum_half, the epilogue may be the mask by M
-struct FixupArgs {
-    const RowFix *row_fix = nullptr;
-    const int32_t *slot_ids = nullptr;
-    const float *partial = nullptr;
-    int64_t ldp = 0;
-    const float *base = nullptr;
-    int64_t ldbase = 0;
-    float *S_out = nullptr;
-    int64_t lds = 0;
-    const float *M = nullptr;
-    int64_t ldm = 0;
-    int transposed = 1, epilogue = 0;
+struct EmuArgs {
+    const float *A;
+    int64_t lda;
+    const uint32_t *mask_in;
+    float *Gm;
+    int64_t ldgm;
+    uint32_t *mask_out;
+    int64_t n;
+    int K, N;
+    const float *W;
+    int64_t ldw;
+    int transposed;
+    float *C;
+    int64_t ldc;
+    int relu;
 };
 
-template <int NKS, int NBLK>
-int emulate(int mode, const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm, int64_t n, int K, int N,
-            const float *W, int64_t ldw, float *C, int64_t ldc, int relu, const FixupArgs *fx = nullptr) {
+// One launch with the kernel's template parameters: the image as the kernel fills it, every tile through the kernel's own windows,
+// loaders, mask arithmetic and stores.  MODE 0: forward; 1: input gradient.
+template <int NKS, int NBLK, int MODE, bool RAGGED>
+int emulate(const EmuArgs &a) {
     alignas(16) static char image[kImageBytes];
     memset(image, 0xff, sizeof image);                       // (slots the kernel does not fill must not be read)
+    const bool vec = slot_vec_ok(a.W, a.ldw, a.transposed, a.K);
     for (int s = 0; s < kSlotsPerPlane; ++s) {
         const int ks = s >> 8, nb = (s >> 6) & 3;
         if (ks < NKS && nb < NBLK) {
             float v[8];
-            slot_load(W, ldw, mode == 2 ? fx->transposed : mode == 0, K, N, s, v);
+            slot_load(a.W, a.ldw, a.transposed, a.K, a.N, s, v, vec);
             slot_store(image, s, v);
         }
     }
-    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const int64_t n = a.n, ntiles = (n + kRows - 1) / kRows;
+    const int K = a.K, N = a.N, mwK = mask_words(K), mwN = mask_words(N);
+    auto win_of = [&](const void *M, int64_t ld, int64_t t, int width) { return tile_window(M, ld, M ? n : 0, t * kRows, width); };
     for (int64_t tile = 0; tile < ntiles; ++tile) {
-        static TileA<NKS> t[64];
+        static u32x4 ap[NKS][3][64];
+        const window_t wa = win_of(a.A, a.lda, tile, K), wgm = win_of(a.Gm, a.ldgm, tile, K), wc = win_of(a.C, a.ldc, tile, N);
+        const window_t wmi = win_of(a.mask_in, mwK, tile, mwK), wmo = win_of(a.mask_out, mwN, tile, mwN);
         for (int lane = 0; lane < 64; ++lane) {
-            if (mode == 0) {
-                load_tile<NKS>(t[lane], A, lda, tile * kRows, n, K, lane);
-            } else if (mode == 2) {
-                constexpr int H = NKS / 2;
-                const int64_t row = tile * kRows + (lane & 31);
-                RowFix rf = {0, 0};
-                if (row < n) rf = fx->row_fix[row];
-                const int tmax = fx->partial ? (rf.count > 0 ? rf.count : 0) : 0;       // (the kernel: the wave's maximum)
-                for (int half = 0; half < 2; ++half) {
-                    f32x4 v[H][2];
-                    sum_half<H>(v, fx->partial, fx->ldp, fx->slot_ids, fx->base, fx->ldbase, row < n ? row : 0, rf, tmax, K, lane, half * H);
-                    if (fx->S_out) store_half<H>(v, fx->S_out, fx->lds, tile * kRows, n, K, lane, half * H);
-                    for (int i = 0; i < H; ++i) { t[lane].v[half * H + i][0] = v[i][0]; t[lane].v[half * H + i][1] = v[i][1]; }
+            const uint32_t a_off = piece_lane_offset(a.lda, lane), gm_off = piece_lane_offset(a.ldgm, lane);
+            uint32_t mwn[4];
+            const uint32_t no_mask = a.mask_in ? 0u : ~0u;
+            for (int q = 0; q < 4; ++q)
+                mwn[q] = (q < mwK ? win_load4u(wmi, (uint32_t)((lane & 31) * mwK * 4) + 4 * (q < mwK ? q : 0), 0) : 0u) | no_mask;
+            for (int ks = 0; ks < NKS; ++ks) {
+                f32x4 raw[2];
+                load_piece<RAGGED>(raw, wa, a_off, ks, K, lane);
+                if (MODE == 1) {
+                    for (int h = 0; h < 2; ++h) raw[h] = mask4_bits(raw[h], mwn[ks >> 1], ks, h, lane);
+                    store_piece<RAGGED>(raw, wgm, gm_off, ks, K, lane);
                 }
-            } else {
-                constexpr int H = NKS / 2;
-                for (int half = 0; half < 2; ++half) {
-                    HalfRaw<H> raw;
-                    f32x4 v[H][2];
-                    load_half<H>(raw, A, lda, Y, ldy, tile * kRows, n, K, lane, half * H);
-                    mask_half<H>(v, raw, Gm, ldgm, tile * kRows, n, K, lane, half * H);
-                    for (int i = 0; i < H; ++i) { t[lane].v[half * H + i][0] = v[i][0]; t[lane].v[half * H + i][1] = v[i][1]; }
-                }
+                u32x4 p[3];
+                split8(raw[0], raw[1], p);
+                for (int pl = 0; pl < 3; ++pl) ap[ks][pl][lane] = p[pl];
             }
         }
-        static f32x16 acc[NBLK][64];
-        for (int nb = 0; nb < NBLK; ++nb)
+        for (int nb = 0; nb < NBLK; ++nb) {
+            static f32x16 acc[64];
             for (int lane = 0; lane < 64; ++lane)
-                for (int r = 0; r < 16; ++r) acc[nb][lane][r] = 0.f;
-        for (int ks = 0; ks < NKS; ++ks) {
-            static u32x4 a[3][64], b[3][64];
-            for (int lane = 0; lane < 64; ++lane) {
-                u32x4 p[3];
-                split8(t[lane].v[ks][0], t[lane].v[ks][1], p);
-                for (int pl = 0; pl < 3; ++pl) a[pl][lane] = p[pl];
-            }
-            for (int nb = 0; nb < NBLK; ++nb) {
+                for (int r = 0; r < 16; ++r) acc[lane][r] = 0.f;
+            for (int ks = 0; ks < NKS; ++ks) {
+                static u32x4 b[3][64];
                 for (int lane = 0; lane < 64; ++lane)
                     for (int pl = 0; pl < 3; ++pl) memcpy(&b[pl][lane], image + image_offset(pl, ks, nb, lane), 16);
                 PGCN_DENSE_PRODUCTS;
-                for (int i = 0; i < 6; ++i) mfma_emu(a[kPA[i]], b[kPB[i]], acc[nb]);
+                for (int i = 0; i < 6; ++i) mfma_emu(ap[ks][kPA[i]], b[kPB[i]], acc);
             }
-        }
-        for (int lane = 0; lane < 64; ++lane) {
-            f32x16 mine[NBLK];
-            for (int nb = 0; nb < NBLK; ++nb) mine[nb] = acc[nb][lane];
-            if (mode == 2 && fx->epilogue == 2) store_c_masked(mine, NBLK, C, ldc, fx->M, fx->ldm, tile * kRows, n, N, lane);
-            else store_c(mine, NBLK, C, ldc, tile * kRows, n, N, lane, mode == 2 ? fx->epilogue : relu);
+            for (int lane = 0; lane < 64; ++lane)
+                store_regs<RAGGED>(acc[lane], 0, 16, nb, wc, acc_lane_offset(a.ldc, lane), (uint32_t)(a.ldc * 4), N, lane, a.relu);
+            if (MODE == 0) {
+                // the device: ballot of (register r > 0) over the wave, word of (r, h) collected in lane 16 h + r, lanes < 32 store
+                uint32_t mword[64] = {0};
+                for (int r = 0; r < 16; ++r) {
+                    uint64_t bal = 0;
+                    for (int lane = 0; lane < 64; ++lane) bal |= (uint64_t)(mask_bit_of(acc[lane][r]) ? 1 : 0) << lane;
+                    mword[r] = (uint32_t)bal;
+                    mword[16 + r] = (uint32_t)(bal >> 32);
+                }
+                for (int lane = 0; lane < 32; ++lane)
+                    if (nb < mwN) win_store4u(wmo, (uint32_t)(mask_row_of_lane(lane) * mwN * 4) + 4 * nb, 0, mword[lane]);
+            }
         }
     }
     return 0;
 }
-}  // namespace
 
-// mode 0: C = [relu](A . W^T), W: N x K;  mode 1: Gm = A (.) [Y > 0] (when Gm), C = Gm . W, W: K x N.
-static int emulate_any(int mode, const float *A, int64_t lda, const float *Y, int64_t ldy, float *Gm, int64_t ldgm, int64_t n, int K,
-                       int N, const float *W, int64_t ldw, float *C, int64_t ldc, int relu, const FixupArgs *fx = nullptr) {
-    if (K <= 0 || N <= 0 || K > kMaxF || N > kMaxF || K % 4) return -2;
-    const int nks = (K + 15) / 16, nblk = (N + 31) / 32;      // the kernel's own choice of instantiation (its dispatch())
-#define PGCN_DENSE_CASE(KS, NB) \
-    if (nks <= KS && nblk <= NB) return emulate<KS, NB>(mode, A, lda, Y, ldy, Gm, ldgm, n, K, N, W, ldw, C, ldc, relu, fx);
+template <int MODE>
+int emulate_any(const EmuArgs &a) {
+    if (a.K <= 0 || a.N <= 0 || a.K > kMaxF || a.N > kMaxF || a.K % 4) return -2;
+    const int nks = (a.K + 15) / 16, nblk = (a.N + 31) / 32;      // the kernel's own choice of instantiation (its dispatch())
+#define PGCN_DENSE_CASE(KS, NB)                                                    \
+    if (nks <= KS && nblk <= NB) {                                                 \
+        if (a.K == 16 * KS && a.N == 32 * NB) return emulate<KS, NB, MODE, false>(a); \
+        return emulate<KS, NB, MODE, true>(a);                                     \
+    }
     PGCN_DENSE_CASE(4, 2)
     PGCN_DENSE_CASE(4, 4)
     PGCN_DENSE_CASE(8, 2)
@@ -142,56 +145,43 @@ static int emulate_any(int mode, const float *A, int64_t lda, const float *Y, in
 #undef PGCN_DENSE_CASE
     return -2;
 }
+}  // namespace
 
 // ---- the C ABI of include/pgcn_gemm.h: the library's checks in front of the emulator ------------------------------------------
 extern "C" const char *pgcn_dense_last_error(void) { return pgcn_dense::g_err; }
 
 extern "C" int pgcn_linear_relu_f32(const float *X, int64_t ldx, int64_t n, int32_t fin, const float *W, int64_t ldw, int32_t fout,
-                                    float *Y, int64_t ldy, int32_t relu, void *) {
+                                    float *Y, int64_t ldy, int32_t relu, uint32_t *mask, void *) {
     if (int rc = check(X, ldx, n, fin, fout, W, ldw, fout, fin, Y, ldy)) return rc;
     if (n == 0) return 0;
-    return emulate_any(0, X, ldx, nullptr, 0, nullptr, 0, n, fin, fout, W, ldw, Y, ldy, relu ? 1 : 0);
+    EmuArgs a{};
+    a.A = X; a.lda = ldx; a.mask_out = mask; a.n = n; a.K = fin; a.N = fout; a.W = W; a.ldw = ldw; a.transposed = 1; a.C = Y; a.ldc = ldy;
+    a.relu = relu ? 1 : 0;
+    return emulate_any<0>(a);
 }
 
-extern "C" int pgcn_linear_relu_grad_input_f32(const float *G, int64_t ldg, const float *Y, int64_t ldy, float *Gm, int64_t ldgm,
-                                               int64_t n, int32_t fout, const float *W, int64_t ldw, int32_t fin, float *dX,
-                                               int64_t lddx, void *) {
+extern "C" int pgcn_linear_relu_grad_input_f32(const float *G, int64_t ldg, const uint32_t *mask, float *Gm, int64_t ldgm, int64_t n,
+                                               int32_t fout, const float *W, int64_t ldw, int32_t fin, float *dX, int64_t lddx, void *) {
     if (int rc = check(G, ldg, n, fout, fin, W, ldw, fout, fin, dX, lddx)) return rc;
-    if (!Y && n > 0) return fail(-1, "pgcn_linear_relu_grad_input_f32: Y is NULL");
-    if (ldy % 4 || (uintptr_t)Y % 16 || ldy < fout) return fail(-2, "pgcn_dense: rows of Y must be 16-byte pieces");
     if (Gm && (ldgm % 4 || (uintptr_t)Gm % 16 || ldgm < fout)) return fail(-2, "pgcn_dense: rows of Gm must be 16-byte pieces");
     if (n == 0) return 0;
-    return emulate_any(1, G, ldg, Y, ldy, Gm, ldgm, n, fout, fin, W, ldw, dX, lddx, 0);
+    EmuArgs a{};
+    a.A = G; a.lda = ldg; a.mask_in = mask; a.Gm = Gm; a.ldgm = ldgm; a.n = n; a.K = fout; a.N = fin; a.W = W; a.ldw = ldw; a.transposed = 0;
+    a.C = dX; a.ldc = lddx; a.relu = 0;
+    return emulate_any<1>(a);
 }
 
-extern "C" int pgcn_fixup_linear_f32(const int32_t *row_fix, const int32_t *slot_ids, const float *partial, int64_t ldp,
-                                     const float *base, int64_t ldbase, int64_t n, int32_t k, const float *W, int64_t ldw,
-                                     int32_t wrows, int32_t wcols, int32_t transposed, float *S_out, int64_t lds, const float *M,
-                                     int64_t ldm, float *C, int64_t ldc, int32_t epilogue, void *) {
-    if (wrows <= 0 || wcols <= 0 || (transposed ? wcols : wrows) != k) return fail(-1, "pgcn_fixup_linear_f32: W does not match the width of S");
-    const int N = transposed ? wrows : wcols;
-    if (int rc = check_fixup(row_fix, partial, ldp, base, ldbase, n, k, N, W, ldw, wcols, S_out, lds, M, ldm, C, ldc, epilogue)) return rc;
-    if (n == 0) return 0;
-    FixupArgs fx;
-    fx.row_fix = reinterpret_cast<const RowFix *>(row_fix); fx.slot_ids = slot_ids; fx.partial = partial; fx.ldp = ldp; fx.base = base;
-    fx.ldbase = ldbase; fx.S_out = S_out; fx.lds = lds; fx.M = M; fx.ldm = ldm; fx.transposed = transposed ? 1 : 0; fx.epilogue = epilogue;
-    return emulate_any(2, nullptr, 0, nullptr, 0, nullptr, 0, n, k, N, W, ldw, C, ldc, 0, &fx);
-}
-
-extern "C" int pgcn_linear_epilogue_f32(const float *X, int64_t ldx, int64_t n, int32_t k, const float *W, int64_t ldw, int32_t wrows,
-                                        int32_t wcols, int32_t transposed, const float *M, int64_t ldm, float *C, int64_t ldc,
-                                        int32_t epilogue, void *) {
-    if (wrows <= 0 || wcols <= 0 || (transposed ? wcols : wrows) != k || epilogue < 0 || epilogue > 2)
-        return fail(-1, "pgcn_linear_epilogue_f32: W does not match the width of X / bad epilogue");
-    const int N = transposed ? wrows : wcols;
-    if (int rc = check(X, ldx, n, k, N, W, ldw, wrows, wcols, C, ldc)) return rc;
-    if (epilogue == 2 && (!M || ldm < N)) return fail(-1, "pgcn_linear_epilogue_f32: the mask epilogue needs M");
-    if (n == 0) return 0;
-    // (the kernel's plain loader = load_tile; emulated through the fix-up path with every row taken from `base`: the same pieces)
-    static RowFix *all_base = nullptr;
-    static int64_t cap = 0;
-    if (n > cap) { delete[] all_base; all_base = new RowFix[n]; cap = n; for (int64_t i = 0; i < n; ++i) all_base[i] = RowFix{0, -1}; }
-    FixupArgs fx;
-    fx.row_fix = all_base; fx.base = X; fx.ldbase = ldx; fx.M = M; fx.ldm = ldm; fx.transposed = transposed ? 1 : 0; fx.epilogue = epilogue;
-    return emulate_any(2, nullptr, 0, nullptr, 0, nullptr, 0, n, k, N, W, ldw, C, ldc, 0, &fx);
+extern "C" int pgcn_sign_mask_f32(const float *Y, int64_t ldy, int64_t n, int32_t N, uint32_t *mask, void *) {
+    if (n < 0 || N <= 0 || ldy < N || (n > 0 && (!Y || !mask))) return fail(-1, "pgcn_sign_mask_f32: bad argument");
+    const int mw = (N + 31) / 32;
+    for (int64_t row = 0; row < n; ++row)
+        for (int w = 0; w < mw; ++w) {
+            uint32_t bits = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int c = 32 * w + b;
+                if (c < N && mask_bit_of(Y[row * ldy + c])) bits |= 1u << b;
+            }
+            mask[row * mw + w] = bits;
+        }
+    return 0;
 }

@@ -76,7 +76,7 @@ class PlanKernels(OracleKernels):
         from plan_interpreter import run_plan
         if A.nrows == 0:
             return C
-        if A.col.numel() == 0 and A.core is None and A.dense is None and A.strip is None:
+        if A.col.numel() == 0 and A.core is None and A.strip is None:
             if not accumulate:                       # an empty block: C = 0 (kernels._bind_spmm does the same without a launch)
                 (C[:A.nrows] if A.row_map is None else C[A.row_map.long()]).zero_()
             return C
@@ -98,7 +98,7 @@ class _CpuGat(_CpuCSR):
         assert np.array_equal(listed, np.arange(self.nrows)), "every row must be in exactly one list"
 
 
-def _prepare_gat(self, csr, rows_wave, rows_block):
+def _prepare_gat(self, csr, rows_wave, rows_block, chunk=None, small_row=None):
     assert csr.core is None and csr.row_map is None
     return _CpuGat(csr, rows_wave, rows_block)
 

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE: a numpy walk of the launch group's DATA STRUCTURES, exactly as include/pgcn_hip.h documents them.
 
 The HIP kernels consume a host-built plan: gather tasks + fix records (pgcn_spmm_plan_host), strip records
-(partition.build_strips), LDS-core tiles, MFMA tiles (partition.build_dense) and the combined per-row slot lists
+(partition.build_strips), LDS-core tiles, bf16 blocks (partition.build_dense3) and the combined per-row slot lists
 (kernels.HipKernels._attach_core).  Everything up to the upload is host code, and a wrong offset in it only shows on a
 GPU.  ``HostPlanner`` runs that host code without a device (it borrows ``HipKernels.prepare`` / ``_attach_core``
 unchanged -- they only need ``self.device``), ``run_plan`` then executes the plan the way the kernels are specified to:
@@ -18,20 +18,19 @@ PKG = "scalable-graph-convolutional-network-training-on-distributed-memory-syste
 class HostPlanner:
     """The host half of ``HipKernels`` (plan building, slot lists), tensors left on the CPU."""
 
-    def __init__(self, chunk=None, small_row=None, adaptive_chunk=None, pair_row=None):
+    def __init__(self, chunk=None, small_row=None, adaptive_chunk=None):
         k = importlib.import_module(PKG + ".kernels")
         self.device = torch.device("cpu")
         self.chunk = k.DEFAULT_CHUNK if chunk is None else chunk
         self.small_row = k.DEFAULT_SMALL_ROW if small_row is None else small_row
         self.adaptive_chunk = k._T.spmm_adaptive_chunk if adaptive_chunk is None else adaptive_chunk
         self._k = k
-        self.pair_row = pair_row
 
-    def prepare(self, csr, pattern_only=False, pair_row=None):
-        return self._k.HipKernels.prepare(self, csr, pattern_only, pair_row)
+    def prepare(self, csr, pattern_only=False, chunk=None, small_row=None):
+        return self._k.HipKernels.prepare(self, csr, pattern_only, chunk, small_row)
 
-    def prepare_gat(self, csr, rows_wave, rows_block):
-        return self._k.HipKernels.prepare_gat(self, csr, rows_wave, rows_block)
+    def prepare_gat(self, csr, rows_wave, rows_block, chunk=None, small_row=None):
+        return self._k.HipKernels.prepare_gat(self, csr, rows_wave, rows_block, chunk, small_row)
 
     def _attach_core(self, d, csr, fix_rem):
         return self._k.HipKernels._attach_core(self, d, csr, fix_rem)
@@ -41,7 +40,7 @@ def _np(t):
     return None if t is None else t.detach().cpu().numpy()
 
 
-def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None, pair_row=0):
+def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None):
     """C (+)= A . B by walking the device-side arrays of ``d`` (a DeviceCSR whose tensors live on the CPU).
     Returns (C, info); rows nobody wrote stay NaN when ``accumulate`` is False (the caller decides what they must be).
     ``slice_of(cols)``: the slice of a column when the block was built with range slices (default col % nslices)."""
@@ -65,7 +64,7 @@ def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None, pair_r
         o = out_row(r)
         C[o] = (C[o] + s) if accumulate else s
 
-    tiled = d.core is not None or d.dense is not None or d.strip is not None or getattr(d, "dense3", None) is not None
+    tiled = d.core is not None or d.strip is not None or getattr(d, "dense3", None) is not None
     # ---- gather part -----------------------------------------------------------------------------------------
     if d.tasks is None:                                  # one task per row, no plan (pgcn_spmm_csr_f32)
         for r in range(d.nrows):
@@ -90,11 +89,7 @@ def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None, pair_r
                     if d.nslices > 1:       # a task of segment s stays inside slice s of its row -- or is a whole short row
                         whole = k0 == rowptr[rows[0]] and k0 + length == rowptr[rows[0] + 1]
                         sls = col[sl] % d.nslices if slice_of is None else slice_of(col[sl])
-                        rowlen = rowptr[rows[0] + 1] - rowptr[rows[0]]
-                        if pair_row and rowlen <= pair_row:   # (tuning.spmm_pair_row: a task of a PAIR of adjacent slices, on either's segment)
-                            assert whole or ((sls // 2 == s // 2).all() and s == 2 * (s // 2) + (rows[0] & 1))
-                        else:
-                            assert whole or (sls == s).all()
+                        assert whole or (sls == s).all()
                 acc = (val[sl, None] * B[col[sl]]).sum(0)
                 if dst >= 0:
                     assert np.isnan(ws[dst]).all(), "two tasks share a partial-sum slot"
@@ -165,24 +160,6 @@ def run_plan(d, B, C0=None, accumulate=False, checks=True, slice_of=None, pair_r
                         assert (cols < d.ncols).all()
                         acc[rit[q]] += (cval[a:b, None] * B[cols]).sum(0)
                         info["entries_core"] += int(b - a)
-            assert np.isnan(ws[slot0:slot0 + TR]).all()
-            ws[slot0:slot0 + TR] = acc
-    # ---- MFMA tiles (pgcn_spmm_dense_f32): A-operand order of v_mfma_f32_32x32x2_f32 -------------------------
-    if d.dense is not None:
-        TR = part.CORE_TR
-        de = d.dense
-        work, tp, vals = _np(de.work), _np(de.tile_panel), _np(de.vals).astype(np.float64)
-        i, k = np.meshgrid(np.arange(128), np.arange(128), indexing="ij")
-        idx = ((i // 32 * 16 + (k // 2) // 4) * 64 + (k % 2) * 32 + i % 32) * 4 + (k // 2) % 4
-        for tr, first, cnt, slot0 in work:
-            acc = np.zeros((TR, f))
-            for t in range(first, first + cnt):
-                tile = vals[t][idx]                                        # [row in tile, column in panel]
-                c0 = int(tp[t]) * 128
-                w = min(128, d.ncols - c0)
-                assert w > 0 and not tile[:, w:].any(), "values beyond the last column of the block"
-                acc += tile[:, :w] @ B[c0:c0 + w]
-                info["entries_dense"] += int((tile != 0).sum())
             assert np.isnan(ws[slot0:slot0 + TR]).all()
             ws[slot0:slot0 + TR] = acc
     # ---- bf16 three-plane blocks (pgcn_spmm_dense_bf16x3_f32): 512 x 128, A-operand order of v_mfma_f32_32x32x16_bf16 ----

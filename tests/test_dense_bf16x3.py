@@ -58,7 +58,7 @@ def test_blocks_are_stored_in_the_a_operand_order_of_the_bf16_mfma():
     D[600:, 300:] *= rng.random((500, 400)) < 0.1
     h = partition.csr_from_scipy(sp.coo_matrix(D), nslices=1, core=True, strip=True, strip_min=32, dense3_tau=0.2)
     hd = h.dense3
-    assert hd is not None and h.dense is None and h.nnz == int((D != 0).sum())
+    assert hd is not None and h.nnz == int((D != 0).sum())
     nb = hd.vals3.shape[0]
     assert tuple(hd.vals3.shape) == (nb, 512 * 128) and hd.vals3.dtype == torch.float32
     Dp = np.zeros((1536, 768), np.float32); Dp[:n, :m] = D

@@ -140,8 +140,8 @@ def test_csr_from_coo_with_strips_keeps_every_entry():
     D[:256, :256] = (rng.random((256, 256)) < 0.5) * 1.0
     A = sp.csr_matrix(D.astype(np.float32))
     for nslices in (1, 8):
-        h = partition.csr_from_scipy(A, nslices=nslices, core=True, dense_tau=0.2, strip=True, strip_min=32)
-        assert h.strip is not None and h.dense is not None and h.core is None and h.nnz == A.nnz
+        h = partition.csr_from_scipy(A, nslices=nslices, core=True, dense3_tau=2.0, strip=True, strip_min=32)
+        assert h.strip is not None and h.dense3 is None and h.core is None and h.nnz == A.nnz
         r, c, v = h.to_coo()
         B = sp.csr_matrix((v.numpy(), (r.numpy(), c.numpy())), shape=A.shape)
         assert (abs(B - A) > 0).nnz == 0

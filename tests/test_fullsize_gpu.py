@@ -93,7 +93,7 @@ def _check_rank(K, dev, n, row, col, val, partvec, r, P, X, G, sample=400, oracl
     eng = engine.AggregationEngine(p, K, dev, ex)
     if need_tiles:                          # the tiled kernels take part at this size (a small LOCAL block of an 8-way
         blocks = [eng.A_loc] + list(eng.A_halo)   # shard runs gather-only since r03; its halo block is tiled)
-        assert any(a.strip is not None or a.dense is not None for a in blocks)
+        assert any(a.strip is not None or a.dense3 is not None for a in blocks)
     own = p.owned.to(dev)
     pv = partvec.to(dev)
     gen = torch.Generator(device=dev)

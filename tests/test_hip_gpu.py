@@ -136,7 +136,7 @@ def test_spmm_dense_core_lds_kernel(K, dev, f, nslices):
     assert h.core is not None and h.core.nnz > 0.2 * A.nnz and h.ngroups == (3 if nslices > 1 else 1)
     d = K.prepare(h)
     assert d.core is not None
-    assert d.nslots_total == d.nslots + h.core.nslots + sum(x.nslots for x in (h.dense, h.dense3) if x is not None)
+    assert d.nslots_total == d.nslots + h.core.nslots + (h.dense3.nslots if h.dense3 is not None else 0)
     rng = np.random.default_rng(f)
     B = rng.random((n, f), dtype=np.float32) * 2 - 1
     ref = oracle.spmm(A, B)
@@ -162,64 +162,6 @@ def test_spmm_dense_core_lds_kernel(K, dev, f, nslices):
         assert np.isfinite(C4.cpu().numpy()).all()
 
 
-@pytest.mark.parametrize("f", [4, 30, 64, 128, 132, 256])
-@pytest.mark.parametrize("nslices", [1, 8])
-def test_spmm_mfma_dense_tiles(K, dev, f, nslices):
-    """The densest tiles go through the fp32 matrix cores (pgcn_spmm_dense_f32), the rest through the
-    LDS core and the gather kernel; one fix-up.  Same tolerance as every other SpMM path; zeros of a
-    dense tile stay structural when the panel holds Inf."""
-    partition = pkg("partition")
-    rng = np.random.default_rng(f + nslices)
-    n, m = 700, 520
-    D = (rng.random((n, m)) < 0.02).astype(np.float32)
-    D[:256, :256] = rng.random((256, 256)) < 0.6
-    D[256:384, :128] = rng.random((128, 128)) < 0.12
-    D[640:, 384:] = rng.random((60, 136)) < 0.5
-    D[5, :] = 0                                              # an empty row inside a dense tile
-    D[:, 300] = 0                                            # a column nobody references
-    D *= rng.standard_normal((n, m)).astype(np.float32)
-    A = sp.csr_matrix(D)
-    h = partition.csr_from_scipy(A, nslices=nslices, core=True, tau=0.05, emax=3000, dense_tau=0.2,
-                                 ngroups=2 if nslices > 1 else None, strip=False)
-    assert h.dense is not None and h.dense.tile_row.numel() == 5 and h.core is not None
-    d = K.prepare(h)
-    assert d.dense is not None and d.nslots_total == d.nslots + h.core.nslots + h.dense.nslots
-    B = rng.random((m, f), dtype=np.float32) * 2 - 1
-    ref = oracle.spmm(A, B)
-    Bd = torch.from_numpy(B).to(dev)
-    C = torch.full((n, f), float("nan"), device=dev)
-    K.spmm(d, Bd, C)
-    torch.cuda.synchronize()
-    assert rel_err(C.cpu().numpy(), ref) < TOL
-    C2 = torch.full((n, f), float("nan"), device=dev)
-    K.spmm(d, Bd, C2)
-    assert torch.equal(C, C2)                                # deterministic
-    base = rng.random((n, f), dtype=np.float32)
-    C3 = torch.from_numpy(base).to(dev)
-    K.spmm(d, Bd, C3, accumulate=True)
-    assert rel_err(C3.cpu().numpy(), ref + base) < TOL
-    # a panel with an odd leading dimension / unaligned base takes the scalar staging path
-    wide = torch.zeros((m, f + 3), device=dev)
-    wide[:, 1:f + 1] = Bd
-    C4 = torch.full((n, f), float("nan"), device=dev)
-    K.spmm(d, wide[:, 1:f + 1], C4)
-    assert rel_err(C4.cpu().numpy(), ref) < TOL
-    # Inf in a feature row no entry references: nothing leaks.  Inf in a referenced row: exactly the
-    # rows with an entry in that column see it (the exact path multiplies only where A != 0).
-    B2 = B.copy(); B2[300] = np.inf
-    C5 = torch.empty((n, f), device=dev)
-    K.spmm(d, torch.from_numpy(B2).to(dev), C5)
-    assert np.isfinite(C5.cpu().numpy()).all() and rel_err(C5.cpu().numpy(), ref) < TOL
-    B3 = B.copy(); B3[17, 0] = np.inf
-    C6 = torch.empty((n, f), device=dev)
-    K.spmm(d, torch.from_numpy(B3).to(dev), C6)
-    got = C6.cpu().numpy()
-    hit = np.asarray(A[:, 17].todense()).ravel() != 0
-    assert hit.sum() > 100                                   # column 17 crosses the dense tiles
-    assert np.isinf(got[hit, 0]).all() and np.isfinite(got[~hit]).all() and np.isfinite(got[:, 1:]).all()
-    assert rel_err(got[:, 1:], ref[:, 1:]) < TOL
-
-
 @pytest.mark.parametrize("f", [4, 30, 64, 100, 128, 132, 256])
 @pytest.mark.parametrize("nslices", [1, 8])
 def test_spmm_bf16x3_blocks(K, dev, f, nslices):
@@ -239,7 +181,7 @@ def test_spmm_bf16x3_blocks(K, dev, f, nslices):
     D *= (rng.standard_normal((n, m)) * np.exp(rng.standard_normal((n, 1)))).astype(np.float32)      # rows of different scale
     A = sp.csr_matrix(D)
     h = partition.csr_from_scipy(A, nslices=nslices, core=True, strip=True, strip_min=32, dense3_tau=0.2)
-    assert h.dense3 is not None and h.dense3.blk_row.tolist() == [0, 0, 0, 1, 2] and h.dense is None and h.nnz == A.nnz
+    assert h.dense3 is not None and h.dense3.blk_row.tolist() == [0, 0, 0, 1, 2] and h.nnz == A.nnz
     d = K.prepare(h)
     assert d.dense3 is not None and d.nslots_total >= d.nslots + h.dense3.nslots
     B = (rng.random((m, f), dtype=np.float32) * 2 - 1) * np.exp(rng.standard_normal((m, 1))).astype(np.float32)
@@ -350,13 +292,13 @@ def test_spmm_strip_tiles(K, dev, f, nslices):
     D[:, 300] = 0                                                    # a column nobody references
     D *= rng.standard_normal((n, m)).astype(np.float32)
     A = sp.csr_matrix(D)
-    h = partition.csr_from_scipy(A, nslices=nslices, core=True, dense_tau=0.2, strip=True, strip_min=64)
-    assert h.strip is not None and h.core is None and h.dense is not None
+    h = partition.csr_from_scipy(A, nslices=nslices, core=True, dense3_tau=2.0, strip=True, strip_min=64)
+    assert h.strip is not None and h.core is None and h.dense3 is None
     assert int(h.strip.rec[:, 3].max()) >= 4 and h.strip.rec.shape[0] >= 9      # tiles of several layers
     assert h.strip.nnz > 0.4 * A.nnz and h.col.numel() > 0
     assert h.nnz == A.nnz
     d = K.prepare(h)
-    assert d.strip is not None and d.nslots_total == d.nslots + h.strip.nslots + h.dense.nslots
+    assert d.strip is not None and d.nslots_total == d.nslots + h.strip.nslots
     B = rng.random((m, f), dtype=np.float32) * 2 - 1
     ref = oracle.spmm(A, B)
     Bd = torch.from_numpy(B).to(dev)
@@ -406,8 +348,8 @@ def test_spmm_feature_passes_bit_identical(K, dev):
     D[40, :] = rng.random(m) < 0.7                                   # a hub row: several gather tasks per slice
     D *= rng.standard_normal((n, m)).astype(np.float32)
     A = sp.csr_matrix(D)
-    h = partition.csr_from_scipy(A, nslices=8, core=True, dense_tau=0.3, strip=True, strip_min=64)
-    assert h.strip is not None and h.dense is not None and h.col.numel() > 0
+    h = partition.csr_from_scipy(A, nslices=8, core=True, dense3_tau=2.0, strip=True, strip_min=64)
+    assert h.strip is not None and h.col.numel() > 0
     d = K.prepare(h)
     Bd = torch.from_numpy(rng.random((m, f), dtype=np.float32) * 2 - 1).to(dev)
     flags0 = K.base_flags
@@ -443,7 +385,7 @@ def test_spmm_strip_pieces_and_panel_reuse(K, dev):
     assert 3 <= st.npieces <= 8 and int(st.rec[:, 1].sum()) > 0       # some records reuse the staged panel
     first_recs = st.work[:, 1].long()
     assert bool((st.rec[first_recs, 1] == 0).all())                   # ... but never the first of a piece
-    h = partition.csr_from_scipy(A, nslices=1, core=True, dense_tau=2.0, strip=True, strip_min=1)
+    h = partition.csr_from_scipy(A, nslices=1, core=True, dense3_tau=2.0, strip=True, strip_min=1)
     d = K.prepare(h)
     B = rng.random((m, f), dtype=np.float32) * 2 - 1
     C = torch.full((n, f), float("nan"), device=dev)

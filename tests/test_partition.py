@@ -181,44 +181,30 @@ def test_synthetic_graph_is_normalised_symmetric():
     assert torch.equal(row, r2) and torch.equal(val, v2)
 
 
-def test_mfma_tiles_layout_and_bookkeeping():
-    """The densest tiles are stored dense in the A-operand order of v_mfma_f32_32x32x2_f32
-    (vals[t][w][s4][lane][e] = A[32 w + (lane & 31)][2 (4 s4 + e) + (lane >> 5)]): un-swizzling gives back
-    exactly the entries, every entry lives in exactly one of the three parts, pieces tile the tiles."""
-    partition = pkg("partition")
-    rng = np.random.default_rng(4)
-    n, m = 700, 520
-    D = (rng.random((n, m)) < 0.02).astype(np.float32)
-    D[:256, :256] = rng.random((256, 256)) < 0.6            # 4 MFMA tiles
-    D[256:384, :128] = rng.random((128, 128)) < 0.12        # an LDS-core tile
-    D[640:, 384:] = rng.random((60, 136)) < 0.5             # ragged corner: 60 x 128 (dense) and 60 x 8 (sparse)
-    D *= rng.standard_normal((n, m)).astype(np.float32)
-    A = sp.coo_matrix(D)
-    h = partition.csr_from_scipy(A, nslices=1, core=True, tau=0.05, emax=3000, dense_tau=0.2, strip=False)
-    assert h.dense is not None and h.core is not None and h.col.numel() > 0
-    hd = h.dense
-    nt = hd.tile_row.numel()
-    assert nt == 5 and h.nnz == A.nnz and hd.nnz + h.core.nnz + h.col.numel() == A.nnz
-    i, k = np.meshgrid(np.arange(128), np.arange(128), indexing="ij")
-    idx = ((i // 32 * 16 + (k // 2) // 4) * 64 + (k % 2) * 32 + i % 32) * 4 + (k // 2) % 4
-    assert np.array_equal(np.sort(idx.ravel()), np.arange(128 * 128))            # a permutation of the tile
-    vals = hd.vals.numpy()
-    Dp = np.zeros((768, 640), np.float32); Dp[:n, :m] = D
-    for t in range(nt):
-        tr, tp = int(hd.tile_row[t]), int(hd.tile_panel[t])
-        np.testing.assert_array_equal(vals[t][idx], Dp[tr * 128:(tr + 1) * 128, tp * 128:(tp + 1) * 128])
-    work = hd.work.numpy()
-    assert sorted(np.concatenate([np.arange(b, b + c) for _, b, c, _ in work]).tolist()) == list(range(nt))
-    assert np.array_equal(np.sort(work[:, 3]), np.arange(len(work)) * 128)       # one 128-row slot block per piece
-    for tr_, b, c, _ in work:
-        assert (hd.tile_row.numpy()[b:b + c] == tr_).all() and c <= 16
-    # the whole block is what went in
-    r, c, v = h.to_coo()
-    got = sp.coo_matrix((v.numpy(), (r.numpy(), c.numpy())), shape=(n, m)).toarray()
-    np.testing.assert_array_equal(got, D)
-    # rows of MFMA / core tiles are flagged (their gather-part sums go through the fix-up)
-    flagged = np.nonzero(h.row_flags.numpy())[0]
-    assert set(flagged) == set(range(0, 384)) | set(range(640, 700))
-    # switched off: everything dense goes to the LDS core
-    h2 = partition.csr_from_scipy(A, nslices=1, core=True, tau=0.05, emax=3000, dense_tau=2.0, strip=False)
-    assert h2.dense is None and h2.core.nnz == hd.nnz + h.core.nnz
+
+
+def test_single_rank_symmetric_block_shares_its_transpose():
+    """r06: at P = 1 a matrix that equals its transpose entry for entry (bit-compared, duplicates included) builds ONE set of
+    structures (A_loc_T is A_loc); an unsymmetric one, or one whose values differ in the last bit, builds both."""
+    partition, synth = pkg("partition"), pkg("synth")
+    n, row, col, val = synth.make_graph(900, 20000, seed=3)
+    pv = torch.zeros(n, dtype=torch.int64)
+    p = partition.build_partition(row, col, val, n, pv, 0, 1)
+    assert p.A_loc_T is p.A_loc
+    np.testing.assert_array_equal(_dense(p.A_loc), _dense(p.A_loc).T)
+    v2 = val.clone()
+    k = int(torch.nonzero(row != col)[0])
+    v2[k] = torch.nextafter(v2[k], torch.tensor(2.0))                 # one entry off by an ulp: no longer its own transpose
+    q = partition.build_partition(row, col, v2, n, pv, 0, 1)
+    assert q.A_loc_T is not q.A_loc
+    np.testing.assert_array_equal(_dense(q.A_loc_T), _dense(q.A_loc).T)
+    keep = ~((row == row[k]) & (col == col[k]))                       # an unsymmetric pattern
+    u = partition.build_partition(row[keep], col[keep], val[keep], n, pv, 0, 1)
+    assert u.A_loc_T is not u.A_loc
+    # two ranks: never shared (the local block of a rank is square but its transpose is built with the halo logic)
+    p2 = partition.build_partition(row, col, val, n, synth.random_partvec(n, 2, seed=0), 0, 2)
+    assert p2.A_loc_T is not p2.A_loc
+    # duplicates stored in another order on the two sides still count as symmetric
+    r = torch.tensor([0, 1, 0, 1, 0, 1]); c = torch.tensor([1, 0, 1, 0, 0, 1]); v = torch.tensor([1.0, 2.0, 2.0, 1.0, 5.0, 6.0])
+    assert partition._coo_is_symmetric(r, c, v, 2)
+    assert not partition._coo_is_symmetric(r, c, torch.tensor([1.0, 2.0, 2.0, 3.0, 5.0, 6.0]), 2)

@@ -34,17 +34,15 @@ def _power_law_block(n=3000, nnz=300000, seed=4):
 
 VARIANTS = {
     # name: (csr_from_coo arguments, planner arguments, parts that must be present)
-    "strips+mfma": (dict(nslices=8, core=True, strip=True, strip_min=64, dense_tau=0.2), {}, ("strip", "dense")),
     "strips+bf16x3": (dict(nslices=8, core=True, strip=True, strip_min=64, dense3_tau=0.12), {}, ("strip", "dense3")),
-    "strips_only": (dict(nslices=8, core=True, strip=True, strip_min=64, dense_tau=2.0), {}, ("strip",)),
-    "core+mfma": (dict(nslices=8, core=True, strip=False, tau=0.05, emax=5000, dense_tau=0.3), {}, ("core", "dense")),
+    "strips_only": (dict(nslices=8, core=True, strip=True, strip_min=64, dense3_tau=2.0), {}, ("strip",)),
+    "core_only": (dict(nslices=8, core=True, strip=False, tau=0.05, emax=5000, dense3_tau=2.0), {}, ("core",)),
     "gather_sliced": (dict(nslices=8, core=False), {}, ()),
     "gather_sliced_short_tasks": (dict(nslices=8, core=False), dict(chunk=64, small_row=16, adaptive_chunk=False), ()),
     "gather_unsliced_long_rows": (dict(nslices=1, core=False), dict(chunk=128, adaptive_chunk=False), ()),
     "gather_column_groups": (dict(nslices=8, core=False, ngroups=4), {}, ()),
-    "gather_slice_pairs": (dict(nslices=8, core=False), dict(small_row=16, pair_row=200, adaptive_chunk=False), ()),
-    "strips+bf16x3+slice_pairs": (dict(nslices=8, core=True, strip=True, strip_min=64, dense3_tau=0.12), dict(small_row=8, pair_row=120, adaptive_chunk=False),
-                                  ("strip", "dense3")),
+    "strips+bf16x3+short_rows": (dict(nslices=8, core=True, strip=True, strip_min=64, dense3_tau=0.12), dict(small_row=8, adaptive_chunk=False),
+                                 ("strip", "dense3")),
     "range_slices": (dict(core=True, strip=True, strip_min=64, dense3_tau=0.15, slice_bounds=[0, 40, 100, 250, 600, 1100, 1700, 2400, 3000]), {},
                      ("strip", "dense3")),
 }
@@ -56,7 +54,7 @@ def test_launch_group_plan_reproduces_the_product(name):
     kw, pk, parts = VARIANTS[name]
     n, r, c, val, A = _power_law_block()
     h = partition.csr_from_coo(r, c, val, n, n, **kw)
-    for p in ("strip", "core", "dense", "dense3"):
+    for p in ("strip", "core", "dense3"):
         assert (getattr(h, p) is not None) == (p in parts), "variant %s: part %s" % (name, p)
     assert h.nnz == A.nnz
     d = HostPlanner(**pk).prepare(h)
@@ -67,16 +65,8 @@ def test_launch_group_plan_reproduces_the_product(name):
     if "slice_bounds" in kw:        # range slices: a task's slice is the column range it falls in, not col % 8
         inner = np.asarray(kw["slice_bounds"][1:-1])
         slice_of = lambda cols: np.searchsorted(inner, cols, side="right")      # noqa: E731
-    C, info = run_plan(d, B, slice_of=slice_of, pair_row=pk.get("pair_row", 0))
+    C, info = run_plan(d, B, slice_of=slice_of)
     assert not np.isnan(C).any(), "rows nobody wrote"
-    if "slice_pairs" in name:     # rows in (small_row, pair_row] have 4 tasks (fewer if a pair is empty), never 8
-        ln = np.diff(d.rowptr.numpy())
-        t = d.tasks.numpy().astype(np.int64)
-        k0 = (t[:, 0] & 0xffffffff) | (t[:, 1] << 32)
-        trow = np.searchsorted(d.rowptr.numpy(), k0[t[:, 2] > 0], side="right") - 1
-        per_row = np.bincount(trow, minlength=d.nrows)
-        mid = (ln > pk["small_row"]) & (ln <= pk["pair_row"])
-        assert mid.sum() > 20 and per_row[mid].max() <= 4 and (not (ln > pk["pair_row"]).any() or per_row[ln > pk["pair_row"]].max() > 4)
     assert np.abs(C - ref).max() < TOL
     assert info["entries_gather"] == h.col.numel()
     assert info["entries_strip"] == (h.strip.nnz if h.strip is not None else 0)
@@ -85,12 +75,12 @@ def test_launch_group_plan_reproduces_the_product(name):
         assert d.nfix > 100                                   # many rows are cut into several tasks
     # accumulate: C0 + A . B through the same plan
     C0 = rng.standard_normal((n, 6))
-    C2, _ = run_plan(d, B, C0=C0, accumulate=True, slice_of=slice_of, pair_row=pk.get("pair_row", 0))
+    C2, _ = run_plan(d, B, C0=C0, accumulate=True, slice_of=slice_of)
     assert np.abs(C2 - (C0 + ref)).max() < TOL
     # pattern-only upload (the unpack matrices of the backward exchange): all values one
     if not parts:
         dp = HostPlanner(**pk).prepare(h, pattern_only=True)
-        Cp, _ = run_plan(dp, B, pair_row=pk.get("pair_row", 0))
+        Cp, _ = run_plan(dp, B)
         ones = sp.csr_matrix((np.ones(A.nnz), A.indices, A.indptr), shape=A.shape)
         assert np.abs(Cp - ones @ B).max() < TOL
 
@@ -129,8 +119,8 @@ def test_ragged_block_and_the_last_panel_window():
     D *= rng.standard_normal((n, m))
     A = sp.coo_matrix(D)
     B = rng.standard_normal((m, 5))
-    for kw in (dict(strip=True, strip_min=32, dense_tau=0.2), dict(strip=True, strip_min=32, dense_tau=2.0),
-               dict(strip=False, tau=0.05, emax=3000, dense_tau=0.2)):
+    for kw in (dict(strip=True, strip_min=32, dense3_tau=0.2), dict(strip=True, strip_min=32, dense3_tau=2.0),
+               dict(strip=False, tau=0.05, emax=3000, dense3_tau=2.0)):
         h = partition.csr_from_scipy(A, nslices=1, core=True, **kw)
         if kw["strip"]:
             assert h.strip is not None and int(h.strip.rec[:, 0].max()) == 4            # panel 4 = columns 392..519
@@ -158,7 +148,7 @@ def test_duplicate_coordinates_deeper_than_a_tile_keep_their_sum():
     c = torch.from_numpy(np.concatenate([base.col, dup_c]).astype(np.int64))
     v = torch.from_numpy(np.concatenate([base.data, rng.uniform(-1, 1, dup_r.size)]).astype(np.float32))
     A = sp.coo_matrix((v.numpy().astype(np.float64), (r.numpy(), c.numpy())), shape=(n, n)).tocsr()      # sums duplicates
-    h = partition.csr_from_coo(r, c, v, n, n, nslices=1, core=True, strip=True, strip_min=32, dense_tau=2.0)
+    h = partition.csr_from_coo(r, c, v, n, n, nslices=1, core=True, strip=True, strip_min=32, dense3_tau=2.0)
     assert h.strip is not None and h.nnz == r.numel()
     assert int(h.strip.rec[:, 3].max()) <= 63
     sr, sc, _ = h.strip.to_coo()
@@ -274,13 +264,13 @@ def test_default_tuning_on_a_dense_graph_reaches_every_tile_path(monkeypatch):
     pt = partition.build_partition(row, col, val, n, torch.zeros(n, dtype=torch.int64), 0, 1)
     own = pt.owned.numpy()
     for blk, ref in ((pt.A_loc, AH), (pt.A_loc_T, ATH)):
-        assert blk.strip is not None and blk.dense3 is not None and blk.dense is None and blk.col.numel() > 0 and blk.nnz == A.nnz
+        assert blk.strip is not None and blk.dense3 is not None and blk.col.numel() > 0 and blk.nnz == A.nnz
         assert blk.strip.nnz > 0.2 * A.nnz and blk.dense3.nnz > 0.2 * A.nnz
         C, info = run_plan(K.prepare(blk), H[own])
         assert np.abs(C - ref[own]).max() < TOL
     pt = partition.build_partition(row, col, val, n, synth.random_partvec(n, 4, seed=0), 1, 4)
     own, hg = pt.owned.numpy(), pt.halo_global.numpy()
-    assert pt.A_loc.strip is None and pt.A_loc.core is None and pt.A_loc.dense is None and pt.A_loc.dense3 is None          # a small block: gather only
+    assert pt.A_loc.strip is None and pt.A_loc.core is None and pt.A_loc.dense3 is None          # a small block: gather only
     assert any(a.core is not None or a.dense3 is not None or a.strip is not None for a in pt.A_halo)
     C, _ = run_plan(K.prepare(pt.A_loc), H[own])
     for a in pt.A_halo:
@@ -290,8 +280,8 @@ def test_default_tuning_on_a_dense_graph_reaches_every_tile_path(monkeypatch):
 
 @pytest.mark.parametrize("tuning,parts1,parts3,rounds3", [
     ("core_min_nnz=0,core_min_frac=0,strip_min_records=0,dense3_min_blocks=0,exchange_rounds=3", "s3", "s3", 3),   # strips + bf16 blocks on a shard too
-    ("dense_bf16x3=0,core_min_nnz=0,core_min_frac=0,strip_min_records=0", "sd", "sd", 2),        # the fp32-MFMA tiles instead
-    ("strip=0,dense_bf16x3=0,core_min_nnz=0,core_emax=500,exchange_rounds=1", "cd", "cd", 1),    # LDS core with short pieces
+    ("dense_bf16x3=0,core_min_nnz=0,core_min_frac=0,strip_min_records=0", "s", "s", 2),          # no bf16 blocks: their entries go to the strips
+    ("strip=0,dense_bf16x3=0,core_min_nnz=0,core_emax=500,exchange_rounds=1", "c", "c", 1),      # LDS core with short pieces
     ("tiles=0,slices=1,spmm_chunk=64,spmm_adaptive_chunk=0", "-", "-", 2),                       # gather only, unsliced, short tasks
 ])
 def test_non_default_tunings_keep_the_plans_exact(tuning, parts1, parts3, rounds3):

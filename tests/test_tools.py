@@ -11,8 +11,8 @@ def test_tuning_is_read_once_from_one_variable():
     tuning = pkg("tuning")
     d = tuning.load(env={})
     assert d == tuning.Tuning() and d.strip_pieces == 1024 and d.exchange_rounds == 2 and d.fpass == "auto"
-    t = tuning.load(env={"PGCN_TUNING": "strip_pieces=256, strip_min_records=0,dense=0,dense_tau=0.2,order=degree"})
-    assert (t.strip_pieces, t.strip_min_records, t.dense, t.dense_tau, t.order) == (256, 0, False, 0.2, "degree")
+    t = tuning.load(env={"PGCN_TUNING": "strip_pieces=256, strip_min_records=0,dense_bf16x3=0,dense3_tau=0.25,order=degree"})
+    assert (t.strip_pieces, t.strip_min_records, t.dense_bf16x3, t.dense3_tau, t.order) == (256, 0, False, 0.25, "degree")
     with pytest.raises(ValueError):
         tuning.load(env={"PGCN_TUNING": "no_such_knob=1"})
     with pytest.raises(ValueError):

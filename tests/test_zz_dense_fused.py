@@ -29,10 +29,9 @@ def test_library_exports_the_dense_entry_points():
     P = pkg("PGCN")
     src = open(os.path.join(ROOT, "include", "pgcn_gemm.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = sorted(set(re.findall(r"\b(pgcn_(?:linear|dense|wgrad)_[a-z0-9_]+)\s*\(", src)))
-    names += sorted(set(re.findall(r"\b(pgcn_fixup_[a-z0-9_]+)\s*\(", src)))
-    assert names == ["pgcn_dense_last_error", "pgcn_linear_epilogue_f32", "pgcn_linear_relu_f32", "pgcn_linear_relu_grad_input_f32",
-                     "pgcn_fixup_linear_f32"]
+    names = sorted(set(re.findall(r"\b(pgcn_(?:linear|dense|wgrad|sign)_[a-z0-9_]+)\s*\(", src)))
+    assert names == ["pgcn_dense_last_error", "pgcn_linear_relu_f32", "pgcn_linear_relu_grad_input_f32", "pgcn_linear_weight_grad_f32",
+                     "pgcn_linear_weight_grad_ws_elems", "pgcn_sign_mask_f32", "pgcn_wgrad_last_error"]
     L = ctypes.CDLL(P.GEMM_LIB_PATH)
     for n in names:
         assert hasattr(L, n), "libpgcn_gemm.so does not export %s" % n
@@ -54,8 +53,18 @@ def _rel(got, want, den):
     return float(((got.double() - want).abs() / (den + 1e-30)).max())
 
 
+def _pack_mask(y):
+    """The sign mask of y as the kernels lay it out (include/pgcn_gemm.h): int32 [n, ceil(N / 32)], bit b of word w = (y[:, 32 w + b] > 0)."""
+    n, N = y.shape
+    mw = (N + 31) // 32
+    bits = torch.zeros((n, mw * 32), dtype=torch.int64, device=y.device)
+    bits[:, :N] = (y > 0).to(torch.int64)
+    words = (bits.view(n, mw, 32) << torch.arange(32, device=y.device)).sum(-1)
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+
+
 def _check_pair(P, L, n, fin, fout, stream, dev="cpu", pad=0, seed=0):
-    """forward + input gradient of one shape through the entry points of L against float64; returns the two errors."""
+    """forward (+ sign mask) + input gradient of one shape through the entry points of L against float64; returns the two errors."""
     g0 = torch.Generator().manual_seed(seed)
     x = torch.randn(n, fin + pad, generator=g0)[:, :fin].to(dev) if pad else torch.randn(n, fin, generator=g0).to(dev)
     w = (torch.randn(fout, fin, generator=g0) / 8).to(dev)
@@ -67,10 +76,18 @@ def _check_pair(P, L, n, fin, fout, stream, dev="cpu", pad=0, seed=0):
     ef = _rel(y, want, den) if n else 0.0
     ylin = P.linear_relu_call(L, x, w, False, stream)
     assert torch.equal(ylin.clamp_min(0), y)                          # relu = 0: the same product, unclamped
-    gm, gx = P.linear_relu_grad_input_call(L, g, y, w, stream)
+    y2, mask = P.linear_relu_call(L, x, w, True, stream, want_mask=True)
+    assert torch.equal(y2, y) and mask.shape == (n, P.mask_words(fout)) and mask.dtype is torch.int32
+    assert torch.equal(mask, _pack_mask(y))                           # 1 bit per element, exactly (y > 0)
+    assert torch.equal(P.sign_mask_call(L, y, stream), mask)          # ... and the stand-alone mask of an existing matrix
+    gm, gx = P.linear_relu_grad_input_call(L, g, mask, w, stream)
     assert torch.equal(gm, torch.where(y > 0, g, torch.zeros((), device=dev)))      # threshold_backward, exactly
     wantx = gm.double() @ w.double()
     eb = _rel(gx, wantx, gm.double().abs() @ w.double().abs()) if n else 0.0
+    gm0, gx0 = P.linear_relu_grad_input_call(L, g, None, w, stream)   # no mask: the plain product
+    assert torch.equal(gm0, g)
+    if n:
+        assert _rel(gx0, g.double() @ w.double(), g.double().abs() @ w.double().abs()) <= BOUND
     return ef, eb
 
 
@@ -105,13 +122,14 @@ def test_host_build_padded_rows_and_in_place_mask(emu):
     torch.manual_seed(3)
     g, y, w = torch.randn(50, 32), torch.randn(50, 32), torch.randn(32, 16)
     want = torch.where(y > 0, g, torch.zeros(()))
+    mask = _pack_mask(y)
     gx = torch.empty(50, 16)
-    rc = emu.pgcn_linear_relu_grad_input_f32(g.data_ptr(), 32, y.data_ptr(), 32, g.data_ptr(), 32, 50, 32, w.data_ptr(), 16, 16,
+    rc = emu.pgcn_linear_relu_grad_input_f32(g.data_ptr(), 32, mask.data_ptr(), g.data_ptr(), 32, 50, 32, w.data_ptr(), 16, 16,
                                              gx.data_ptr(), 16, None)
     assert rc == 0 and torch.equal(g, want) and torch.allclose(gx, want @ w, atol=1e-4)
     # no Gm asked for: only the product
     gx2 = torch.empty(50, 16)
-    rc = emu.pgcn_linear_relu_grad_input_f32(want.data_ptr(), 32, y.data_ptr(), 32, None, 0, 50, 32, w.data_ptr(), 16, 16,
+    rc = emu.pgcn_linear_relu_grad_input_f32(want.data_ptr(), 32, mask.data_ptr(), None, 0, 50, 32, w.data_ptr(), 16, 16,
                                              gx2.data_ptr(), 16, None)
     assert rc == 0 and torch.equal(gx2, gx)
 
@@ -123,16 +141,17 @@ def test_refusals_are_minus_two_and_errors_minus_one(emu):
     assert P.linear_relu_call(emu, torch.randn(10, 6), torch.randn(8, 6), True, None) is None   # rows are not 16-byte pieces
     assert P.linear_relu_call(emu, torch.randn(10, 17)[:, 1:], torch.randn(8, 16), True, None) is None  # misaligned base / ld
     assert P.linear_relu_call(emu, torch.randn(10, 8), torch.randn(8, 4), True, None) is None    # widths disagree: not called
-    assert P.linear_relu_grad_input_call(emu, torch.randn(10, 6), torch.randn(10, 6), torch.randn(6, 8), None) is None
+    assert P.linear_relu_grad_input_call(emu, torch.randn(10, 6), None, torch.randn(6, 8), None) is None
+    assert P.linear_relu_grad_input_call(emu, torch.randn(10, 8), torch.zeros(10, 2, dtype=torch.int32), torch.randn(8, 8), None) is None   # mask of another width
     y = torch.empty(4, 4)
-    assert emu.pgcn_linear_relu_f32(None, 4, 4, 4, torch.randn(4, 4).data_ptr(), 4, 4, y.data_ptr(), 4, 1, None) == -1
+    assert emu.pgcn_linear_relu_f32(None, 4, 4, 4, torch.randn(4, 4).data_ptr(), 4, 4, y.data_ptr(), 4, 1, None, None) == -1
     assert b"bad argument" in emu.pgcn_dense_last_error()
-    assert emu.pgcn_linear_relu_f32(y.data_ptr(), 2, 4, 4, y.data_ptr(), 4, 4, y.data_ptr(), 4, 1, None) != 0   # ld below the width
+    assert emu.pgcn_linear_relu_f32(y.data_ptr(), 2, 4, 4, y.data_ptr(), 4, 4, y.data_ptr(), 4, 1, None, None) != 0   # ld below the width
 
 
 def test_autograd_node_through_the_host_build(emu, monkeypatch):
-    """PGCN._LinearReluNoBias with tuning.dense_fused = 2 takes both entry points (here: the host build on CPU tensors) and
-    agrees with the stock route; level 0 never touches them."""
+    """PGCN._LinearReluNoBias with tuning.dense_fused >= 2 takes both entry points (here: the host build on CPU tensors), the
+    sign mask travelling from the forward to the backward instead of y, and agrees with the stock route; level 0 never touches them."""
     P, tuning = pkg("PGCN"), pkg("tuning")
     calls = []
     monkeypatch.setattr(P, "_dense_operand_ok", lambda *ts: all(t.dim() == 2 and t.stride(1) == 1 for t in ts))
@@ -141,15 +160,15 @@ def test_autograd_node_through_the_host_build(emu, monkeypatch):
     torch.manual_seed(1)
     x0, w0 = torch.randn(90, 64), torch.randn(32, 64) / 8
     out = {}
-    for level in (0, 1, 2):
+    for level in (0, 1, 2, 3):
         monkeypatch.setattr(tuning.T, "dense_fused", level)
         x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
         calls.clear()
         y = P._LinearReluNoBias.apply(x, w)
         (y * torch.arange(32.0)).sum().backward()
         out[level] = (y.detach(), x.grad, w.grad, len(calls))
-    assert [out[l][3] for l in (0, 1, 2)] == [0, 1, 2]
-    for level in (1, 2):
+    assert [out[l][3] for l in (0, 1, 2, 3)] == [0, 1, 2, 3]       # (level 3 asks the library for the weight gradient too: the host build has none)
+    for level in (1, 2, 3):
         for a, b in zip(out[level][:3], out[0][:3]):                    # (sums with cancellation: relative to the tensor's scale)
             assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (level, float((a - b).abs().max()))
     assert torch.equal(out[1][0], out[2][0])
@@ -161,154 +180,14 @@ def test_autograd_node_through_the_host_build(emu, monkeypatch):
     assert torch.allclose(yw, (xw @ ww.t()).clamp_min(0), atol=1e-5) and xw.grad is not None
 
 
-# ---- the fix-up of the aggregation as the loader of the product (pgcn_fixup_linear_f32) --------------------------------------------
-
-def _random_deferred(n, f, seed, dev="cpu", max_slots=11, ids=True):
-    """A random decomposition of an n x f matrix into partial rows: (row_fix, slot_ids, ws, base, S) with S the ordered fp32 sums
-    exactly as csrc's spmm_fixup_list_kernel forms them (((0 + x0) + x1) + ...).  Some rows are `direct` (count -1: taken from
-    base), some empty (count 0), some have more slots than one chunk of ids."""
-    g0 = torch.Generator().manual_seed(seed)
-    cnt = torch.randint(0, 6, (n,), generator=g0)
-    cnt[torch.rand(n, generator=g0) < 0.1] = torch.randint(9, max_slots + 1, (1,), generator=g0).item()
-    direct = torch.rand(n, generator=g0) < 0.15
-    cnt[direct] = 0
-    total = int(cnt.sum())
-    nslots = total + 5
-    ws = torch.randn(nslots, f, generator=g0)
-    if ids:
-        slot_ids = torch.randperm(nslots, generator=g0)[:total].to(torch.int32)
-        begin = torch.cumsum(cnt, 0) - cnt
-    else:                                             # consecutive slots: begin IS the first slot
-        slot_ids, begin = None, torch.cumsum(cnt, 0) - cnt
-    base = torch.randn(n, f, generator=g0)
-    S = torch.zeros(n, f)
-    for r in range(n):
-        if direct[r]:
-            S[r] = base[r]
-            continue
-        acc = torch.zeros(f)
-        for t in range(int(cnt[r])):
-            sid = int(slot_ids[begin[r] + t]) if ids else int(begin[r] + t)
-            acc = acc + ws[sid]
-        S[r] = acc
-    row_fix = torch.stack([begin, torch.where(direct, torch.full_like(cnt, -1), cnt)], 1).to(torch.int32).contiguous()
-    mv = lambda t: None if t is None else t.to(dev)
-    return mv(row_fix), mv(slot_ids), mv(ws), mv(base), mv(S)
-
-
-FIX_SHAPES = [(77, 128, 128), (64, 64, 64), (33, 16, 16), (100, 36, 128), (5, 8, 4), (1, 128, 128), (96, 128, 64), (200, 64, 128)]
-
-
-def _check_fixup(P, L, n, fin, fout, stream, dev="cpu", ids=True):
-    row_fix, slot_ids, ws, base, S = _random_deferred(n, fin, seed=n + fin, dev=dev, ids=ids)
-    g0 = torch.Generator().manual_seed(5)
-    w = (torch.randn(fout, fin, generator=g0) / 8).to(dev)
-    # forward: relu(S . W^T), bit-identical to the separate route (the ordered sum, then the product kernel on it)
-    y, none = P.fixup_linear_call(L, row_fix, slot_ids, ws, base, fin, w, True, P.EPI_RELU, None, False, stream)
-    assert none is None and torch.equal(y, P.linear_relu_call(L, S, w, True, stream))
-    # backward shape: S . W2 with the sum written out and the mask of the layer below folded in
-    w2 = (torch.randn(fin, fout, generator=g0) / 8).to(dev)
-    m = torch.randn(n, fout, generator=g0).to(dev)
-    y2, S2 = P.fixup_linear_call(L, row_fix, slot_ids, ws, base, fin, w2, False, P.EPI_MASK, m, True, stream)
-    assert torch.equal(S2, S)
-    plain = P.linear_epilogue_call(L, S, w2, False, P.EPI_NONE, None, stream)
-    assert torch.equal(y2, torch.where(m > 0, plain, torch.zeros((), device=dev)))
-    assert torch.equal(P.linear_epilogue_call(L, S, w2, False, P.EPI_MASK, m, stream), y2)
-    want = S.double() @ w2.double()
-    den = S.double().abs() @ w2.double().abs()
-    return _rel(plain, want, den) if n else 0.0
-
-
-@pytest.mark.parametrize("n,fin,fout", FIX_SHAPES)
-def test_host_build_of_the_fixup_loader(emu, n, fin, fout):
-    """gemm/pgcn_dense_tile.h sum_half / store_half / store_c_masked around the emulated MFMA: slot lists with ids and consecutive,
-    direct rows, empty rows, lists longer than one chunk of ids, ragged rows and widths."""
-    P = pkg("PGCN")
-    assert _check_fixup(P, emu, n, fin, fout, None) <= BOUND
-    assert _check_fixup(P, emu, n, fin, fout, None, ids=False) <= BOUND
-
-
-def test_fixup_loader_refusals(emu):
-    P = pkg("PGCN")
-    row_fix, slot_ids, ws, base, S = _random_deferred(10, 8, 1)
-    assert P.fixup_linear_call(emu, row_fix, slot_ids, ws, base, 8, torch.randn(4, 6), True, 1, None, False, None) is None   # W does not fit
-    rf6, ids6, ws6, base6, _ = _random_deferred(10, 6, 1)
-    assert P.fixup_linear_call(emu, rf6, ids6, ws6, base6, 6, torch.randn(4, 6), True, 1, None, False, None) is None        # width % 4
-    assert P.fixup_linear_call(emu, row_fix, slot_ids, ws, base, 8, torch.randn(8, 4), False, 2, None, False, None) is None  # mask missing
-    y = torch.empty(10, 4)
-    assert emu.pgcn_fixup_linear_f32(None, None, None, 8, base.data_ptr(), 8, 10, 8, torch.randn(4, 8).data_ptr(), 8, 4, 8, 1, None, 0,
-                                     None, 0, y.data_ptr(), 4, 1, None) == -1
-
-
-class _FakeEngine:
-    """AggregationEngine stand-in on CPU tensors: A is dense, every aggregation comes back as a kernels.DeferredSum whose partial rows
-    are a random split of the true rows (so that the loader's sum is exercised), as the HIP provider returns them."""
-
-    def __init__(self, A):
-        self.A = A
-        self.calls = []
-
-    def _split(self, X):
-        K = pkg("kernels")
-        n, f = X.shape
-        g0 = torch.Generator().manual_seed(len(self.calls))
-        a = torch.randn(n, f, generator=g0)
-        ws = torch.cat([a, X - a])                        # two slots per row: a and (X - a)
-        row_fix = torch.stack([2 * torch.arange(n), torch.full((n,), 2)], 1).to(torch.int32)
-        slot_ids = torch.stack([torch.arange(n), n + torch.arange(n)], 1).reshape(-1).to(torch.int32)
-        base = torch.empty(n, f)
-        def finish():
-            base.copy_(ws[:n] + ws[n:])
-            return base
-        return K.DeferredSum(row_fix, slot_ids, ws, base, f, finish)
-
-    def forward_deferred(self, H):
-        self.calls.append("f")
-        return self._split(self.A @ H)
-
-    def backward_deferred(self, G):
-        self.calls.append("b")
-        return self._split(self.A.t() @ G)
-
-
-def test_fused_layer_node_through_the_host_build(emu, monkeypatch):
-    """PGCN._AggLinearRelu (tuning.layer_fused): two stacked layers on the host build against plain autograd of the same two layers --
-    the re-associated backward (T = A^T.Gm, dH = T.W, dW = T^T.H), the mask of the layer below folded into the upper layer's input
-    gradient, and the lower layer recognising the pre-masked gradient it is handed."""
-    P, tuning = pkg("PGCN"), pkg("tuning")
-    monkeypatch.setattr(P, "_dense_stream", lambda t: None)
-    monkeypatch.setattr(P, "_dense_lib", lambda: emu)
-    monkeypatch.setattr(P, "_layer_fused_ok", lambda A, H, w: True)
-    monkeypatch.setattr(P, "_layer_fused_level", lambda: 2)
-    torch.manual_seed(4)
-    n, f = 70, 32
-    A = (torch.rand(n, n) < 0.1).float() * torch.rand(n, n)
-    eng = _FakeEngine(A)
-    l1, l2 = P.PGCN(eng, f, f), P.PGCN(eng, f, f)
-    H0 = torch.randn(n, f)
-    coef = torch.randn(n, f)
-    premasks = []
-    real_tb = torch.ops.aten.threshold_backward
-    H = H0.clone().requires_grad_(True)
-    out = l2(l1(H))
-    import unittest.mock as mock
-    with mock.patch.object(P.torch.ops.aten, "threshold_backward", side_effect=lambda *a: (premasks.append(1), real_tb(*a))[1]):
-        (out * coef).sum().backward()
-    Hr = H0.clone().requires_grad_(True)
-    w1, w2 = l1.linear.weight.detach().clone().requires_grad_(True), l2.linear.weight.detach().clone().requires_grad_(True)
-    ref = torch.relu((A @ torch.relu((A @ Hr) @ w1.t())) @ w2.t())
-    (ref * coef).sum().backward()
-    for got, want in ((out, ref), (H.grad, Hr.grad), (l1.linear.weight.grad, w1.grad), (l2.linear.weight.grad, w2.grad)):
-        assert float((got - want).detach().abs().max()) <= 5e-6 * float(want.detach().abs().max())
-    assert eng.calls == ["f", "f", "b", "b"]
-    assert len(premasks) == 1, "only the top layer runs a separate mask pass; the lower one is handed a pre-masked gradient"
-
-
 def test_cpu_tensors_never_reach_the_kernels():
     P, tuning = pkg("PGCN"), pkg("tuning")
-    assert tuning.Tuning().dense_fused == 2 and tuning.Tuning().layer_fused == 0   # (tuning.py has the epochs behind both)
+    assert tuning.Tuning().dense_fused == 3 and not hasattr(tuning.Tuning(), "layer_fused")   # (tuning.py / HISTORY.md have the epochs)
     assert P.linear_relu_fused(torch.randn(8, 8), torch.randn(4, 8)) is None
-    assert P.linear_relu_grad_input_fused(torch.randn(8, 4), torch.randn(8, 4), torch.randn(4, 8)) is None
+    assert P.linear_relu_grad_input_fused(torch.randn(8, 4), None, torch.randn(4, 8)) is None
+    assert P.weight_grad_fused(torch.randn(8, 4), torch.randn(8, 8)) is None
+    y = torch.randn(5, 70)
+    assert torch.equal(P.unpack_sign_mask(_pack_mask(y), 70), y > 0)
 
 
 # ---- GPU ------------------------------------------------------------------------------------------------------------------
@@ -349,12 +228,21 @@ def test_kernels_against_the_library_route_and_reproducible():
     side.synchronize()
     assert torch.equal(y2, y)
     g = torch.randn(n, f, generator=g0).to(dev)
-    gm, gx = P.linear_relu_grad_input_fused(g, y, w)
+    ym, mask = P.linear_relu_fused(x, w, want_mask=True)
+    assert torch.equal(ym, y) and torch.equal(mask, _pack_mask(y))
+    gm, gx = P.linear_relu_grad_input_fused(g, mask, w)
     assert torch.equal(gm, torch.ops.aten.threshold_backward(g, y, 0.0))
     exact = gm.double() @ w.double()
     e_mine, e_stock = float((gx.double() - exact).abs().max()), float(((gm @ w).double() - exact).abs().max())
     assert e_mine <= max(2 * e_stock, 1e-6 * float(exact.abs().max())), (e_mine, e_stock)
-    assert torch.equal(P.linear_relu_grad_input_fused(g, y, w)[1], gx)
+    assert torch.equal(P.linear_relu_grad_input_fused(g, mask, w)[1], gx)
+    # the weight gradient at the same shape: against float64, no further than twice the library's, bit-identical run to run
+    gw = P.weight_grad_fused(gm, x)
+    assert gw is not None and gw.shape == (f, f)
+    exact = gm.double().t() @ x.double()
+    e_mine, e_stock = float((gw.double() - exact).abs().max()), float(((gm.t() @ x).double() - exact).abs().max())
+    assert e_mine <= max(2 * e_stock, 1e-6 * float(exact.abs().max())), (e_mine, e_stock)
+    assert torch.equal(P.weight_grad_fused(gm, x), gw)
     xp = torch.randn(5000, 2 * f, device=dev)[:, :f]                   # leading dimension 256
     assert torch.allclose(P.linear_relu_fused(xp, w), (xp @ w.t()).clamp_min_(0), atol=1e-4)
     assert P.linear_relu_fused(torch.randn(64, 132, device=dev), torch.randn(8, 132, device=dev)) is None
@@ -362,7 +250,7 @@ def test_kernels_against_the_library_route_and_reproducible():
 
 @pytest.mark.gpu
 def test_layer_with_the_kernels_switched_on(monkeypatch):
-    """The autograd node of PGCN.py:146-147 with tuning.dense_fused = 2 against level 0 on the GPU."""
+    """The autograd node of PGCN.py:146-147 with tuning.dense_fused = 3 (all three products) against level 0 on the GPU."""
     P, tuning = pkg("PGCN"), pkg("tuning")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -370,110 +258,58 @@ def test_layer_with_the_kernels_switched_on(monkeypatch):
     x0, w0 = torch.randn(30011, 128, device=dev), torch.randn(128, 128, device=dev) / 11
     coef = torch.randn(30011, 128, device=dev)
     out = {}
-    for level in (0, 2, 2):
+    for level in (0, 3, 3):
         monkeypatch.setattr(tuning.T, "dense_fused", level)
         x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
         y = P._LinearReluNoBias.apply(x, w)
         (y * coef).sum().backward()
         torch.cuda.synchronize()
-        if level in out:            # reproducible (the two tensors these kernels write; dW stays the library's batched product)
-            assert torch.equal(out[level][0], y.detach()) and torch.equal(out[level][1], x.grad)
+        if level in out:            # reproducible: all three products are the package's own, fixed-order kernels
+            assert torch.equal(out[level][0], y.detach()) and torch.equal(out[level][1], x.grad) and torch.equal(out[level][2], w.grad)
         out[level] = (y.detach(), x.grad, w.grad)
-    for a, b in zip(out[2], out[0]):
+    for a, b in zip(out[3], out[0]):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
 
 
+WG_SHAPES = [(232965, 128, 128), (100003, 64, 64), (4097, 128, 44), (77, 128, 128), (1000, 40, 128), (33, 4, 4), (15, 64, 128), (1, 128, 128),
+             (5000, 100, 36), (16, 32, 32), (600, 96, 64), (0, 128, 128)]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,fin,fout", FIX_SHAPES + [(232965, 128, 128), (100003, 64, 64)])
-def test_fixup_loader_kernel(n, fin, fout):
-    """pgcn_fixup_linear_f32 on the GPU: bit-identical to the ordered sums followed by the product kernel, S written out exactly,
-    mask epilogue exact; both slot-list forms."""
+@pytest.mark.parametrize("n,fout,fin", WG_SHAPES)
+def test_weight_gradient_kernel(n, fout, fin):
+    """gm^T . x (gemm/pgcn_wgrad.hip) against float64: full, ragged and tiny shapes, rows that are not a multiple of a step, padded
+    leading dimensions; bound 1e-6 of sum |g||x| per element."""
     P = pkg("PGCN")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    st = torch.cuda.current_stream(dev).cuda_stream
-    if n > 5000:                                       # (the host-side reference sum of _random_deferred is a Python loop)
-        g0 = torch.Generator().manual_seed(3)
-        cnt = torch.randint(0, 7, (n,), generator=g0)
-        cnt[::97] = 19
-        direct = torch.rand(n, generator=g0) < 0.1
-        cnt[direct] = 0
-        total = int(cnt.sum())
-        ws = torch.randn(total + 3, fin, generator=g0).to(dev)
-        slot_ids = torch.randperm(total + 3, generator=g0)[:total].to(torch.int32).to(dev)
-        begin = (torch.cumsum(cnt, 0) - cnt)
-        base = torch.randn(n, fin, generator=g0).to(dev)
-        row_fix = torch.stack([begin, torch.where(direct, torch.full_like(cnt, -1), cnt)], 1).to(torch.int32).contiguous().to(dev)
-        # the ordered sums by the library's own fix-up kernel (csrc): the route the folded loader replaces
-        K = pkg("kernels").HipKernels(dev)
-        rows = torch.nonzero(~direct).reshape(-1)
-        fix = torch.stack([rows, begin[rows], cnt[rows], torch.zeros_like(rows)], 1).to(torch.int32).contiguous().to(dev)
-        S = base.clone()
-        lib = pkg("_lib")
-        lib.check(K.lib.pgcn_spmm_fixup_f32(fix.data_ptr(), fix.shape[0], slot_ids.data_ptr(), None, ws.data_ptr(), S.data_ptr(), fin, fin,
-                                            0, st), "pgcn_spmm_fixup_f32")
-        w = (torch.randn(fout, fin, generator=g0) / 8).to(dev)
-        y, _ = P.fixup_linear_call(P._dense_lib(), row_fix, slot_ids, ws, base, fin, w, True, P.EPI_RELU, None, False, st)
-        assert torch.equal(y, P.linear_relu_call(P._dense_lib(), S, w, True, st))
-        w2 = (torch.randn(fin, fout, generator=g0) / 8).to(dev)
-        m = torch.randn(n, fout, generator=g0).to(dev)
-        y2, S2 = P.fixup_linear_call(P._dense_lib(), row_fix, slot_ids, ws, base, fin, w2, False, P.EPI_MASK, m, True, st)
-        assert torch.equal(S2, S)
-        assert torch.equal(y2, P.linear_epilogue_call(P._dense_lib(), S, w2, False, P.EPI_MASK, m, st))
-        assert torch.equal(y2, torch.where(m > 0, P.linear_epilogue_call(P._dense_lib(), S, w2, False, P.EPI_NONE, None, st),
-                                           torch.zeros((), device=dev)))
-        torch.cuda.synchronize()
-        return
-    assert _check_fixup(P, P._dense_lib(), n, fin, fout, st, dev=dev) <= BOUND
-    assert _check_fixup(P, P._dense_lib(), n, fin, fout, st, dev=dev, ids=False) <= BOUND
-    torch.cuda.synchronize()
+    g0 = torch.Generator().manual_seed(n + fout)
+    gm = torch.randn(n, fout + 4, generator=g0).to(dev)[:, :fout]           # leading dimension fout + 4
+    gm = gm * (torch.rand(n, fout, generator=g0).to(dev) > 0.4)             # (a masked gradient: zeros in it)
+    x = torch.randn(n, fin, generator=g0).to(dev)
+    dw = P.weight_grad_fused(gm, x)
+    assert dw is not None and dw.shape == (fout, fin)
+    want = gm.double().t() @ x.double()
+    den = gm.double().abs().t() @ x.double().abs()
+    err = float(((dw.double() - want).abs() / (den + 1e-30)).max()) if n else float(dw.abs().max())
+    assert err <= BOUND, err
+    assert torch.equal(P.weight_grad_fused(gm, x), dw)                      # fixed-order sums: bit-identical run to run
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("f", [128, 64])
-def test_fused_layer_on_the_engine(f, monkeypatch):
-    """tuning.layer_fused on the real engine (a graph with strips, bf16 blocks and a gather part): the forward is BIT-IDENTICAL to
-    PSpMM + the separate product (same partial rows, same order of the sums, same product kernel), the re-associated backward agrees
-    with it to fp32 rounding, twice the same bits, and the deferred sum can still be finished by the separate fix-up."""
-    P, tuning, partition, synth = pkg("PGCN"), pkg("tuning"), pkg("partition"), pkg("synth")
-    engine, kernels = pkg("engine"), pkg("kernels")
+def test_weight_gradient_on_a_side_stream_and_refusals():
+    P = pkg("PGCN")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    n = 40000
-    _, row, col, val = synth.make_graph(n, 6_000_000, seed=3)
-    monkeypatch.setattr(partition, "CORE_MIN_NNZ", 0)
-    monkeypatch.setattr(partition, "DENSE3_MIN_BLOCKS", 0)
-    monkeypatch.setattr(partition, "STRIP_MIN_RECORDS", 0)
-    part = partition.build_partition(row, col, val, n, torch.zeros(n, dtype=torch.int64), 0, 1)
-    K = kernels.HipKernels(dev)
-    eng = engine.AggregationEngine(part, K, dev)
-    assert eng.A_loc.fix_all is not None, "the test graph should have tiled parts (a separate fix-up to fold)"
-    P.device, P.myrank, P.world_size = dev, 0, 1
-    P.init_stats()
-    torch.manual_seed(0)
-    H0 = torch.rand(n, f, device=dev)
-    d = eng.forward_deferred(H0)
-    assert isinstance(d, kernels.DeferredSum)
-    assert torch.equal(d.finish(), eng.forward(H0))                      # the deferred sum completed by the separate fix-up
-    l1, l2 = P.PGCN(eng, f, f).to(dev), P.PGCN(eng, f, f).to(dev)
-    coef = torch.randn(n, f, device=dev)
-    res = {}
-    for level in (0, 2, 2, 1):
-        monkeypatch.setattr(tuning.T, "layer_fused", level)
-        for l in (l1, l2):
-            l.linear.weight.grad = None
-        H = H0.clone().requires_grad_(True)
-        out = l2(l1(H))
-        (out * coef).sum().backward()
-        torch.cuda.synchronize()
-        got = (out.detach(), H.grad, l1.linear.weight.grad.clone(), l2.linear.weight.grad.clone())
-        if level in res:
-            for a, b in zip(got, res[level]):
-                assert torch.equal(a, b), "the fused layer is not reproducible"
-        res[level] = got
-    assert torch.equal(res[2][0], res[0][0]), "folding the fix-up into the product changed the forward's bits"
-    for a, b in zip(res[1], res[2]):
-        assert torch.equal(a, b), "the node with finished operands (level 1) and with the folded fix-up (level 2) differ"
-    for a, b in zip(res[2][1:], res[0][1:]):
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), float((a - b).abs().max()) / float(b.abs().max())
+    torch.manual_seed(4)
+    gm, x = torch.randn(20000, 128, device=dev), torch.randn(20000, 128, device=dev)
+    ref = P.weight_grad_fused(gm, x)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        dw = P.weight_grad_fused(gm, x)
+    side.synchronize()
+    assert torch.equal(dw, ref)
+    assert P.weight_grad_fused(torch.randn(64, 132, device=dev), torch.randn(64, 8, device=dev)) is None      # wider than 128
+    assert P.weight_grad_fused(torch.randn(64, 8, device=dev), torch.randn(32, 8, device=dev)) is None        # rows disagree

@@ -64,8 +64,8 @@ def main():
         if k == 0:
             out["parts"] = {"gather": int(h.col.numel()), "strip": 0 if h.strip is None else h.strip.nnz,
                             "strip_records": 0 if h.strip is None else int(h.strip.rec.shape[0]),
-                            "dense": 0 if h.dense is None else h.dense.nnz,
-                            "dense_tiles": 0 if h.dense is None else int(h.dense.tile_row.numel())}
+                            "dense3": 0 if h.dense3 is None else h.dense3.nnz,
+                            "dense3_blocks": 0 if h.dense3 is None else int(h.dense3.blk_row.numel())}
         del h
     def run_tiled():
         for k in range(heads):

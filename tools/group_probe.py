@@ -37,7 +37,7 @@ def main():
         K.spmm(A, B, C, accumulate=a.block != "loc")
     torch.cuda.synchronize()
     print("block %s: nnz %d gather %d strip %d dense %d core %d alg_bytes %d" % (
-        a.block, A.nnz, A.col.numel(), A.strip.nnz if A.strip else 0, A.dense.nnz if A.dense else 0, A.core.nnz if A.core else 0,
+        a.block, A.nnz, A.col.numel(), A.strip.nnz if A.strip else 0, A.dense3.nnz if A.dense3 else 0, A.core.nnz if A.core else 0,
         A.alg_bytes(f)))
 
 

@@ -1,11 +1,13 @@
 #!/bin/bash
-# Builds tools/micro/dense_fused_bench.bin: the kernels of gemm/pgcn_dense.hip linked in directly (no rocBLAS, no Python).
-# PGCN_EXTRA_FLAGS reaches the kernel file (an A/B build: compile twice under different output names).
+# Builds tools/micro/dense_fused_bench.bin (binds lib/libpgcn_gemm.so with dlopen: build the package first) and, for the A/B,
+#   tools/micro/libpgcn_dense_r05.so    the r05 kernels (tools/micro/r05/: the sources as they were at the end of round 5),
+#   tools/micro/libpgcn_wgrad_probe.so  gemm/pgcn_wgrad.hip with the fp32-MFMA probe entry point.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 PKG="scalable-graph-convolutional-network-training-on-distributed-memory-systems_amd"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$HERE/../../$PKG/gemm/pgcn_dense.hip" -o "$HERE/dense_fused_kernels.o" ${PGCN_EXTRA_FLAGS:-}
-"$HIPCC" --offload-arch=gfx950 -O2 -std=c++17 -c "$HERE/dense_fused_bench.cpp" -o "$HERE/dense_fused_bench.o"
-"$HIPCC" --offload-arch=gfx950 "$HERE/dense_fused_bench.o" "$HERE/dense_fused_kernels.o" -o "$HERE/dense_fused_bench.bin"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I"$HERE/r05" "$HERE/r05/pgcn_dense.hip" -o "$HERE/libpgcn_dense_r05.so" &
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -DPGCN_WGRAD_PROBES "$HERE/../../$PKG/gemm/pgcn_wgrad.hip" -o "$HERE/libpgcn_wgrad_probe.so" &
+"$HIPCC" --offload-arch=gfx950 -O2 -std=c++17 "$HERE/dense_fused_bench.cpp" -o "$HERE/dense_fused_bench.bin" -ldl &
+wait
 echo "built $HERE/dense_fused_bench.bin"

@@ -28,7 +28,7 @@ def main():
         ds = d if isinstance(d, list) else [d]
         tot = sum(x.nnz for x in ds if x is not None)
         return 100.0 * sum((x.core.nnz if x.core is not None else 0) + (x.strip.nnz if getattr(x, "strip", None) is not None else 0)
-                           + (x.dense.nnz if getattr(x, "dense", None) is not None else 0) for x in ds if x is not None) / max(tot, 1)
+                           + (x.dense3.nnz if getattr(x, "dense3", None) is not None else 0) for x in ds if x is not None) / max(tot, 1)
     print("rounds=%d " % p.rounds, end="")
     print("P=%d rank=%d n_local=%d n_halo=%d n_send=%d nnz_loc=%d nnz_halo=%d | build %.2fs prepare %.2fs | tiled%% (strips + core + MFMA): loc %.0f halo %.0f locT %.0f haloT %.0f"
           % (a.world, a.rank, p.n_local, p.n_halo, p.n_send, p.A_loc.nnz, sum(x.nnz for x in p.A_halo), tb, tp,

@@ -183,14 +183,14 @@ def main():
         out[name] = {"median_ms": med, "min_ms": mn, "alg_GBs": alg / med / 1e6, "gather_TBs": 4 * f * nnz / med / 1e9,
                      "ntasks": d.ntasks, "nslots": d.nslots_total,
                      "core_nnz": d.core.nnz if d.core else 0, "core_pieces": d.core.npieces if d.core else 0,
-                     "dense_nnz": d.dense.nnz if d.dense else 0, "gather_nnz": int(d.col.numel()),
+                     "dense_nnz": d.dense3.nnz if d.dense3 else 0, "gather_nnz": int(d.col.numel()),
                      "strip_nnz": d.strip.nnz if d.strip else 0, "strip_pieces": d.strip.npieces if d.strip else 0,
                      "strip_recs": int(d.strip.rec.shape[0]) if d.strip else 0,
                      "split_ms": split.get(name)}
         if split.get(name):
             print("    split:", "  ".join("%s %.3f" % (k.replace("pgcn_spmm_", ""), v) for k, v in split[name].items()),
                   " gather_nnz %d dense_nnz %d strip_nnz %d pieces %d recs %d" % (
-                      d.col.numel(), d.dense.nnz if d.dense else 0, d.strip.nnz if d.strip else 0,
+                      d.col.numel(), d.dense3.nnz if d.dense3 else 0, d.strip.nnz if d.strip else 0,
                       d.strip.npieces if d.strip else 0, d.strip.rec.shape[0] if d.strip else 0))
         print("%-14s median %.3f ms  min %.3f ms  alg %.0f GB/s (%.2f%% of 8 TB/s)  gather %.1f TB/s  tasks %d core %.1f%% pieces %d"
               % (name, med, mn, alg / med / 1e6, 100 * alg / med / 1e6 / 8000, 4 * f * nnz / med / 1e9, d.ntasks,
