@@ -82,6 +82,28 @@ class KernelTimer:
         return (sum(ts) / len(ts), len(ts)) if ts else (None, 0)
 
 
+def exchange_summary(probe, P, dev, world):
+    """The rank-0 view of engine.ExchangeProbe.summary() plus, per (direction, round), the MAX over ranks of the transfer and of the
+    exposed wait (the rank that waits longest sets the step).  Every rank calls this (collective)."""
+    rep = probe.summary()
+    keys = [(tag, i) for tag in ("forward", "backward") for i in range(len(rep.get(tag, [])))]
+    vals = [rep[tag][i][k] for tag, i in keys for k in ("ms", "exposed_ms")]
+    ar = rep.get("allreduce")
+    vals += [ar["ms"], ar["exposed_ms"]] if ar else [0.0, 0.0]
+    t = torch.tensor(vals, dtype=torch.float64, device=dev)
+    if world > 1:
+        P._all_reduce(t, dist.ReduceOp.MAX)
+    t = t.tolist()
+    for j, (tag, i) in enumerate(keys):
+        rep[tag][i]["ms_max_over_ranks"], rep[tag][i]["exposed_ms_max_over_ranks"] = t[2 * j], t[2 * j + 1]
+    if ar:
+        ar["ms_max_over_ranks"], ar["exposed_ms_max_over_ranks"] = t[-2], t[-1]
+    rep["what"] = ("per round of the boundary all-to-all-v of ONE aggregation (mean over the timed steps, this rank): bytes sent / received, "
+                   "the largest single peer segment (what one xGMI link carries), ms on the stream that runs it, exposed_ms = how long the "
+                   "compute stream stood waiting for it, GB/s on that link against 153 GB/s; *_max_over_ranks: the slowest rank")
+    return rep
+
+
 def kernel_source_stamp():
     """sha256 over the kernel sources and the layout code: what a PMC traffic figure is valid for."""
     import glob
@@ -849,6 +871,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.on = not args.no_kernel_timing
+    # N > 1: what the boundary exchange costs and how much of it the compute stream sees (engine.ExchangeProbe: HIP events on the comm
+    # stream around every round, on the compute stream around every wait for one, and around the fused gradient all-reduce)
+    xprobe = None
+    if world > 1 and not args.no_kernel_timing and not (args.emulate_rank and part.size > 1):
+        xprobe = eng.probe = engine.ExchangeProbe(dev)
+        xprobe.on = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -858,6 +886,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.on = False
+    exchange_report = None
+    if xprobe is not None:
+        xprobe.on = False
+        exchange_report = exchange_summary(xprobe, P, dev, world)
+        eng.probe = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         P._all_reduce(t, dist.ReduceOp.MAX)
@@ -985,6 +1018,8 @@ def main():
         P._all_reduce(vol)
         out["exchange_rows_total"] = float(vol)
         out["selftest"] = selftest
+        if exchange_report is not None:
+            out["exchange"] = exchange_report
     out["config"]["timed_region"] = "%d eagerly launched training steps" % args.steps
     if args.graph == "on" or (args.graph == "auto" and world > 1 and dev.type == "cuda"):
         # LAST thing that touches the device: the eager line above is complete.  A replay whose collectives never finish cannot be
@@ -992,6 +1027,7 @@ def main():
         def bail(what):
             out["graph_replay"] = {"captured": True, "ranks": world, "eager_ms_per_step": ms_per_step,
                                    "error": "%s did not complete within its deadline; the eager line stands" % what}
+            out["replay_failed"] = True            # (explicit flag: the launcher sees exit code 0 because the eager line IS complete)
             if rank == 0:
                 out.setdefault("cpu_baseline", None)
                 print(json.dumps(out), flush=True)
@@ -1001,17 +1037,12 @@ def main():
         out["graph_replay"] = graph_replay(model, lambda: nn.Sequential(*[P.PGCN(eng, f, f) for _ in range(L)]).to(dev),
                                            H, labels, n, P, args.steps, dev, ms_per_step, world, on_timeout=bail)
         gr = out["graph_replay"]
-        if world > 1 and gr.get("captured") and gr.get("ms_per_step") and gr["ms_per_step"] < ms_per_step:
-            # N > 1: the same K training steps were timed twice with the same barriers -- launched eagerly (per-kernel HIP events,
-            # the roofline object) and as K replays of ONE captured HIP graph of the whole step (RCCL calls included; MAX over
-            # ranks).  The replayed steps are the job's rate: a rank's step is ~150 launches of ~20 us, the host-side enqueue is 11-13 %
-            # of it.  Both are in the line; `value` / `ms_per_step` are the replayed ones and say so.
-            out["eager"] = {"ms_per_step": ms_per_step, "value": edges_per_s}
-            out["ms_per_step"] = out["ms_per_epoch"] = gr["ms_per_step"]
-            out["value"] = 2 * L * nnz_job / (gr["ms_per_step"] * 1e-3)
-            out["config"]["timed_region"] = ("%d replays of one captured HIP graph of the whole training step on every rank (forward, loss, "
-                                             "backward, RCCL exchange and gradient all-reduce, Adam); the eager launches of the same steps: "
-                                             "`eager`" % args.steps)
+        if gr.get("captured") and gr.get("ms_per_step"):
+            # ONE method for `value` at every N (r06; the r05 line took the faster of two): the eagerly launched steps.  The same K steps as K
+            # replays of one captured HIP graph of the whole step (RCCL calls included; MAX over ranks) are reported beside it -- at
+            # N > 1 a rank's step is ~150 launches of ~20 us and the host-side enqueue is 11-13 % of it, which the replay removes.
+            gr["value"] = 2 * L * nnz_job / (gr["ms_per_step"] * 1e-3)
+            gr["unit"] = out["unit"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not emul:
         try:
             out["cpu_baseline"] = cpu_baseline(part, f, L, args.cpu_budget)

@@ -209,6 +209,56 @@ def make_exchanger(rank: int, size: int, device: torch.device, impl: str = "auto
 # --------------------------------------------------------------------------
 
 
+XGMI_LINK_GBS = 153.0      # one xGMI link of an MI355X, per direction (the bound of a round is max_q(s_pq f 4) / 153 GB/s)
+
+
+class ExchangeProbe:
+    """What the boundary exchange of a rank costs and how much of it the compute stream SEES (r06; bench.py's N > 1 line).
+    Switched on around an eager timed region: every round of every exchange is bracketed by HIP events on the stream that runs
+    it (the comm stream under overlap), every wait of the compute stream for a round by a pair of events on the compute stream
+    (their distance = the time the aggregation stood still for that round = the EXPOSED part of the transfer), and the fused
+    gradient all-reduce likewise.  Over a host-staged transport (gloo) the rounds are timed with the wall clock instead.
+    ``summary()`` reduces the records per (direction, round): bytes out / in, the largest single peer segment (what one xGMI link
+    carries), mean ms, mean exposed ms, GB/s on that link and its fraction of the link rate."""
+
+    def __init__(self, device: torch.device):
+        self.device, self.on = torch.device(device), False
+        self.rounds, self.waits, self.reduces = [], [], []
+
+    def clear(self):
+        self.rounds, self.waits, self.reduces = [], [], []
+
+    @staticmethod
+    def _ms(x):
+        a, b = x
+        if isinstance(a, float):
+            return 1e3 * (b - a)
+        return a.elapsed_time(b)
+
+    def summary(self, link_gbs: float = XGMI_LINK_GBS):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        out = {}
+        keys = sorted({(t, r) for (t, r, *_x) in self.rounds})
+        for tag, r in keys:
+            recs = [x for x in self.rounds if x[0] == tag and x[1] == r]
+            ms = [self._ms(x[5]) for x in recs]
+            ex = [self._ms(x[2]) for x in self.waits if x[0] == tag and x[1] == r]
+            _, _, b_out, b_in, b_peer, _ = recs[-1]
+            mean_ms = sum(ms) / len(ms)
+            gbs = b_peer / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
+            out.setdefault(tag, []).append({
+                "round": r, "calls": len(recs), "bytes_out": b_out, "bytes_in": b_in, "max_peer_bytes": b_peer,
+                "ms": mean_ms, "exposed_ms": (sum(ex) / len(ex)) if ex else mean_ms,
+                "GBs_per_link": gbs, "frac_of_%dGBs" % int(link_gbs): gbs / link_gbs,
+                "bound_ms_at_link_rate": b_peer / (link_gbs * 1e9) * 1e3})
+        if self.reduces:
+            ms = [self._ms(x[1]) for x in self.reduces]
+            ex = [self._ms(x[2]) for x in self.reduces]
+            out["allreduce"] = {"calls": len(ms), "bytes": self.reduces[-1][0], "ms": sum(ms) / len(ms), "exposed_ms": sum(ex) / len(ex)}
+        return out
+
+
 class BoundaryExchange:
     """Rank p's boundary-row slabs and the round-wise all-to-all-v over them (shared by the GCN
     aggregation engine and the GAT engine)."""
@@ -236,8 +286,39 @@ class BoundaryExchange:
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.overlap else None
         # PGCN.py:78-83 counters (rows and messages); host integers -> no device kernels
         self.stats = {"send_volume": 0, "recv_volume": 0, "send_nmsg": 0, "recv_nmsg": 0}
+        self.probe: Optional[ExchangeProbe] = None     # bench.py attaches one for its eager timed region
 
     # ------------------------------------------------------------------
+    def _probing(self) -> Optional[ExchangeProbe]:
+        p = self.probe
+        return p if (p is not None and p.on) else None
+
+    def _host_staged(self) -> bool:
+        return (not self.on_gpu) or getattr(self.exch, "backend", "") == "gloo"
+
+    def _round_bytes(self, src_off, dst_off, f):
+        seg = lambda off, q: (off[q + 1] - off[q]) * f * 4
+        peers = [q for q in range(self.size) if q != self.rank]
+        peer = max([max(seg(src_off, q), seg(dst_off, q)) for q in peers] or [0])
+        return (src_off[-1] - src_off[0]) * f * 4, (dst_off[-1] - dst_off[0]) * f * 4, peer
+
+    def _timed(self, stream, fn):
+        """Run fn() bracketed for the probe: HIP events on `stream`, or the wall clock over a host-staged transport."""
+        if self._host_staged():
+            import time
+            if self.on_gpu:
+                torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            fn()
+            if self.on_gpu:
+                torch.cuda.synchronize(self.device)
+            return (t0, time.perf_counter())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        fn()
+        e1.record(stream)
+        return (e0, e1)
+
     def _slab(self, name: str, rows: int, f: int) -> torch.Tensor:
         key = (name, f)
         t = self._buf.get(key)
@@ -261,14 +342,21 @@ class BoundaryExchange:
         b0, b1 = dst_off[0], dst_off[-1]
         self.exch.alltoallv(src[a0:a1], [o - a0 for o in src_off], dst[b0:b1], [o - b0 for o in dst_off], f)
 
-    def _exchange_all(self, src, src_offs, dst, dst_offs, f, ready=None):
+    def _exchange_all(self, src, src_offs, dst, dst_offs, f, ready=None, tag="forward"):
         """All rounds of one boundary-row exchange.  ``ready[r]`` (optional) is an event after which
         round r's source rows exist.  Returns one waiter per round (call it on the compute stream
-        before touching that round's destination rows)."""
+        before touching that round's destination rows).  ``tag`` names the exchange for an attached ExchangeProbe."""
         self._count(src_offs[-1][-1], dst_offs[-1][-1])
+        probe = self._probing()
         if not self.overlap:
             for r in range(self.rounds):
-                self._exchange_round(src, src_offs[r], dst, dst_offs[r], f)
+                if probe is None:
+                    self._exchange_round(src, src_offs[r], dst, dst_offs[r], f)
+                else:
+                    cur = torch.cuda.current_stream(self.device) if self.on_gpu else None
+                    span = self._timed(cur, lambda: self._exchange_round(src, src_offs[r], dst, dst_offs[r], f))
+                    probe.rounds.append((tag, r) + self._round_bytes(src_offs[r], dst_offs[r], f) + (span,))
+                    probe.waits.append((tag, r, span))           # nothing overlaps it: all of it is exposed
             return [lambda: None] * self.rounds
         main = torch.cuda.current_stream(self.device)
         if ready is None:
@@ -279,10 +367,23 @@ class BoundaryExchange:
         with torch.cuda.stream(self.comm_stream):
             for r in range(self.rounds):
                 self.comm_stream.wait_event(ready[r])
-                self._exchange_round(src, src_offs[r], dst, dst_offs[r], f)
+                if probe is None:
+                    self._exchange_round(src, src_offs[r], dst, dst_offs[r], f)
+                else:
+                    span = self._timed(self.comm_stream, lambda: self._exchange_round(src, src_offs[r], dst, dst_offs[r], f))
+                    probe.rounds.append((tag, r) + self._round_bytes(src_offs[r], dst_offs[r], f) + (span,))
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
-                waiters.append(lambda d=done: main.wait_event(d))
+                if probe is None or self._host_staged():
+                    waiters.append(lambda d=done: main.wait_event(d))
+                else:
+                    def wait(d=done, r=r):
+                        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        w0.record(main)
+                        main.wait_event(d)
+                        w1.record(main)
+                        probe.waits.append((tag, r, (w0, w1)))
+                    waiters.append(wait)
         return waiters
 
     def allreduce_sum(self, buf: torch.Tensor) -> None:
@@ -295,23 +396,46 @@ class BoundaryExchange:
         if not buf.is_contiguous():
             raise ValueError("allreduce_sum needs a contiguous buffer")
         if buf.is_cuda and getattr(self.exch, "backend", "") == "gloo":
-            h = buf.cpu()
-            self.exch.allreduce_sum(h)
-            buf.copy_(h)
+            def staged():
+                h = buf.cpu()
+                self.exch.allreduce_sum(h)
+                buf.copy_(h)
+            probe = self._probing()
+            if probe is None:
+                staged()
+            else:
+                span = self._timed(None, staged)
+                probe.reduces.append((buf.numel() * buf.element_size(), span, span))
             return
+        probe = self._probing()
+        nbytes = buf.numel() * buf.element_size()
         if not self.overlap:
-            self.exch.allreduce_sum(buf)
+            if probe is None:
+                self.exch.allreduce_sum(buf)
+            else:
+                span = self._timed(torch.cuda.current_stream(self.device) if self.on_gpu else None, lambda: self.exch.allreduce_sum(buf))
+                probe.reduces.append((nbytes, span, span))
             return
         main = torch.cuda.current_stream(self.device)
         ev = torch.cuda.Event()
         ev.record(main)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
-            self.exch.allreduce_sum(buf)
+            if probe is None:
+                self.exch.allreduce_sum(buf)
+            else:
+                span = self._timed(self.comm_stream, lambda: self.exch.allreduce_sum(buf))
             done = torch.cuda.Event()
             done.record(self.comm_stream)
         buf.record_stream(self.comm_stream)
-        main.wait_event(done)
+        if probe is None:
+            main.wait_event(done)
+        else:
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0.record(main)
+            main.wait_event(done)
+            w1.record(main)
+            probe.reduces.append((nbytes, span, (w0, w1)))
 
 
 class AggregationEngine(BoundaryExchange):
@@ -345,7 +469,7 @@ class AggregationEngine(BoundaryExchange):
         send = self._slab("send", self.n_send, f)
         halo = self._slab("halo", self.n_halo, f)
         self.k.gather_rows(H, self.send_idx, send)
-        waits = self._exchange_all(send, self.round_send_off, halo, self.round_recv_off, f)
+        waits = self._exchange_all(send, self.round_send_off, halo, self.round_recv_off, f, tag="forward")
         self.k.spmm(self.A_loc, H, C)            # overlaps the exchange (main.c:271)
         for r in range(self.rounds):
             waits[r]()
@@ -372,7 +496,7 @@ class AggregationEngine(BoundaryExchange):
                 ev.record(torch.cuda.current_stream(self.device))
                 ready.append(ev)
         waits = self._exchange_all(partial, self.round_recv_off, back, self.round_send_off, f,
-                                   ready if self.overlap else None)
+                                   ready if self.overlap else None, tag="backward")
         self.k.spmm(self.A_loc_T, G, dH)
         for r in range(self.rounds):
             waits[r]()

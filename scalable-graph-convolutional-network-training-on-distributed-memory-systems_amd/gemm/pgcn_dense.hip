@@ -73,10 +73,16 @@ PG_HD void read_b(u32x4 (&b)[3], const char *image, int ks, int nb, int lane) {
     for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(image + image_offset(pl, ks, nb, lane));
 }
 
-// v[LANE] = x (x wave-uniform); the other lanes keep their value
-template <int LANE>
-PG_HD void write_lane(uint32_t &v, uint32_t x) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(x), "n"(LANE));
+// The sign-mask bits of accumulator register R over the wave: lane R of `word` takes the ballot's low half (the rows of half wave 0),
+// lane 16 + R its high half.  One asm block, because the compare -> v_writelane hand-over through VCC needs wait states that the
+// compiler's hazard recogniser does not insert around inline asm (first hardware run of r06: v_writelane issued straight after the
+// v_cmp read the PREVIOUS compare's VCC -- 20 % of the mask bits belonged to the neighbouring register).
+template <int R>
+PG_HD void mask_lanes(uint32_t &word, float x) {
+    asm volatile("v_cmp_nge_f32_e32 vcc, 0, %1\n\ts_nop 4\n\tv_writelane_b32 %0, vcc_lo, %2\n\tv_writelane_b32 %0, vcc_hi, %3"
+                 : "+v"(word)
+                 : "v"(x), "n"(R), "n"(16 + R)
+                 : "vcc");
 }
 
 struct Args {
@@ -192,9 +198,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_kernel(const Args a) {
         if constexpr (MODE == 0) {
             static_for<kChunk * c, kChunk * (c + 1)>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(mask_bit_of(x[r]));
-                write_lane<r>(mword, (uint32_t)bal);
-                write_lane<16 + r>(mword, (uint32_t)(bal >> 32));
+                mask_lanes<r>(mword, x[r]);               // (mask_bit_of: !(x <= 0))
             });
             // (bits of columns beyond N come out of zero products: 0 > 0 is false; lanes 32..63 and blocks beyond the mask's
             //  width aim outside the window)

@@ -45,16 +45,27 @@ def pspmm_worker(rank, P, port, path_A, path_pv, f, seed, q):
     own = eng.part.owned.numpy()
     Hfull, Gfull = golden_inputs(A.shape[0], f, seed)
     H = torch.tensor(Hfull[own], requires_grad=True)
+    from conftest import pkg as _pkg
+    probe = eng.probe = _pkg("engine").ExchangeProbe(torch.device("cpu"))      # what bench.py attaches at N > 1 (r06)
+    probe.on = P > 1
     out = M.PSpMM.apply(eng, H)
     M._sync_stats(eng)                       # counters live in the engine; run() publishes them
     stats_fwd = {k: int(v) for k, v in M.stats.items()}
     out.backward(torch.tensor(Gfull[own]))
+    if P > 1:
+        g = torch.ones(3 * f)
+        eng.allreduce_sum(g)
+        assert torch.equal(g, torch.full((3 * f,), float(P)))
+    probe.on = False
+    exchange = probe.summary()
+    eng.probe = None
     # the standalone communicate_fgm entry point
     halo = M.communicate_fgm(H.detach(), backward=False)
     ok_halo = bool(np.array_equal(halo.numpy(), Hfull[eng.part.halo_global.numpy()]))
     q.put({"rank": rank, "own": own, "fwd": out.detach().numpy(), "bwd": H.grad.numpy(),
            "stats_fwd": stats_fwd, "stats_all": {k: int(v) for k, v in M.stats.items()},
-           "ok_halo": ok_halo,
+           "ok_halo": ok_halo, "exchange": exchange, "rounds": eng.rounds,
+           "round_send_off": eng.round_send_off, "round_recv_off": eng.round_recv_off,
            "send_map": {k: v.numpy() for k, v in M.send_map.items()}})
     dist.barrier()
     dist.destroy_process_group()

@@ -53,6 +53,23 @@ def test_pspmm_forward_backward(name, mtx, pv, P):
         # after fwd + bwd + one more forward exchange: 3 exchanges
         assert r["stats_all"]["send_nmsg"] == 3 * (P - 1)
         assert r["stats_all"]["send_volume"] == 2 * m["stats_fwd"]["send_volume"] + m["stats_fwd"]["recv_volume"]
+        # the exchange probe of bench.py's N > 1 line (r06): one record per round and direction, bytes from the slab offsets
+        ex = r["exchange"]
+        if P == 1:
+            assert ex == {}
+            continue
+        f = meta["f"]
+        assert sorted(ex) == ["allreduce", "backward", "forward"] and ex["allreduce"]["bytes"] == 3 * f * 4 and ex["allreduce"]["calls"] == 1
+        for tag, so, ro in (("forward", r["round_send_off"], r["round_recv_off"]), ("backward", r["round_recv_off"], r["round_send_off"])):
+            assert [e["round"] for e in ex[tag]] == list(range(r["rounds"]))
+            for e in ex[tag]:
+                k = e["round"]
+                assert e["calls"] == 1 and e["bytes_out"] == (so[k][-1] - so[k][0]) * f * 4 and e["bytes_in"] == (ro[k][-1] - ro[k][0]) * f * 4
+                peers = [q for q in range(P) if q != r["rank"]]
+                assert e["max_peer_bytes"] == max(max(so[k][q + 1] - so[k][q], ro[k][q + 1] - ro[k][q]) for q in peers) * f * 4
+                assert e["ms"] >= 0 and e["exposed_ms"] == e["ms"]          # host-staged transport: nothing overlaps it
+                assert abs(e["GBs_per_link"] - e["max_peer_bytes"] / max(e["ms"], 1e-12) / 1e6) <= 1e-6 * max(e["GBs_per_link"], 1) or e["ms"] == 0
+                assert abs(e["frac_of_153GBs"] - e["GBs_per_link"] / 153.0) < 1e-9 and e["bound_ms_at_link_rate"] >= 0
     assert rel_err(fwd, arrays["fwd"]) < TOL                     # reference PSpMM.forward
     if "bwd" in arrays:
         assert rel_err(bwd, arrays["bwd"]) < TOL                 # reference PSpMM.backward (P <= 2)

@@ -23,4 +23,4 @@ run() { n=$(echo "$1" | tr '/+ =,' '_-__.' | tr -s '_')_$2
   PGCN_TUNING="$1" timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$out/bench_$n.json" 2> "$out/bench_$n.err"
   python -c "
 import json; r=json.load(open('$out/bench_$n.json')); print('%-20s'%'[$1]', 'ms/epoch %.3f'%r['ms_per_step'], 'loss', r.get('loss'), 'group ms', r['roofline']['avg_launch_ms'], '|', r['config'].get('dense_fused'))" || tail -3 "$out/bench_$n.err"; }
-for rep in 1 2; do for t in "dense_fused=3" "dense_fused=2" "dense_fused=0"; do run "$t" $rep; done; done
+for rep in 1 2; do for t in "dense_fused=3" "dense_fused=2"; do run "$t" $rep; done; done
