@@ -295,6 +295,40 @@ class NoExchange:
         pass
 
 
+class PacedExchange(NoExchange):
+    """--emulate-rank r/P --pace-exchange GBs: nothing is sent, but every round OCCUPIES the stream it is issued on (the comm
+    stream) for as long as its largest peer segment would take on one xGMI link at the given rate (a spin kernel: no memory
+    traffic, one wave), the gradient all-reduce for a fixed 25 us.  With engine.ExchangeProbe on, the line then says how much of a
+    transfer of that length the aggregation hides (`exposed_ms`) -- a PRICE of the N > 1 overlap from one GPU, not a measurement
+    of xGMI (r06)."""
+
+    def __init__(self, rank, gbs, dev):
+        self.rank, self.rate, self.dev = rank, float(gbs) * 1e9, dev
+        self.name = "none (emulated rank; every round paced at %.0f GB/s per link)" % gbs
+        # cycles of torch.cuda._sleep per microsecond, measured once
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000000)
+        e0.record()
+        torch.cuda._sleep(20000000)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        self.cycles_per_us = 20000000.0 / max(e0.elapsed_time(e1) * 1e3, 1e-3)
+
+    def _spin(self, seconds):
+        c = int(seconds * 1e6 * self.cycles_per_us)
+        if c > 0:
+            torch.cuda._sleep(c)
+
+    def alltoallv(self, send, send_off, recv, recv_off, f):
+        size = len(send_off) - 1
+        peer = max([max(send_off[q + 1] - send_off[q], recv_off[q + 1] - recv_off[q]) for q in range(size) if q != self.rank] or [0])
+        self._spin(peer * f * 4 / self.rate)
+
+    def allreduce_sum(self, buf):
+        self._spin(25e-6)
+
+
 def real_mtx_for(workload):
     """A real dataset dropped next to the benchmark is used instead of the synthetic stand-in:
     $PGCN_DATA_DIR/<workload>.mtx (default ./data/), written e.g. by the reference's preprocess/GrB-GNN-IDG.py."""
@@ -619,7 +653,7 @@ def bench_gat(args, rank, world, dev, backend, stage):
     K = kernels.HipKernels(dev)
     emul = bool(args.emulate_rank and part.size > 1)
     if emul:
-        exch = NoExchange()
+        exch = PacedExchange(part.rank, args.pace_exchange, dev) if args.pace_exchange > 0 else NoExchange()
     else:
         exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
     eng = gat.GatEngine(part, K, dev, exch, mode="standard")
@@ -654,6 +688,10 @@ def bench_gat(args, rank, world, dev, backend, stage):
         dist.barrier()
     torch.cuda.synchronize()
     timer.on = not args.no_kernel_timing
+    xprobe = None
+    if world > 1 and not args.no_kernel_timing and not emul:      # what the exchange costs and what of it the compute stream sees (r06)
+        xprobe = eng.probe = pkg("engine").ExchangeProbe(dev)
+        xprobe.on = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -663,6 +701,11 @@ def bench_gat(args, rank, world, dev, backend, stage):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.on = False
+    exchange_report = None
+    if xprobe is not None:
+        xprobe.on = False
+        exchange_report = exchange_summary(xprobe, pkg("PGCN"), dev, world)
+        eng.probe = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         pkg("PGCN")._all_reduce(t, dist.ReduceOp.MAX)
@@ -711,6 +754,8 @@ def bench_gat(args, rank, world, dev, backend, stage):
         vol = torch.tensor([eng.stats["send_volume"]], dtype=torch.float64, device=dev)
         pkg("PGCN")._all_reduce(vol)
         out["exchange_rows_total"] = float(vol)
+        if exchange_report is not None:
+            out["exchange"] = exchange_report
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -766,6 +811,9 @@ def main():
                          "step (r04: 3.06 ms eager, 2.71 replayed on rank 0 of 8), off for N = 1 (device-bound: 10.66 vs 10.64 ms)")
     ap.add_argument("--emulate-rank", default=None, metavar="r/P",
                     help="one GPU runs rank r of a P-rank job with a no-op exchange (per-rank compute of 2/4/8 GPUs)")
+    ap.add_argument("--pace-exchange", type=float, default=0.0, metavar="GBs",
+                    help="with --emulate-rank: every exchange round occupies the comm stream as long as its largest peer segment takes at "
+                         "this rate per link (153 = one xGMI link) -- prices the overlap, reported under `exchange`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -823,7 +871,7 @@ def main():
     stage("partition built")
     K = kernels.HipKernels(dev)
     if args.emulate_rank and part.size > 1:
-        exch = NoExchange()
+        exch = PacedExchange(part.rank, args.pace_exchange, dev) if args.pace_exchange > 0 else NoExchange()
     else:
         exch = engine.make_exchanger(rank, world, dev, os.environ.get("PGCN_EXCHANGE", "auto")) if world > 1 else None
     eng = engine.AggregationEngine(part, K, dev, exch)
@@ -874,7 +922,8 @@ def main():
     # N > 1: what the boundary exchange costs and how much of it the compute stream sees (engine.ExchangeProbe: HIP events on the comm
     # stream around every round, on the compute stream around every wait for one, and around the fused gradient all-reduce)
     xprobe = None
-    if world > 1 and not args.no_kernel_timing and not (args.emulate_rank and part.size > 1):
+    paced = bool(args.emulate_rank and part.size > 1 and args.pace_exchange > 0)
+    if (world > 1 or paced) and not args.no_kernel_timing and (paced or not (args.emulate_rank and part.size > 1)):
         xprobe = eng.probe = engine.ExchangeProbe(dev)
         xprobe.on = True
     t0 = time.perf_counter()
@@ -1018,8 +1067,8 @@ def main():
         P._all_reduce(vol)
         out["exchange_rows_total"] = float(vol)
         out["selftest"] = selftest
-        if exchange_report is not None:
-            out["exchange"] = exchange_report
+    if exchange_report is not None:
+        out["exchange"] = exchange_report
     out["config"]["timed_region"] = "%d eagerly launched training steps" % args.steps
     if args.graph == "on" or (args.graph == "auto" and world > 1 and dev.type == "cuda"):
         # LAST thing that touches the device: the eager line above is complete.  A replay whose collectives never finish cannot be

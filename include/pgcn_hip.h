@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PGCN_ABI_VERSION 2   /* r04: + pgcn_spmm_dense_bf16x3_f32; r03 changed layouts of the GAT entry points (entry-major de / src) */
+#define PGCN_ABI_VERSION 3   /* r06: panel_list of pgcn_spmm_dense_bf16x3_f32 holds first ROWS (any origin); pgcn_spmm_dense_f32 and the slice-pair
+                              * plan option are gone.  r04: + pgcn_spmm_dense_bf16x3_f32; r03: entry-major de / src of the GAT entry points */
 
 #define PGCN_OK 0
 #define PGCN_EINVAL (-1)  /* bad argument (null pointer, misaligned, negative size) */
@@ -227,8 +228,8 @@ int pgcn_spmm_strip_f32(const int32_t *work, int64_t nwork, const int32_t *recs,
  *     (65 536 fp32 per block, 16-byte aligned: the A-operand order of the instruction for wave w of 8);
  *   work: 4 x int32 per piece {block row, first block, number of blocks, first slot}; a piece leaves a 512 x f block of
  *     partial sums in partial_ws (slot rows of f floats) for pgcn_spmm_fixup_f32;
- *   panel_list[npanels]: the distinct column blocks the blocks refer to (rows [128 p, 128 p + 128) of B, rows >= ncols
- *     read as zero), blk_img[b]: position of block b's column block in panel_list.
+ *   panel_list[npanels]: FIRST ROW p of the distinct panels the blocks refer to (rows [p, p + 128) of B -- any p since ABI 3, not
+ *     only multiples of 128 -- rows >= ncols read as zero), blk_img[b]: position of block b's panel in panel_list.
  * The call first splits the listed panels of B into bf16 planes in image_ws (pgcn_dense_bf16x3_image_bytes(npanels, f)
  * bytes, 16-byte aligned; scratch, rewritten by every call), then runs the blocks.  Zeros of a block are structural:
  * a panel holding Inf / NaN takes an exact (slow) path that multiplies only where A != 0.  Any f, ldb, alignment of B. */
@@ -325,6 +326,15 @@ int pgcn_gat_edge_softmax_f32(const int64_t *rowptr, const int32_t *col, int64_t
                               int64_t nrows_block, const float *s1, int64_t lds1, const float *s2,
                               int64_t lds2, int32_t heads, float slope, int32_t mode, int64_t n_global,
                               float *alpha, float *beta, float *rowstat, pgcn_stream_t stream);
+/* The statistics-only form (alpha = NULL) for the rows listed in `rows` -- the LONG rows of a structure -- by chunks of `chunk`
+ * entries (>= 512): one workgroup per (row, chunk), then a merge of a row's (maximum, sum) pairs in chunk order; the same maximum
+ * as the one-pass kernel, the sum to fp32 rounding, deterministic.  ws: nrows_list * ceil(max_row_len / chunk) * heads * 2 floats,
+ * 8-byte aligned.  (r06: the hub rows of the Reddit shape cost 0.77 ms per layer as one workgroup per row.) */
+int pgcn_gat_edge_stats_chunked_f32(const int64_t *rowptr, const int32_t *col, int64_t nrows, int64_t nnz, const int32_t *rows,
+                                    int64_t nrows_list, int64_t max_row_len, int32_t chunk, const float *s1, int64_t lds1,
+                                    const float *s2, int64_t lds2, int32_t heads, float slope, int32_t mode, int64_t n_global,
+                                    float *beta, float *rowstat, float *ws, int64_t ws_elems, pgcn_stream_t stream);
+
 int pgcn_gat_edge_weights_t_f32(const int64_t *rowptr_t, const int32_t *col_t, int64_t nrows_t,
                                 int64_t nnz, const int32_t *rows_wave, int64_t nrows_wave,
                                 const int32_t *rows_block, int64_t nrows_block, const float *s2,

@@ -55,7 +55,7 @@
 
 #pragma clang diagnostic ignored "-Winline-asm"
 
-// Measurement builds (tools/micro/build_dense3_bench.sh compiles this file again with -DPGCN_DENSE3_PROBE=N and another
+// Measurement builds (r04's tools/micro/dense3_bench, in the git history, compiled this file again with -DPGCN_DENSE3_PROBE=N and another
 // entry-point name; the library is built with 0 and every branch below folds away).  1: no MFMAs (TIMING ONLY, wrong
 // sums); 5: the real kernel with s_memtime phase timers: every wave writes {ticks waiting at the top of a quarter
 // (copies + barrier), ticks computing, quarters, whole loop} to the first float of its first four slot rows.
@@ -113,7 +113,7 @@ __device__ __forceinline__ f32x16 mma(const u32x4 &a, const u32x4 &b, const f32x
 // grid (panels in the list, feature blocks of 128); thread t: column n = t & 127, k groups 8 (t >> 7) .. + 8
 __global__ __launch_bounds__(kSplitThreads) void spmm_split_panels_kernel(const int32_t *__restrict__ panel_list, const float *__restrict__ B,
                                                                   int64_t ldb, int64_t ncols, int32_t f, u32x4 *__restrict__ image) {
-    const int64_t r0 = (int64_t)panel_list[blockIdx.x] * kT;
+    const int64_t r0 = (int64_t)panel_list[blockIdx.x];          // first row of the panel (r06: any row -- a grid aligned to the vertex order's bands)
     const int fcol0 = blockIdx.y * kT;
     const int n = threadIdx.x & (kT - 1);
     const bool n_ok = fcol0 + n < f;
@@ -346,7 +346,7 @@ __device__ __noinline__ void dense3_piece_exact(const int4 wk, const int32_t *__
     const int hi = lane >> 5, lo = lane & 31;
     for (int t = 0; t < wk.z; ++t) {
         const int64_t bi = (int64_t)wk.y + t;
-        const int64_t prow0 = (int64_t)panel_list[blk_img[bi]] * kT;
+        const int64_t prow0 = (int64_t)panel_list[blk_img[bi]];
         for (int k = 0; k < kT; ++k) {
             const int ks = k >> 4, hk = (k >> 3) & 1, h = (k >> 2) & 1, e = k & 3;
             float b[NBLK];

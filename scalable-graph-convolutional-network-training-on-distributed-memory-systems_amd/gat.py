@@ -54,6 +54,12 @@ class GatGraph:
     fwd_block: torch.Tensor
     bwd_wave: torch.Tensor
     bwd_block: torch.Tensor
+    # r06: the transposed structure once more as its halo rows and its local rows (N > 1 only): the backward computes the halo rows
+    # first and sends them home while the local rows are computed (GatEngine.backward)
+    bwd_halo: Optional[HostCSR] = None       # n_halo x n_local
+    bwd_local: Optional[HostCSR] = None      # n_local x n_local
+    bwd_halo_lists: Optional[tuple] = None   # (wave rows, block rows) of each
+    bwd_local_lists: Optional[tuple] = None
 
     @property
     def nnz(self) -> int:
@@ -67,7 +73,8 @@ def _row_lists(rowptr: torch.Tensor, long_row: int):
     return order[~big].to(torch.int32).contiguous(), order[big].to(torch.int32).contiguous()
 
 
-def build_gat_graph(part: Partition, positive_only: bool = False, long_row: Optional[int] = None) -> GatGraph:
+def build_gat_graph(part: Partition, positive_only: bool = False, long_row: Optional[int] = None,
+                    split_backward: bool = False) -> GatGraph:
     """Coalesce the partition's pieces into one pattern over [local ; halo] columns.
     Duplicate coordinates count once (the reference masks a DENSE matrix, PGAT.py:146);
     ``positive_only`` keeps the coordinates whose summed value is > 0 (``A > 0``)."""
@@ -100,7 +107,15 @@ def build_gat_graph(part: Partition, positive_only: bool = False, long_row: Opti
     lr = LONG_ROW if long_row is None else long_row
     fw, fb = _row_lists(fwd.rowptr, lr)
     bw, bb = _row_lists(bwd.rowptr, lr)
-    return GatGraph(n_p, n_h, fwd, bwd, perm.contiguous(), fw, fb, bw, bb)
+    g = GatGraph(n_p, n_h, fwd, bwd, perm.contiguous(), fw, fb, bw, bb)
+    if n_h > 0 and split_backward:
+        cb, rb = c[perm], r[perm]
+        hal = cb >= n_p
+        g.bwd_halo = csr_from_coo(cb[hal] - n_p, rb[hal], ones[:int(hal.sum())], n_h, n_p, nslices=St, core=False)
+        g.bwd_local = csr_from_coo(cb[~hal], rb[~hal], ones[:int((~hal).sum())], n_p, n_p, nslices=St, core=False)
+        g.bwd_halo_lists = _row_lists(g.bwd_halo.rowptr, lr)
+        g.bwd_local_lists = _row_lists(g.bwd_local.rowptr, lr)
+    return g
 
 
 @dataclass
@@ -126,13 +141,16 @@ class GatEngine(BoundaryExchange):
     """Device-resident GAT structures of one rank + forward / backward of the aggregation."""
 
     def __init__(self, part: Partition, kernels, device: torch.device, exchanger=None, mode: str = "standard",
-                 slope: float = 0.2, long_row: Optional[int] = None):
-        super().__init__(part, kernels, device, exchanger, overlap=False)
+                 slope: float = 0.2, long_row: Optional[int] = None, overlap: Optional[bool] = None):
+        # r06: the exchanges run on the comm stream like the GCN engine's (PGCN_OVERLAP=0 switches it off).  The forward needs the halo
+        # rows of [Z | s2] before its one gather pass can start; the BACKWARD computes the halo rows of [dZ | ds2] first and sends them
+        # home while the local rows are computed (PGAT.py:138-151; the overlap structure of Parallel-GCN/main.c:238-299)
+        super().__init__(part, kernels, device, exchanger, overlap=overlap)
         if mode not in MODES:
             raise ValueError("mode must be 'standard' or 'reference', got %r" % (mode,))
         self.mode, self.mode_id, self.slope = mode, MODES[mode], float(slope)
         self.n_global = part.n
-        g = build_gat_graph(part, positive_only=(mode == "reference"), long_row=long_row)
+        g = build_gat_graph(part, positive_only=(mode == "reference"), long_row=long_row, split_backward=self.overlap)
         self.graph = g
         self.nnz = g.nnz
         # the provider's plan parameters are the GCN path's: the attention structures get their own (tuning.gat_chunk / gat_small_row),
@@ -141,6 +159,10 @@ class GatEngine(BoundaryExchange):
         small = max(int(getattr(kernels, "small_row", 0)), int(_T.gat_small_row))
         self.fwd = kernels.prepare_gat(g.fwd, g.fwd_wave, g.fwd_block, chunk=chunk, small_row=small)
         self.bwd = kernels.prepare_gat(g.bwd, g.bwd_wave, g.bwd_block, chunk=chunk, small_row=small)
+        self.bwd_halo = self.bwd_local = None
+        if g.bwd_halo is not None:
+            self.bwd_halo = kernels.prepare_gat(g.bwd_halo, *g.bwd_halo_lists, chunk=chunk, small_row=small)
+            self.bwd_local = kernels.prepare_gat(g.bwd_local, *g.bwd_local_lists, chunk=chunk, small_row=small)
         self.perm = g.perm.to(self.device)
         self._inv_perm = None              # forward entry -> its position in the transposed structure (built on demand)
         self._scratch = {}
@@ -270,6 +292,21 @@ class GatEngine(BoundaryExchange):
             dZc = pack                 # the kernels write [dZ | ds2] straight into the gradient that goes back (no slab, no copy)
         else:
             dZc = self._slab("gat_dzc", n_p + n_h, Fp)[:n_p + n_h]
+        if st.fused and self.bwd_halo is not None and self.overlap and n_h > 0:
+            # N > 1 (r06): the same pass in two parts -- the HALO rows of [dZ | ds2] first, their way home on the comm stream under the
+            # local rows' part
+            if self.k.spmm_heads_grad(self.bwd_halo, st.rowstat, st.s2c[n_p:], self.slope, self.mode_id, dOut, st.Zc[n_p:], t,
+                                      dZc[n_p:], None, K, d):
+                if Fp > F + K:
+                    dZc[n_p:, F + K:].zero_()
+                back = self._slab("gat_send", self.n_send, Fp)
+                waits = self._exchange_all(dZc[n_p:], self.round_recv_off, back, self.round_send_off, Fp, tag="backward")
+                if not self.k.spmm_heads_grad(self.bwd_local, st.rowstat, st.s2c[:n_p], self.slope, self.mode_id, dOut, st.Zc[:n_p], t,
+                                              dZc[:n_p], None, K, d):
+                    raise RuntimeError("the local part of the fused GAT backward was refused after its halo part was taken")
+                ds1 = dots[1] if dots is not None and dots[1] is not None else \
+                    (dOut.view(n_p, K, d) * st.V[:, :F].view(n_p, K, d)).sum(-1) - t * st.V[:, F:F + K]
+                return self._finish_backward(st, dOut, dZc, ds1, pack, waits=(back, waits))
         if st.fused:
             # one gather pass: dZc = A_alpha^T . dOut and ds2 = the row sums of the edge gradient, which is not stored:
             # ds1 = its column sums = <dOut_i, V_i> - t_i C_i from the forward pass's second accumulator
@@ -327,17 +364,21 @@ class GatEngine(BoundaryExchange):
         return self._finish_backward(st, dOut, dZc, ds1, pack)
 
     def _finish_backward(self, st: GatLayerState, dOut: torch.Tensor, dZc: torch.Tensor, ds1: torch.Tensor,
-                         pack: Optional[torch.Tensor] = None):
-        """Halo rows of [dZ | ds2] back to their owners (added), then the owned rows."""
+                         pack: Optional[torch.Tensor] = None, waits=None):
+        """Halo rows of [dZ | ds2] back to their owners (added), then the owned rows.  ``waits`` = (slab, waiters) of an exchange
+        of the halo rows that is already on its way (the split backward)."""
         K, d = st.heads, st.d
         F = K * d
         n_p, n_h = self.n_local, self.n_halo
         Fp = st.Zc.shape[1]
         if Fp > F + K:
-            dZc[:, F + K:].zero_()
+            (dZc[:n_p] if waits is not None else dZc)[:, F + K:].zero_()
         if self.size > 1:                                   # partial rows of [dZ | ds2] back to their owners, ADDED
-            back = self._slab("gat_send", self.n_send, Fp)
-            waits = self._exchange_all(dZc[n_p:], self.round_recv_off, back, self.round_send_off, Fp)
+            if waits is not None:
+                back, waits = waits
+            else:
+                back = self._slab("gat_send", self.n_send, Fp)
+                waits = self._exchange_all(dZc[n_p:], self.round_recv_off, back, self.round_send_off, Fp, tag="backward")
             for r in range(self.rounds):
                 waits[r]()
                 self.k.spmm(self.unpack[r], back, dZc[:n_p], accumulate=True)

@@ -59,6 +59,8 @@ class DeviceCSR:
     rows_block: Optional[torch.Tensor] = None  # ... and by one 256-thread workgroup each (hub rows)
     slice_off: Optional[torch.Tensor] = None   # int32 [nrows, 9] offsets of a row's 8 col % 8 slices (XCD-sliced storage)
     rows_all: Optional[torch.Tensor] = None    # int32 all rows, longest first
+    max_row_len: int = 0                       # GAT structures: entries of the longest row
+    stat_ws: Optional[torch.Tensor] = None     # ... and the work-space of the chunked row statistics
     launch_cache: dict = None                 # bound C-ABI calls per (ldb, ldc, f, accumulate)
 
     def __post_init__(self):
@@ -246,7 +248,8 @@ class HipKernels:
             d.dense3 = DeviceDense3(work.to(dev).contiguous(), h3.blk_img.to(dev).contiguous(), h3.vals3.to(dev).contiguous(),
                                     h3.panel_list.to(dev).contiguous(), h3.npieces, int(h3.panel_list.numel()), h3.nnz)
             w64 = work.cpu().to(torch.int64)
-            pieces.append(torch.stack([w64[:, 0] * STRIP_TR, torch.full_like(w64[:, 0], STRIP_TR), w64[:, 3]], 1))
+            # (a block may start at any row and its band may end inside it: the piece's own first row and row count)
+            pieces.append(torch.stack([h3.piece_row0.cpu().to(torch.int64), h3.piece_rows.cpu().to(torch.int64), w64[:, 3]], 1))
         wk = torch.cat(pieces)
         cntp = wk[:, 1]
         startp = torch.cumsum(cntp, 0) - cntp
@@ -431,6 +434,7 @@ class HipKernels:
             raise _lib.PgcnError("GAT structures are plain (sliced) CSR blocks")
         d = self.prepare(csr, pattern_only=True, chunk=chunk, small_row=small_row)        # (the attention kernels walk (row, slice) pieces)
         d.rows_wave = rows_wave.to(self.device, torch.int32).contiguous()
+        d.max_row_len = int((csr.rowptr[1:] - csr.rowptr[:-1]).max()) if csr.nrows else 0
         d.rows_block = rows_block.to(self.device, torch.int32).contiguous()
         if csr.nslices == 8 and csr.slice_cnt is not None and csr.ngroups == 1:
             off = torch.zeros((csr.nrows, 9), dtype=torch.int32, device=csr.slice_cnt.device)
@@ -613,8 +617,27 @@ class HipKernels:
         if rowstat is not None and not (rowstat.is_cuda and rowstat.dtype is torch.float32 and rowstat.is_contiguous()
                                         and rowstat.numel() == A.nrows * heads * 4):
             raise _lib.PgcnError("rowstat must be a contiguous fp32 [nrows, heads, 4] CUDA tensor")
+        lists = self._lists(A)
+        chunk = int(_T.gat_stat_chunk)
+        nblock = 0 if A.rows_block is None else int(A.rows_block.numel())
+        if alpha is None and chunk > 0 and nblock and A.max_row_len > 2 * chunk:
+            # statistics only: the long rows by chunks (r06: one workgroup per hub ROW cost 0.77 ms per layer on the Reddit shape)
+            maxc = -(-A.max_row_len // chunk)
+            need = nblock * maxc * heads * 2
+            ws = A.stat_ws
+            if ws is None or ws.numel() < need:
+                ws = A.stat_ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.pgcn_gat_edge_softmax_f32(
+                A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, lists[0], lists[1], None, 0, s1.data_ptr(),
+                s1.stride(0), s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, None, beta.data_ptr(),
+                _ptr(rowstat), self._stream()), "pgcn_gat_edge_softmax_f32")
+            _lib.check(self.lib.pgcn_gat_edge_stats_chunked_f32(
+                A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, lists[2], lists[3], A.max_row_len, chunk, s1.data_ptr(), s1.stride(0),
+                s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, beta.data_ptr(), _ptr(rowstat), ws.data_ptr(), ws.numel(),
+                self._stream()), "pgcn_gat_edge_stats_chunked_f32")
+            return
         _lib.check(self.lib.pgcn_gat_edge_softmax_f32(
-            A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, *self._lists(A), s1.data_ptr(),
+            A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, *lists, s1.data_ptr(),
             s1.stride(0), s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, _ptr(alpha), beta.data_ptr(),
             _ptr(rowstat), self._stream()), "pgcn_gat_edge_softmax_f32")
 

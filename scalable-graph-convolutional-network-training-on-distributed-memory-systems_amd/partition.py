@@ -183,13 +183,17 @@ class HostDense3:
     SpMM into a work-space (one 96 KB image per entry of ``panel_list`` and 128 features)."""
     nrows: int
     ncols: int
-    work: torch.Tensor        # int32 [npieces, 4] {block row, first block, number of blocks, first slot (local)}
-    blk_row: torch.Tensor     # int32 [nblocks]
-    blk_panel: torch.Tensor   # int32 [nblocks]
+    work: torch.Tensor        # int32 [npieces, 4] {block row id, first block, number of blocks, first slot (local)}
+    blk_row: torch.Tensor     # int32 [nblocks] block row id (blocks of one id share their 512 rows: they may share a piece)
+    blk_panel: torch.Tensor   # int32 [nblocks] panel id
     vals3: torch.Tensor       # fp32 [nblocks, 512 * 128]
-    panel_list: torch.Tensor  # int32 [npanels] the distinct panels of the blocks, ascending
+    panel_list: torch.Tensor  # int32 [npanels] FIRST ROW (of the dense operand) of the distinct panels of the blocks, ascending
     blk_img: torch.Tensor     # int32 [nblocks] position of a block's panel in panel_list
     coo: tuple                # (row, col, val) of the stored entries (host-side bookkeeping / checker)
+    blk_row0: torch.Tensor = None    # int32 [nblocks] first matrix row of a block (r06: any row, not only multiples of 512 -- a grid
+    blk_col0: torch.Tensor = None    # int32 [nblocks] first matrix column   aligned to the communities of the vertex order)
+    piece_row0: torch.Tensor = None  # int32 [npieces] first matrix row of a piece's 512-row partial block (the order of ``work``)
+    piece_rows: torch.Tensor = None  # int32 [npieces] rows of it that belong to the piece (the band may end inside the block)
 
     @property
     def nnz(self) -> int:
@@ -204,8 +208,10 @@ class HostDense3:
         return self.npieces * DENSE3_BR
 
 
-def build_dense3(r64, c64, v, bkey_local, nblocks, blk_row, blk_panel, nrows, ncols, piece: int = None) -> HostDense3:
-    """``bkey_local`` numbers the blocks 0..nblocks-1 in (block row, panel) order."""
+def build_dense3(r64, c64, v, bkey_local, nblocks, blk_row, blk_panel, nrows, ncols, piece: int = None,
+                 blk_row0=None, blk_col0=None, blk_rows=None) -> HostDense3:
+    """``bkey_local`` numbers the blocks 0..nblocks-1 in (block row id, panel id) order; ``blk_row0 / blk_col0`` are their origins
+    (default: the global 512 x 128 grid) and ``blk_rows`` the rows of a block that lie inside its band."""
     import numpy as np
     BR, TC = DENSE3_BR, CORE_TC
     piece = DENSE3_PIECE if piece is None else piece
@@ -215,8 +221,13 @@ def build_dense3(r64, c64, v, bkey_local, nblocks, blk_row, blk_panel, nrows, nc
         # blocks per piece -> launch group 1.747 / 1.663 / 1.642 ms)
         piece = int(min(8, max(1, -(-nblocks // 256))))
     dev = r64.device
+    if blk_row0 is None:
+        blk_row0, blk_col0 = blk_row.to(torch.int64) * BR, blk_panel.to(torch.int64) * TC
+        blk_rows = torch.clamp(nrows - blk_row0, max=BR)
+    blk_row0, blk_col0, blk_rows = blk_row0.to(torch.int64), blk_col0.to(torch.int64), blk_rows.to(torch.int64)
     vals = torch.zeros(nblocks * BR * TC, dtype=torch.float32, device=dev)
-    vals.index_add_(0, bkey_local * (BR * TC) + dense3_index(r64 % BR, c64 % TC), v.to(torch.float32))   # duplicates add
+    vals.index_add_(0, bkey_local * (BR * TC) + dense3_index(r64 - blk_row0[bkey_local], c64 - blk_col0[bkey_local]),
+                    v.to(torch.float32))                                                             # duplicates add
     brw = blk_row.cpu().numpy()
     run_start = np.r_[True, brw[1:] != brw[:-1]]
     pos_in_run = np.arange(nblocks) - np.maximum.accumulate(np.where(run_start, np.arange(nblocks), 0))
@@ -225,22 +236,45 @@ def build_dense3(r64, c64, v, bkey_local, nblocks, blk_row, blk_panel, nrows, nc
     kcnt = np.r_[kbeg[1:], nblocks] - kbeg
     lpt = np.argsort(-kcnt, kind="stable")
     work = np.stack([brw[kbeg][lpt], kbeg[lpt], kcnt[lpt], np.arange(len(kbeg)) * BR], 1).astype(np.int32)
-    plist, bimg = torch.unique(blk_panel.to(torch.int64), return_inverse=True)
+    first = torch.from_numpy(kbeg[lpt]).to(dev)
+    plist, bimg = torch.unique(blk_col0, return_inverse=True)              # (a panel id has one origin: unique origins = unique panels)
     return HostDense3(nrows, ncols, torch.from_numpy(work).to(dev), blk_row, blk_panel, vals.view(nblocks, BR * TC),
-                      plist.to(torch.int32), bimg.to(torch.int32), (r64, c64, v.to(torch.float32)))
+                      plist.to(torch.int32), bimg.to(torch.int32), (r64, c64, v.to(torch.float32)),
+                      blk_row0.to(torch.int32), blk_col0.to(torch.int32), blk_row0[first].to(torch.int32), blk_rows[first].to(torch.int32))
 
 
-def split_dense3(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int, tau: float = None):
+def band_grid(x64: torch.Tensor, size: int, unit: int, bands: Optional[torch.Tensor]):
+    """Cells of a 1-D grid of ``unit``-wide cells that restarts at every band start: (cell id, cell origin, end of the cell's
+    band, number of cells).  ``bands``: ascending int64 starts with bands[0] == 0 (None: one band = the plain global grid)."""
+    if bands is None or bands.numel() <= 1:
+        cell = x64 // unit
+        return cell, cell * unit, torch.full_like(x64, size), (size + unit - 1) // unit
+    bands = bands.to(x64.device, torch.int64)
+    ends = torch.cat([bands[1:], torch.tensor([size], dtype=torch.int64, device=x64.device)])
+    ncell = (ends - bands + unit - 1) // unit
+    base = torch.cumsum(ncell, 0) - ncell
+    k = torch.bucketize(x64, bands, right=True) - 1
+    j = (x64 - bands[k]) // unit
+    return base[k] + j, bands[k] + j * unit, ends[k], int(ncell.sum())
+
+
+def split_dense3(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int, tau: float = None,
+                 row_bands: Optional[torch.Tensor] = None, col_bands: Optional[torch.Tensor] = None):
     """Separate the entries of 512 x 128 blocks at least ``tau`` full.  Returns (keep_mask or None, HostDense3 or None).
-    With the default ``tau`` a matrix with fewer than DENSE3_MIN_BLOCKS such blocks keeps them for the other paths."""
+    With the default ``tau`` a matrix with fewer than DENSE3_MIN_BLOCKS such blocks keeps them for the other paths.
+    ``row_bands / col_bands`` (r06): starts of the bands the block grid restarts at -- the communities of the vertex order, so
+    that a community's diagonal block is tiled from ITS first vertex instead of wherever the global grid happens to cut it (the
+    planted-partition stand-in: 65 % of the entries sit inside communities at ~23 % fill, the global grid caught 20 %)."""
     min_blocks = DENSE3_MIN_BLOCKS if tau is None else 0
-    tau = DENSE3_TAU if tau is None else tau
+    banded = (row_bands is not None and row_bands.numel() > 1) or (col_bands is not None and col_bands.numel() > 1)
+    tau = (DENSE3_TAU_BANDED if banded else DENSE3_TAU) if tau is None else tau
     if r.numel() == 0 or tau > 1.0:
         return None, None
     BR, TC = DENSE3_BR, CORE_TC
     r64, c64 = r.to(torch.int64), c.to(torch.int64)
-    ncp = (ncols + TC - 1) // TC
-    bkey = (r64 // BR) * ncp + c64 // TC
+    rb, r0, rend, _ = band_grid(r64, nrows, BR, row_bands)
+    cp, c0, _, ncp = band_grid(c64, ncols, TC, col_bands)
+    bkey = rb * ncp + cp
     uniq, inv, cnt = torch.unique(bkey, return_inverse=True, return_counts=True)
     sel = cnt >= max(1, int(tau * BR * TC))
     nb = int(sel.sum())
@@ -249,8 +283,13 @@ def split_dense3(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     is3 = sel[inv]
     bmap = torch.cumsum(sel.to(torch.int64), 0) - 1
     bk = uniq[sel]
-    h3 = build_dense3(r64[is3], c64[is3], v[is3], bmap[inv[is3]], nb, (bk // ncp).to(torch.int32), (bk % ncp).to(torch.int32),
-                      nrows, ncols)
+    bl = bmap[inv[is3]]
+    # origins of the selected blocks (every entry of a block carries them)
+    blk_r0 = torch.zeros(nb, dtype=torch.int64, device=r64.device).index_copy_(0, bl, r0[is3])
+    blk_c0 = torch.zeros(nb, dtype=torch.int64, device=r64.device).index_copy_(0, bl, c0[is3])
+    blk_rows = torch.clamp(torch.zeros(nb, dtype=torch.int64, device=r64.device).index_copy_(0, bl, rend[is3]) - blk_r0, max=BR)
+    h3 = build_dense3(r64[is3], c64[is3], v[is3], bl, nb, (bk // ncp).to(torch.int32), (bk % ncp).to(torch.int32),
+                      nrows, ncols, None, blk_r0, blk_c0, blk_rows)
     return ~is3, h3
 
 
@@ -509,7 +548,8 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
                  compact_rows: bool = False, nslices: Optional[int] = None, core: bool = False,
                  tau: float = None, emax: int = None, ngroups: Optional[int] = None,
                  slice_bounds: Optional[torch.Tensor] = None,
-                 strip: Optional[bool] = None, strip_min: Optional[int] = None, dense3_tau: Optional[float] = None) -> HostCSR:
+                 strip: Optional[bool] = None, strip_min: Optional[int] = None, dense3_tau: Optional[float] = None,
+                 row_bands: Optional[torch.Tensor] = None, col_bands: Optional[torch.Tensor] = None) -> HostCSR:
     """Sort by (row, slice, col) and build CSR.  Duplicate entries are kept as
     separate stored entries (an uncoalesced COO sums them, PGCN.py:63).  With ``core``
     the entries of dense 128 x 128 tiles are split off into a HostCore (LDS-tiled kernel).
@@ -537,7 +577,7 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
         # the bf16 three-plane blocks (512 x 128); dense3_tau > 1 switches them off
         use3 = DENSE3_ON if dense3_tau is None else dense3_tau <= 1.0
         if use3 and ncols >= CORE_TC:
-            keep3, hdense3 = split_dense3(r, c, v, nrows, ncols, dense3_tau)
+            keep3, hdense3 = split_dense3(r, c, v, nrows, ncols, dense3_tau, row_bands, col_bands)
             if keep3 is not None:
                 r, c, v = r[keep3], c[keep3], v[keep3]
         keep, hcore = split_core(r, c, v, nrows, ncols, 2.0 if use_strip else tau, emax)
@@ -565,8 +605,13 @@ def csr_from_coo(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
             for h, tr in ((hcore, CORE_TR), (hstrip, STRIP_TR), (hdense3, DENSE3_BR)):
                 if h is None:
                     continue
-                trs = torch.unique((h.work[:, 0] if (h is hstrip or h is hdense3) else h.tile_row).to(torch.int64))
-                rows = (trs[:, None] * tr + torch.arange(tr, device=dev)[None, :]).reshape(-1)
+                if h is hdense3:                       # (blocks of any origin: the rows of every piece that lie inside its band)
+                    p0, pr = h.piece_row0.to(torch.int64), h.piece_rows.to(torch.int64)
+                    off = torch.arange(tr, device=dev)[None, :]
+                    rows = (p0[:, None] + off)[off < pr[:, None]]
+                else:
+                    trs = torch.unique((h.work[:, 0] if h is hstrip else h.tile_row).to(torch.int64))
+                    rows = (trs[:, None] * tr + torch.arange(tr, device=dev)[None, :]).reshape(-1)
                 row_flags[rows[rows < nrows]] = 1
     if r.numel():
         r64, c64 = r.to(torch.int64), c.to(torch.int64)
@@ -752,7 +797,7 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     theirs = (pcol == rank) & (prow != rank)
     suniq = torch.unique(prow[theirs] * n + grank[col[theirs]])
     p = _finish_partition(row[mine], col[mine], val[mine], n, part, rank, size, gorder, grank, suniq,
-                          int(row.numel()), with_transpose, rounds)
+                          int(row.numel()), with_transpose, rounds, order_info.get("bands"))
     p.order_info = order_info
     return p
 
@@ -859,6 +904,8 @@ ORDER_LPA_ITERS = _T.order_iters
 ORDER_MIN_INSIDE = _T.order_min_inside     # share of entries inside communities
 ORDER_MAX_SHARE = _T.order_max_share       # largest community / n
 ORDER_MIN_N = _T.order_min_n
+ORDER_BAND_MIN = _T.order_band_min        # vertices a band of the block grid holds at least (0: one global grid)
+DENSE3_TAU_BANDED = _T.dense3_tau_banded
 # (numbering the top-degree vertices of ALL communities first as "hubs" was measured on the SBM stand-in in r02:
 #  worse at every share -- pulling hubs out of their communities costs more intra-community density than it buys)
 
@@ -914,6 +961,16 @@ def vertex_order(row: torch.Tensor, col: torch.Tensor, n: int, gdeg: Optional[to
     grank = torch.empty(n, dtype=torch.int64, device=dev)
     grank[gorder] = torch.arange(n, dtype=torch.int64, device=dev)
     info["order"] = "community"
+    # the bands of the order: global positions where a community starts, small communities merged into bands of at least
+    # ORDER_BAND_MIN vertices (the bf16 blocks restart their 512 x 128 grid at every band start: partition.split_dense3)
+    csize = torch.zeros(ul.numel(), dtype=torch.int64, device=dev).index_add_(0, crank[linv], torch.ones_like(linv))
+    cstart = (torch.cumsum(csize, 0) - csize).cpu().tolist()
+    bands, last = [0], 0
+    for s_ in cstart[1:]:
+        if s_ - last >= ORDER_BAND_MIN and n - s_ >= ORDER_BAND_MIN:
+            bands.append(s_)
+            last = s_
+    info["bands"] = bands
     return gorder, grank, info
 
 
@@ -943,7 +1000,7 @@ def _coo_is_symmetric(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, n: int)
 
 def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Tensor, n: int, part: torch.Tensor,
                       rank: int, size: int, gorder: torch.Tensor, grank: torch.Tensor, suniq: torch.Tensor,
-                      nnz_global: int, with_transpose: bool, rounds: Optional[int]) -> Partition:
+                      nnz_global: int, with_transpose: bool, rounds: Optional[int], bands_global=None) -> Partition:
     """Everything after the two global facts (degree ranking, who needs which of my rows):
     ``row_m/col_m/val_m`` are this rank's entries in GLOBAL coordinates."""
     dev = row_m.device
@@ -959,7 +1016,17 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
     cp = part[col_m]
     loc = cp == rank
 
-    A_loc = csr_from_coo(r[loc], g2l[c[loc]], v[loc], n_p, n_p, core=CORE_ON)
+    # bands of the vertex order (community starts, global positions) in LOCAL numbering: the owned vertices are numbered in the
+    # global order, so a band starts at the number of owned vertices that come before its global start
+    lbands = None
+    if bands_global is not None and len(bands_global) > 1 and ORDER_BAND_MIN > 0:
+        pos = torch.searchsorted(grank[owned].contiguous(), torch.as_tensor(bands_global, dtype=torch.int64, device=dev))
+        lbands = torch.unique(pos)                       # (ascending; a band without owned vertices disappears)
+        if lbands.numel() == 0 or int(lbands[0]) != 0:
+            lbands = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), lbands])
+        if lbands.numel() <= 1:
+            lbands = None
+    A_loc = csr_from_coo(r[loc], g2l[c[loc]], v[loc], n_p, n_p, core=CORE_ON, row_bands=lbands, col_bands=lbands)
     R = max(1, (EXCHANGE_ROUNDS if rounds is None else rounds)) if size > 1 else 1
     # halo columns: per owner the reference's recv_map[q] as a SET (PGCN.py:44-48), ordered
     # (round, owner, degree rank)
@@ -976,6 +1043,8 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
     ecol_round = h_round[hcol] if n_halo else hcol
     rr, vv = r[~loc], v[~loc]
     A_halo, A_halo_T = [], []
+    # (r06, VERDICT r05 item 5: restarting the block grid of a halo block at every peer segment of the slab and allowing bf16 blocks on a
+    #  shard was measured on rank 0 of 8 -- halo group 0.261 -> 0.280 ms, epoch 2.66 -> 2.74 ms replayed -- and removed: HISTORY.md section 11)
     for k in range(R if size > 1 else 0):
         sel = ecol_round == k
         A_halo.append(csr_from_coo(rr[sel], hcol[sel], vv[sel], n_p, n_halo, compact_rows=not halo_core,
@@ -992,7 +1061,7 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
             # the block -- half the structure memory and half of the "partition built" stage (r06)
             A_loc_T = A_loc
         else:
-            A_loc_T = csr_from_coo(cl, rl, vl, n_p, n_p, core=CORE_ON)
+            A_loc_T = csr_from_coo(cl, rl, vl, n_p, n_p, core=CORE_ON, row_bands=lbands, col_bands=lbands)
 
     # rows of mine that other ranks need, in the peers' slab order (round, target rank, degree rank)
     s_order, _, round_send_off = _round_major(suniq // n, size, R)

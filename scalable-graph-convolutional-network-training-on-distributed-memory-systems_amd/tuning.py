@@ -43,6 +43,9 @@ class Tuning:
                                      # products) instead of the fp32-MFMA tiles
     dense3_tau: float = 0.20         # blocks at least this full (of 65 536) take that path (r04 sweep on the benchmark graph,
                                      # SpMM launch group: off 1.742 ms, 0.12 1.724, 0.16 1.728, 0.20 1.685, 0.26 1.796)
+    dense3_tau_banded: float = 0.12  # ... under a grid aligned to the communities of the vertex order (tuning.order_band_min): the blocks of a community
+                                     # are evenly ~23 % full on the planted-partition stand-in and the next cluster sits at ~13 % (r06, SBM line: global
+                                     # grid 18.0-18.2 ms / epoch, bands at 0.20 17.5-17.6, bands at 0.12 16.9-17.0: profiles/r06_bands_sbm.txt)
     dense3_piece: int = 0            # blocks per piece (0 = adaptive: one round of 256 pieces, between 1 and 8 blocks)
     dense3_min_blocks: int = 400     # matrices with fewer such blocks leave their entries to the strips / the LDS core (a shard of an
                                      # 8-way run: two more launches and 512-row partial blocks for a few dozen blocks: rank 0 of 8,
@@ -70,6 +73,8 @@ class Tuning:
     order_min_inside: float = 0.25
     order_max_share: float = 0.125
     order_min_n: int = 4096
+    order_band_min: int = 1024       # r06: the 512 x 128 grid of the bf16 blocks restarts at every community start of a community order (bands
+                                     # of at least this many vertices; 0 = one global grid)
     # ---- exchange -------------------------------------------------------------------------------------------
     exchange_rounds: int = 2         # boundary lists are cut into this many all-to-all-v rounds
     # ---- dense H.W (stock library GEMMs) ----------------------------------------------------------------------
@@ -89,6 +94,8 @@ class Tuning:
                                      # and long rows cut into pieces of 8 192 (GCN: 1 024).  Reddit shape, 4 heads x 64, ms per epoch: 96 / 1 024
                                      # 58.7; 192 / 1 024 55.5; 384 / 1 024 56.4; 192 / 2 048 54.2; 192 / 4 096 53.2; 192 / 8 192 52.8;
                                      # 192 / 16 384 52.8; 320 / 8 192 52.9 (tools/probes_r05/p20_gat_plan.sh)
+    gat_stat_chunk: int = 4096       # r06: the row statistics of rows above gat_long_row run as one workgroup per chunk of this many entries + a
+                                     # merge of the (maximum, sum) pairs, when the longest row has more than two chunks (0: one workgroup per row)
     gat_sliced: bool = True          # XCD-sliced edge gradient
     gat_task_grad: bool = True       # edge gradient over the SpMM plan's balanced tasks
     gat_multihead: bool = True       # all heads of attention @ Z in one launch

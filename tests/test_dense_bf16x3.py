@@ -2,7 +2,7 @@
 three-way split the kernels apply to both operands (partition.bf16_split3 restates split_pair), the A-operand block
 layout (partition.dense3_index / HostDense3.vals3) and the arithmetic of the six-product scheme emulated in numpy
 (every partial product exact in fp32, fp32 accumulation) against float64.  The kernel itself is held to the oracle by
-tests/test_hip_gpu.py::test_spmm_bf16x3_blocks and measured by tools/micro/dense3_bench.cpp."""
+tests/test_hip_gpu.py::test_spmm_bf16x3_blocks (its r04 micro-benchmark, tools/micro/dense3_bench.cpp, is in the git history)."""
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -74,8 +74,8 @@ def test_blocks_are_stored_in_the_a_operand_order_of_the_bf16_mfma():
         np.testing.assert_array_equal(hd.vals3[b].numpy()[idx], blk)
         assert (blk != 0).sum() >= 0.2 * 512 * 128
         held[br * 512:(br + 1) * 512, bp * 128:(bp + 1) * 128] = True
-        assert int(hd.panel_list[hd.blk_img[b]]) == bp
-    assert torch.equal(hd.panel_list, torch.unique(hd.blk_panel)) and nb >= 5
+        assert int(hd.panel_list[hd.blk_img[b]]) == 128 * bp and int(hd.blk_row0[b]) == 512 * br and int(hd.blk_col0[b]) == 128 * bp
+    assert torch.equal(hd.panel_list, 128 * torch.unique(hd.blk_panel)) and nb >= 5
     r, c, v = hd.coo
     assert held[r.numpy(), c.numpy()].all() and r.numel() == int(((Dp != 0) & held).sum())
     # pieces: runs of blocks of ONE block row, every block in exactly one piece, 512 slot rows per piece

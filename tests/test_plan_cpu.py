@@ -43,6 +43,9 @@ VARIANTS = {
     "gather_column_groups": (dict(nslices=8, core=False, ngroups=4), {}, ()),
     "strips+bf16x3+short_rows": (dict(nslices=8, core=True, strip=True, strip_min=64, dense3_tau=0.12), dict(small_row=8, adaptive_chunk=False),
                                  ("strip", "dense3")),
+    # r06: the 512 x 128 grid of the bf16 blocks restarts at every band start (communities of the vertex order): blocks at odd origins
+    "strips+bf16x3+bands": (dict(nslices=8, core=True, strip=True, strip_min=64, dense3_tau=0.12, row_bands=[0, 300, 1250, 2100],
+                                 col_bands=[0, 300, 1250, 2100]), {}, ("strip", "dense3")),
     "range_slices": (dict(core=True, strip=True, strip_min=64, dense3_tau=0.15, slice_bounds=[0, 40, 100, 250, 600, 1100, 1700, 2400, 3000]), {},
                      ("strip", "dense3")),
 }
@@ -53,7 +56,19 @@ def test_launch_group_plan_reproduces_the_product(name):
     partition = pkg("partition")
     kw, pk, parts = VARIANTS[name]
     n, r, c, val, A = _power_law_block()
+    kw = {k: (torch.tensor(x) if k.endswith("_bands") else x) for k, x in kw.items()}
     h = partition.csr_from_coo(r, c, val, n, n, **kw)
+    if "row_bands" in kw:            # every block starts at a band start + a multiple of the block size, and none crosses a band
+        d3, bands = h.dense3, kw["row_bands"].tolist() + [n]
+        for r0, c0 in zip(d3.blk_row0.tolist(), d3.blk_col0.tolist()):
+            br = max(b for b in bands[:-1] if b <= r0)
+            bc = max(b for b in bands[:-1] if b <= c0)
+            assert (r0 - br) % 512 == 0 and (c0 - bc) % 128 == 0
+        rr, cc, _ = d3.coo
+        for b in range(d3.blk_row.numel()):
+            pass
+        assert any(x % 512 for x in d3.blk_row0.tolist()) and any(x % 128 for x in d3.blk_col0.tolist())
+        assert bool((d3.piece_rows <= 512).all()) and bool((d3.piece_rows > 0).all())
     for p in ("strip", "core", "dense3"):
         assert (getattr(h, p) is not None) == (p in parts), "variant %s: part %s" % (name, p)
     assert h.nnz == A.nnz

@@ -53,7 +53,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_gat -o gat -- 
 rm -f $out/prof_gat/*kernel_trace.csv $out/prof_gat/*/*kernel_trace.csv
 python bench.py --workload papers --emulate-rank 0/8 --shards /tmp/papers --partvec block --features 64 --layers 2 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_papers_full_rank_0_8.json 2>/dev/null
 python tools/shard_rank_check.py --shards /tmp/papers --rank 0 --ranks 8 --features 64 > $out/papers_full_rank_0_8_check.json 2>/dev/null
-timeout 120 tools/micro/dense3_bench.bin 1982 0.39 490 > $out/dense3_bench.txt 2>&1
 for rp in 0/8 3/8 7/8 0/4 0/2; do t=$(echo $rp | tr '/' '_')
   python bench.py --emulate-rank $rp --graph --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rank_$t.json 2>/dev/null
 done
