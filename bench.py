@@ -689,7 +689,8 @@ def bench_gat(args, rank, world, dev, backend, stage):
     torch.cuda.synchronize()
     timer.on = not args.no_kernel_timing
     xprobe = None
-    if world > 1 and not args.no_kernel_timing and not emul:      # what the exchange costs and what of it the compute stream sees (r06)
+    paced = bool(emul and args.pace_exchange > 0)
+    if (world > 1 or paced) and not args.no_kernel_timing and (paced or not emul):      # what the exchange costs, what of it is exposed (r06)
         xprobe = eng.probe = pkg("engine").ExchangeProbe(dev)
         xprobe.on = True
     t0 = time.perf_counter()
@@ -747,15 +748,15 @@ def bench_gat(args, rank, world, dev, backend, stage):
                       "exchange": exch.name if exch else "none",
                       "rank_shape": {"n_local": part.n_local, "n_halo": part.n_halo, "n_send": part.n_send, "nnz_rank": eng.nnz},
                       "multi_head_spmm": bool(eng.multi_head), "fused_edge_gradient": bool(eng.fused_grad),
-                      "vertex_order": part.order_info},
+                      "vertex_order": {k: v for k, v in (part.order_info or {}).items() if not k.startswith("_")}},
            "roofline": roofline, "ms_per_epoch": ms, "ms_per_layer_fwd_bwd": ms / L, "loss": float(loss), "setup_s": setup_s,
            "cpu_baseline": None}
     if world > 1:
         vol = torch.tensor([eng.stats["send_volume"]], dtype=torch.float64, device=dev)
         pkg("PGCN")._all_reduce(vol)
         out["exchange_rows_total"] = float(vol)
-        if exchange_report is not None:
-            out["exchange"] = exchange_report
+    if exchange_report is not None:
+        out["exchange"] = exchange_report
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -1039,7 +1040,7 @@ def main():
                    "xcd_slices": eng.A_loc.nslices, "chunk": K.chunk,
                    "core_tile_fill_min": partition.CORE_TAU,
                    "bf16x3_block_fill_min": partition.DENSE3_TAU if partition.DENSE3_ON else None,
-                   "exchange_rounds": part.rounds, "vertex_order": part.order_info,
+                   "exchange_rounds": part.rounds, "vertex_order": {k: v for k, v in (getattr(part, "order_info", None) or {}).items() if not k.startswith("_")},
                    "dense_gemm": ("x.W^T and g.W: the package's own matrix-core kernels (see dense_fused); dW = Gm^T.AH: PyTorch's batched "
                                   "product over 64 row slabs + their sum" if int(partition._T.dense_fused) >= 2 and f <= 128 and f % 4 == 0 else
                                   ("stock rocBLAS GEMMs launched by the solution index recorded in tunableop/gfx950.csv (x.W^T, g.W); "

@@ -326,14 +326,7 @@ int pgcn_gat_edge_softmax_f32(const int64_t *rowptr, const int32_t *col, int64_t
                               int64_t nrows_block, const float *s1, int64_t lds1, const float *s2,
                               int64_t lds2, int32_t heads, float slope, int32_t mode, int64_t n_global,
                               float *alpha, float *beta, float *rowstat, pgcn_stream_t stream);
-/* The statistics-only form (alpha = NULL) for the rows listed in `rows` -- the LONG rows of a structure -- by chunks of `chunk`
- * entries (>= 512): one workgroup per (row, chunk), then a merge of a row's (maximum, sum) pairs in chunk order; the same maximum
- * as the one-pass kernel, the sum to fp32 rounding, deterministic.  ws: nrows_list * ceil(max_row_len / chunk) * heads * 2 floats,
- * 8-byte aligned.  (r06: the hub rows of the Reddit shape cost 0.77 ms per layer as one workgroup per row.) */
-int pgcn_gat_edge_stats_chunked_f32(const int64_t *rowptr, const int32_t *col, int64_t nrows, int64_t nnz, const int32_t *rows,
-                                    int64_t nrows_list, int64_t max_row_len, int32_t chunk, const float *s1, int64_t lds1,
-                                    const float *s2, int64_t lds2, int32_t heads, float slope, int32_t mode, int64_t n_global,
-                                    float *beta, float *rowstat, float *ws, int64_t ws_elems, pgcn_stream_t stream);
+
 
 int pgcn_gat_edge_weights_t_f32(const int64_t *rowptr_t, const int32_t *col_t, int64_t nrows_t,
                                 int64_t nnz, const int32_t *rows_wave, int64_t nrows_wave,

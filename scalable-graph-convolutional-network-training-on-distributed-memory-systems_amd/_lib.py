@@ -70,8 +70,6 @@ SIGNATURES = {
     "pgcn_spmm_plan_host_ex": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp,
                                               ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                               ctypes.POINTER(_i64)]),
-    "pgcn_gat_edge_stats_chunked_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _i32, ctypes.c_float,
-                                                       _i32, _i64, _vp, _vp, _vp, _i64, _vp]),
     "pgcn_gat_edge_softmax_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32,
                                                  ctypes.c_float, _i32, _i64, _vp, _vp, _vp, _vp]),
     "pgcn_gat_edge_weights_t_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32,

@@ -234,102 +234,9 @@ __global__ __launch_bounds__(kThreads) void gat_softmax_heads_kernel(
     }
 }
 
-// ---- statistics of the LONG rows by chunks (r06) --------------------------------------------------------------------------------------
-// The one-workgroup-per-row form above walks a hub row of 50 k entries as ~100 dependent gather rounds of 512 entries: 0.77 ms per
-// layer for the 6.7 k rows above 1 024 entries of the Reddit shape (profiles/r05_gat_ladder.txt), almost all of it the tail of the few
-// longest rows.  Here a long row is cut into chunks of `chunk` entries, one workgroup per (row, chunk) computes the chunk's running
-// (maximum, sum of exponentials relative to it) exactly as the one-pass kernel does, and gat_stats_merge_kernel folds a row's pairs in
-// chunk order: the same maximum, the sum to fp32 rounding, fixed order (deterministic).  ws: [row in list][chunk][head] x {m, sum}.
-template <int MODE, int KH>
-__global__ __launch_bounds__(kThreads) void gat_stats_chunk_kernel(
-    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ rows, int64_t nlist,
-    int32_t chunk, int32_t maxc, const float *__restrict__ s1, int64_t lds1, const float *__restrict__ s2, int64_t lds2, int32_t heads,
-    float slope, float2 *__restrict__ ws) {
-    using HV = typename HeadVec<KH>::T;
-    __shared__ float red[4];
-    const int64_t li = blockIdx.x / maxc;
-    const int cidx = (int)(blockIdx.x % maxc);
-    if (li >= nlist) return;
-    const int64_t i = rows[li];
-    const int64_t b = rowptr[i] + (int64_t)cidx * chunk, e0 = rowptr[i + 1];
-    if (b >= e0) return;                                   // (uniform per workgroup)
-    const int64_t e = b + chunk < e0 ? b + chunk : e0;
-    const int kb = blockIdx.y * KH, lane = threadIdx.x;
-    float a[KH], m[KH], sum[KH];
-#pragma unroll
-    for (int k = 0; k < KH; ++k) {
-        a[k] = s1[i * lds1 + kb + k];
-        m[k] = MODE == 1 ? 0.f : -INFINITY;
-        sum[k] = 0.f;
-    }
-    auto scores = [&](int64_t p, float *r) {
-        const HV v = *reinterpret_cast<const HV *>(s2 + (int64_t)col[p] * lds2 + kb);
-        const float *vf = reinterpret_cast<const float *>(&v);
-#pragma unroll
-        for (int k = 0; k < KH; ++k) {
-            const float x = a[k] + vf[k];
-            r[k] = MODE == 0 ? (x > 0.f ? x : x * slope) : x;
-        }
-    };
-    auto push = [&](float &mk, float &sk, float r) {
-        const float hi = fmaxf(mk, r), e1 = expf(fminf(mk, r) - hi);
-        sk = r > mk ? sk * e1 + 1.f : sk + e1;
-        mk = hi;
-    };
-    for (int64_t p = b + lane; p < e; p += 2 * kThreads) {
-        float r0[KH], r1[KH];
-        const bool two = p + kThreads < e;
-        scores(p, r0);
-        scores(two ? p + kThreads : p, r1);
-#pragma unroll
-        for (int k = 0; k < KH; ++k) {
-            push(m[k], sum[k], r0[k]);
-            if (two) push(m[k], sum[k], r1[k]);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < KH; ++k) {
-        const float ml = m[k];
-        m[k] = group_reduce<256, true>(ml, red);
-        // MODE 1 starts every lane's maximum at 0 with an empty sum: a lane without entries adds nothing either way
-        sum[k] = (ml == -INFINITY || sum[k] == 0.f) ? 0.f : sum[k] * expf(ml - m[k]);
-        sum[k] = group_reduce<256, false>(sum[k], red);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < KH; ++k) ws[((int64_t)li * maxc + cidx) * heads + kb + k] = make_float2(m[k], sum[k]);
-    }
-}
-
-// one thread per (long row, head): the row's chunk pairs in order, then the row statistics exactly as gat_softmax_heads_kernel ends
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void gat_stats_merge_kernel(
-    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ rows, int64_t nlist, int32_t chunk, int32_t maxc,
-    const float *__restrict__ s1, int64_t lds1, int32_t heads, float nglobal, const float2 *__restrict__ ws, float *__restrict__ beta,
-    float4 *__restrict__ rowstat) {
-    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (t >= nlist * heads) return;
-    const int64_t li = t / heads;
-    const int k = (int)(t % heads);
-    const int64_t i = rows[li];
-    const int64_t len = rowptr[i + 1] - rowptr[i];
-    const int nc = (int)((len + chunk - 1) / chunk);
-    float m = MODE == 1 ? 0.f : -INFINITY, sum = 0.f;
-    for (int c = 0; c < nc; ++c) {
-        const float2 q = ws[((int64_t)li * maxc + c) * heads + k];
-        const float hi = fmaxf(m, q.x);
-        sum = (m == -INFINITY || sum == 0.f ? 0.f : sum * expf(m - hi)) + (q.y == 0.f ? 0.f : q.y * expf(q.x - hi));
-        m = hi;
-    }
-    float em = 0.f, D = sum;
-    if (MODE == 1) {
-        em = expf(-m);
-        D = (nglobal - (float)len) * em + sum;
-    }
-    const float inv = D > 0.f ? 1.f / D : 0.f;
-    if (MODE == 1) beta[i * heads + k] = em * inv;
-    rowstat[i * heads + k] = make_float4(s1[i * lds1 + k], m, inv, em);
-}
+// (r06: the statistics of the rows above the long-row threshold were also built as one workgroup per CHUNK of a row + a merge of the
+//  (maximum, sum) pairs -- pgcn_gat_edge_stats_chunked_f32, commit 19d1915 -- and measured on the Reddit shape: 52.90 / 53.07 ms per epoch
+//  at chunks of 4 096 against 52.93 / 52.96 with one workgroup per row, 53.6 at 2 048, 54.9 at 8 192: removed.  profiles/r06_gat_stats.txt)
 
 template <int VEC> struct Vec;
 template <> struct Vec<1> {
@@ -757,50 +664,6 @@ extern "C" int pgcn_gat_edge_softmax_f32(const int64_t *rowptr, const int32_t *c
     }
 #undef PGCN_SOFTMAX_K
 #undef PGCN_SOFTMAX
-    PGCN_HIP_CHECK(hipGetLastError());
-    return PGCN_OK;
-}
-
-// Row statistics (alpha = NULL form of pgcn_gat_edge_softmax_f32) of the rows listed in `rows` -- the LONG rows of a structure -- by
-// chunks of `chunk` entries: ws must hold nrows_list * ceil(max_row_len / chunk) * heads float2.  Two launches.
-extern "C" int pgcn_gat_edge_stats_chunked_f32(const int64_t *rowptr, const int32_t *col, int64_t nrows, int64_t nnz, const int32_t *rows,
-                                               int64_t nrows_list, int64_t max_row_len, int32_t chunk, const float *s1, int64_t lds1,
-                                               const float *s2, int64_t lds2, int32_t heads, float slope, int32_t mode,
-                                               int64_t n_global, float *beta, float *rowstat, float *ws, int64_t ws_elems,
-                                               pgcn_stream_t stream) {
-    const char *who = "pgcn_gat_edge_stats_chunked_f32";
-    if (nrows < 0 || nnz < 0 || nrows_list < 0 || heads < 1 || heads > 65535 || lds1 < heads || lds2 < heads || chunk < 512 ||
-        max_row_len < 0 || (mode != 0 && mode != 1))
-        return pgcn_set_error2(PGCN_EINVAL, who, "bad sizes");
-    if (nrows_list == 0) return PGCN_OK;
-    if (!rowptr || !rows || !s1 || !rowstat || !ws || (nnz && (!col || !s2)) || (mode == 1 && !beta))
-        return pgcn_set_error2(PGCN_EINVAL, who, "null pointer");
-    if ((uintptr_t)rowstat % 16 || (uintptr_t)ws % 8) return pgcn_set_error2(PGCN_EINVAL, who, "rowstat / ws alignment");
-    const int64_t maxc = max_row_len > 0 ? (max_row_len + chunk - 1) / chunk : 1;
-    if (ws_elems < nrows_list * maxc * heads * 2) return pgcn_set_error2(PGCN_ENOMEM, who, "work-space too small");
-    if (nrows_list * maxc > 0x7fffffffLL) return pgcn_set_error2(PGCN_EINVAL, who, "too many chunks");
-    hipStream_t s = (hipStream_t)stream;
-    const float ng = (float)n_global;
-    int kh = 1;
-    if (heads % 4 == 0 && lds2 % 4 == 0 && (uintptr_t)s2 % 16 == 0) kh = 4;
-    else if (heads % 2 == 0 && lds2 % 2 == 0 && (uintptr_t)s2 % 8 == 0) kh = 2;
-    float2 *w2 = reinterpret_cast<float2 *>(ws);
-    const dim3 grid((unsigned)(nrows_list * maxc), (unsigned)(heads / kh));
-#define PGCN_CHUNK(MODE, KH)                                                                                                   \
-    hipLaunchKernelGGL((gat_stats_chunk_kernel<MODE, KH>), grid, dim3(kThreads), 0, s, rowptr, col, rows, nrows_list, chunk, (int32_t)maxc, \
-                       s1, lds1, s2, lds2, heads, slope, w2)
-    if (mode == 0) { if (kh == 4) PGCN_CHUNK(0, 4); else if (kh == 2) PGCN_CHUNK(0, 2); else PGCN_CHUNK(0, 1); }
-    else { if (kh == 4) PGCN_CHUNK(1, 4); else if (kh == 2) PGCN_CHUNK(1, 2); else PGCN_CHUNK(1, 1); }
-#undef PGCN_CHUNK
-    PGCN_HIP_CHECK(hipGetLastError());
-    const dim3 mgrid((unsigned)((nrows_list * heads + kThreads - 1) / kThreads));
-    float4 *rs = reinterpret_cast<float4 *>(rowstat);
-    if (mode == 0)
-        hipLaunchKernelGGL((gat_stats_merge_kernel<0>), mgrid, dim3(kThreads), 0, s, rowptr, rows, nrows_list, chunk, (int32_t)maxc, s1, lds1,
-                           heads, ng, w2, beta, rs);
-    else
-        hipLaunchKernelGGL((gat_stats_merge_kernel<1>), mgrid, dim3(kThreads), 0, s, rowptr, rows, nrows_list, chunk, (int32_t)maxc, s1, lds1,
-                           heads, ng, w2, beta, rs);
     PGCN_HIP_CHECK(hipGetLastError());
     return PGCN_OK;
 }

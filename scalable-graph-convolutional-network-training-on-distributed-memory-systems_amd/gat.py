@@ -60,6 +60,12 @@ class GatGraph:
     bwd_local: Optional[HostCSR] = None      # n_local x n_local
     bwd_halo_lists: Optional[tuple] = None   # (wave rows, block rows) of each
     bwd_local_lists: Optional[tuple] = None
+    # ... and the forward structure as its local columns and its halo columns: the row statistics need s2 only (a 16-byte-per-row
+    # exchange), so the product over the local columns runs while the 1 KB rows of the halo are still on the wire
+    fwd_local: Optional[HostCSR] = None      # n_local x n_local
+    fwd_halo: Optional[HostCSR] = None       # n_local x n_halo
+    fwd_local_lists: Optional[tuple] = None
+    fwd_halo_lists: Optional[tuple] = None
 
     @property
     def nnz(self) -> int:
@@ -115,6 +121,11 @@ def build_gat_graph(part: Partition, positive_only: bool = False, long_row: Opti
         g.bwd_local = csr_from_coo(cb[~hal], rb[~hal], ones[:int((~hal).sum())], n_p, n_p, nslices=St, core=False)
         g.bwd_halo_lists = _row_lists(g.bwd_halo.rowptr, lr)
         g.bwd_local_lists = _row_lists(g.bwd_local.rowptr, lr)
+        hal = c >= n_p
+        g.fwd_local = csr_from_coo(r[~hal], c[~hal], ones[:int((~hal).sum())], n_p, n_p, nslices=pick_nslices(n_p), core=False)
+        g.fwd_halo = csr_from_coo(r[hal], c[hal] - n_p, ones[:int(hal.sum())], n_p, n_h, nslices=pick_nslices(n_h), core=False)
+        g.fwd_local_lists = _row_lists(g.fwd_local.rowptr, lr)
+        g.fwd_halo_lists = _row_lists(g.fwd_halo.rowptr, lr)
     return g
 
 
@@ -163,6 +174,10 @@ class GatEngine(BoundaryExchange):
         if g.bwd_halo is not None:
             self.bwd_halo = kernels.prepare_gat(g.bwd_halo, *g.bwd_halo_lists, chunk=chunk, small_row=small)
             self.bwd_local = kernels.prepare_gat(g.bwd_local, *g.bwd_local_lists, chunk=chunk, small_row=small)
+        self.fwd_local = self.fwd_halo = None
+        if g.fwd_halo is not None:
+            self.fwd_local = kernels.prepare_gat(g.fwd_local, *g.fwd_local_lists, chunk=chunk, small_row=small)
+            self.fwd_halo = kernels.prepare_gat(g.fwd_halo, *g.fwd_halo_lists, chunk=chunk, small_row=small)
         self.perm = g.perm.to(self.device)
         self._inv_perm = None              # forward entry -> its position in the transposed structure (built on demand)
         self._scratch = {}
@@ -242,17 +257,48 @@ class GatEngine(BoundaryExchange):
             Zc = st.Zc
             Zc[:n_p, :F].copy_(Z)
             Zc[:n_p, F:F + K].copy_(s2)
+        st.s1 = s1.contiguous()
+        if st.s2c is None or st.s2c.shape != (n_p + n_h, K):
+            # (zeros: under an emulated exchange -- bench.py --emulate-rank -- the halo rows are never written)
+            st.s2c = torch.zeros((n_p + n_h, K), dtype=torch.float32, device=self.device)
+        out = torch.empty((n_p, F), dtype=torch.float32, device=self.device)
+        st.fused = False
+        split = (self.size > 1 and self.overlap and n_h > 0 and self.fwd_halo is not None and self.fused_fwd and self.covers(K, d)
+                 and self.mode_id == 0)
+        if split:
+            # N > 1 (r06): the statistics of the edge softmax need s2 only -- its halo rows (16 bytes each) are exchanged FIRST, the 1 KB
+            # rows of [Z | s2] follow on the comm stream under the statistics pass and the product over the LOCAL columns; the product
+            # over the halo columns (accumulated) waits for them.  PGAT.py:138-151; the overlap structure of Parallel-GCN/main.c:238-299
+            st.s2c[:n_p].copy_(s2)
+            send2 = self._slab("gat_send_s2", self.n_send, K)
+            self.k.gather_rows(st.s2c[:n_p], self.send_idx, send2)
+            w2 = self._exchange_all(send2, self.round_send_off, st.s2c[n_p:], self.round_recv_off, K, tag="forward_s2")
+            send = self._slab("gat_send", self.n_send, Fp)
+            self.k.gather_rows(Zc[:n_p], self.send_idx, send)
+            wz = self._exchange_all(send, self.round_send_off, Zc[n_p:], self.round_recv_off, Fp, tag="forward")
+            for w in w2:
+                w()
+            self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global, None, st.beta, st.rowstat)
+            pw2 = F + (K + 3) // 4 * 4
+            if st.V is None or st.V.shape != (n_p, pw2):
+                st.V = torch.empty((n_p, pw2), dtype=torch.float32, device=self.device)
+            ok = self.k.spmm_heads_forward2(self.fwd_local, st.rowstat, st.s2c[:n_p], self.slope, self.mode_id, Zc[:n_p], out, st.V, K, d)
+            for w in wz:
+                w()
+            if ok:
+                ok = self.k.spmm_heads_forward2(self.fwd_halo, st.rowstat, st.s2c[n_p:], self.slope, self.mode_id, Zc[n_p:], out, st.V,
+                                                K, d, accumulate=True)
+            if not ok:
+                raise RuntimeError("the split GAT forward was refused by a kernel whose shape `covers` accepted")
+            st.fused = True
+            st.out = out
+            return out
         if self.size > 1:                                   # PGAT.py:139 `Comm.apply(H)`: here the rows of [Z | s2]
             send = self._slab("gat_send", self.n_send, Fp)
             self.k.gather_rows(Zc[:n_p], self.send_idx, send)
             for w in self._exchange_all(send, self.round_send_off, Zc[n_p:], self.round_recv_off, Fp):
                 w()
-        st.s1 = s1.contiguous()
-        if st.s2c is None or st.s2c.shape != (n_p + n_h, K):
-            st.s2c = torch.empty((n_p + n_h, K), dtype=torch.float32, device=self.device)
         st.s2c.copy_(Zc[:, F:F + K])        # compact: the per-entry s2 gathers stay in L2 instead of striding the panel
-        out = torch.empty((n_p, F), dtype=torch.float32, device=self.device)
-        st.fused = False
         if self.fused_fwd and self.covers(K, d):
             # statistics only, then ONE gather pass: out, and V | C for the backward's ds1 (no alpha planes, no de)
             self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,

@@ -59,8 +59,6 @@ class DeviceCSR:
     rows_block: Optional[torch.Tensor] = None  # ... and by one 256-thread workgroup each (hub rows)
     slice_off: Optional[torch.Tensor] = None   # int32 [nrows, 9] offsets of a row's 8 col % 8 slices (XCD-sliced storage)
     rows_all: Optional[torch.Tensor] = None    # int32 all rows, longest first
-    max_row_len: int = 0                       # GAT structures: entries of the longest row
-    stat_ws: Optional[torch.Tensor] = None     # ... and the work-space of the chunked row statistics
     launch_cache: dict = None                 # bound C-ABI calls per (ldb, ldc, f, accumulate)
 
     def __post_init__(self):
@@ -434,7 +432,6 @@ class HipKernels:
             raise _lib.PgcnError("GAT structures are plain (sliced) CSR blocks")
         d = self.prepare(csr, pattern_only=True, chunk=chunk, small_row=small_row)        # (the attention kernels walk (row, slice) pieces)
         d.rows_wave = rows_wave.to(self.device, torch.int32).contiguous()
-        d.max_row_len = int((csr.rowptr[1:] - csr.rowptr[:-1]).max()) if csr.nrows else 0
         d.rows_block = rows_block.to(self.device, torch.int32).contiguous()
         if csr.nslices == 8 and csr.slice_cnt is not None and csr.ngroups == 1:
             off = torch.zeros((csr.nrows, 9), dtype=torch.int32, device=csr.slice_cnt.device)
@@ -618,24 +615,6 @@ class HipKernels:
                                         and rowstat.numel() == A.nrows * heads * 4):
             raise _lib.PgcnError("rowstat must be a contiguous fp32 [nrows, heads, 4] CUDA tensor")
         lists = self._lists(A)
-        chunk = int(_T.gat_stat_chunk)
-        nblock = 0 if A.rows_block is None else int(A.rows_block.numel())
-        if alpha is None and chunk > 0 and nblock and A.max_row_len > 2 * chunk:
-            # statistics only: the long rows by chunks (r06: one workgroup per hub ROW cost 0.77 ms per layer on the Reddit shape)
-            maxc = -(-A.max_row_len // chunk)
-            need = nblock * maxc * heads * 2
-            ws = A.stat_ws
-            if ws is None or ws.numel() < need:
-                ws = A.stat_ws = torch.empty(need, dtype=torch.float32, device=self.device)
-            _lib.check(self.lib.pgcn_gat_edge_softmax_f32(
-                A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, lists[0], lists[1], None, 0, s1.data_ptr(),
-                s1.stride(0), s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, None, beta.data_ptr(),
-                _ptr(rowstat), self._stream()), "pgcn_gat_edge_softmax_f32")
-            _lib.check(self.lib.pgcn_gat_edge_stats_chunked_f32(
-                A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, lists[2], lists[3], A.max_row_len, chunk, s1.data_ptr(), s1.stride(0),
-                s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, beta.data_ptr(), _ptr(rowstat), ws.data_ptr(), ws.numel(),
-                self._stream()), "pgcn_gat_edge_stats_chunked_f32")
-            return
         _lib.check(self.lib.pgcn_gat_edge_softmax_f32(
             A.rowptr.data_ptr(), A.col.data_ptr(), A.nrows, nnz, *lists, s1.data_ptr(),
             s1.stride(0), s2.data_ptr(), s2.stride(0), heads, slope, mode, n_global, _ptr(alpha), beta.data_ptr(),

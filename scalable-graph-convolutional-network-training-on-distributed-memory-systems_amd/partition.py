@@ -797,7 +797,7 @@ def build_partition(row: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: 
     theirs = (pcol == rank) & (prow != rank)
     suniq = torch.unique(prow[theirs] * n + grank[col[theirs]])
     p = _finish_partition(row[mine], col[mine], val[mine], n, part, rank, size, gorder, grank, suniq,
-                          int(row.numel()), with_transpose, rounds, order_info.get("bands"))
+                          int(row.numel()), with_transpose, rounds, order_info.get("_bands"))
     p.order_info = order_info
     return p
 
@@ -970,7 +970,8 @@ def vertex_order(row: torch.Tensor, col: torch.Tensor, n: int, gdeg: Optional[to
         if s_ - last >= ORDER_BAND_MIN and n - s_ >= ORDER_BAND_MIN:
             bands.append(s_)
             last = s_
-    info["bands"] = bands
+    info["_bands"] = bands                 # (keys with a leading underscore are not printed by bench.py)
+    info["bands"] = len(bands)
     return gorder, grank, info
 
 

@@ -94,8 +94,6 @@ class Tuning:
                                      # and long rows cut into pieces of 8 192 (GCN: 1 024).  Reddit shape, 4 heads x 64, ms per epoch: 96 / 1 024
                                      # 58.7; 192 / 1 024 55.5; 384 / 1 024 56.4; 192 / 2 048 54.2; 192 / 4 096 53.2; 192 / 8 192 52.8;
                                      # 192 / 16 384 52.8; 320 / 8 192 52.9 (tools/probes_r05/p20_gat_plan.sh)
-    gat_stat_chunk: int = 4096       # r06: the row statistics of rows above gat_long_row run as one workgroup per chunk of this many entries + a
-                                     # merge of the (maximum, sum) pairs, when the longest row has more than two chunks (0: one workgroup per row)
     gat_sliced: bool = True          # XCD-sliced edge gradient
     gat_task_grad: bool = True       # edge gradient over the SpMM plan's balanced tasks
     gat_multihead: bool = True       # all heads of attention @ Z in one launch

@@ -40,18 +40,26 @@ class _Exchanger:
     """One GPU stands in for P: the slab a rank would receive is produced from global data the test holds."""
 
     def __init__(self):
-        self.next_recv, self.sent_parts, self.cursor = None, [], 0
+        self.next_recv, self.sent_parts, self.cursor, self.narrow = None, [], 0, None
 
-    def begin(self, recv_rows):
-        self.next_recv, self.sent_parts, self.cursor = recv_rows, [], 0
+    def begin(self, recv_rows, narrow=None):
+        """``narrow`` (optional): {width: rows} for exchanges of another row width than ``recv_rows`` (the GAT forward sends the
+        s2 columns of its rows ahead of the rows themselves, r06); those do not count as the slab of the exchange under test."""
+        self.next_recv, self.sent_parts, self.cursor, self.narrow = recv_rows, [], 0, dict(narrow or {})
+        self.ncursor = {w: 0 for w in self.narrow}
 
     @property
     def sent(self):
         return torch.cat(self.sent_parts) if self.sent_parts else None
 
     def alltoallv(self, send, send_off, recv, recv_off, f):
-        self.sent_parts.append(send[:send_off[-1]].clone())
         k = recv_off[-1]
+        if self.narrow and f in self.narrow and f != self.next_recv.shape[1]:
+            c = self.ncursor[f]
+            recv[:k] = self.narrow[f][c:c + k]
+            self.ncursor[f] = c + k
+            return
+        self.sent_parts.append(send[:send_off[-1]].clone())
         recv[:k] = self.next_recv[self.cursor:self.cursor + k]
         self.cursor += k
 

@@ -668,7 +668,7 @@ def test_full_size_gat_shard_rank_of_four(K, dev):
     panel = torch.zeros(n, Fp, device=dev)
     panel[:, :F], panel[:, F:F + heads] = Zg, s2g
     st = eng.new_layer_state(heads, d)
-    ex.begin(panel[halo])
+    ex.begin(panel[halo], narrow={heads: s2g[halo]})      # (r06: the s2 columns travel first, the 1 KB rows behind them)
     out = eng.forward(st, Zg[own], s1g[own], s2g[own])
     torch.cuda.synchronize()
     assert torch.equal(ex.sent, panel[part.send_global.to(dev)])           # the packed slab: exactly the rows peers need
@@ -751,49 +751,3 @@ def test_row_dots_of_the_backward(n, K, d):
     assert none is None and torch.equal(t2, t)
     assert k.gat_row_dots(dOut[:, :F - 4], out[:, :F - 4], None, K, d - 1) is None      # a head width the kernel does not take
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["standard", "reference"])
-@pytest.mark.parametrize("heads", [4, 2, 3, 1])
-@pytest.mark.parametrize("chunk", [512, 1024])
-def test_row_statistics_of_long_rows_by_chunks(K, dev, mode, heads, chunk, monkeypatch):
-    """r06: the statistics-only pass of the rows above the long-row threshold as one workgroup per CHUNK + a merge of the (maximum,
-    sum) pairs (pgcn_gat_edge_stats_chunked_f32) against the one-workgroup-per-row form: s1, the maximum and exp(-m) exactly, the
-    normaliser to fp32 rounding; rows of several chunks, of exactly one chunk boundary, short rows untouched, both modes."""
-    tuning = pkg("tuning")
-    rng = np.random.default_rng(heads + chunk)
-    n, m = 300, 9000
-    A = sp.random(n, m, density=0.01, random_state=3, format="lil")
-    A[3, :] = 1                                     # 9 000 entries: many chunks
-    A[11, :2 * chunk] = 1                           # ends exactly on a chunk boundary
-    A[12, :2 * chunk + 1] = 1                       # ... one entry into the third chunk
-    A[20, :700] = 1                                 # a long row (above the threshold of 256) of less than one chunk
-    A[7, :] = 0
-    A = sp.csr_matrix(A)
-    A.data[:] = 1
-    A.eliminate_zeros()
-    mode_id = {"standard": 0, "reference": 1}[mode]
-    dA, _, _, _, _ = _structure(K, A, 8, 256)
-    assert dA.rows_block.numel() >= 4 and dA.max_row_len == m
-    s1 = torch.from_numpy((rng.standard_normal((n, heads)) * 1.5).astype(np.float32)).to(dev)
-    s2 = torch.from_numpy((rng.standard_normal((m, heads)) * 1.5).astype(np.float32)).to(dev)
-    out = {}
-    for c in (0, chunk):
-        monkeypatch.setattr(tuning.T, "gat_stat_chunk", c)
-        beta, rowstat = torch.zeros((n, heads), device=dev), torch.full((n, heads, 4), float("nan"), device=dev)
-        K.gat_edge_softmax(dA, s1, s2, heads, 0.2, mode_id, 20000, None, beta, rowstat)
-        torch.cuda.synchronize()
-        out[c] = (beta, rowstat)
-    (b0, r0), (b1, r1) = out[0], out[chunk]
-    assert torch.equal(r0[..., :2], r1[..., :2]) and torch.equal(r0[..., 3], r1[..., 3])
-    assert torch.allclose(r0[..., 2], r1[..., 2], rtol=3e-6, atol=0) and torch.allclose(b0, b1, rtol=3e-6, atol=0)
-    # ... and against float64
-    e = s1.double().cpu().numpy()[:, None, :] + s2.double().cpu().numpy()[None, :, :]          # [n, m, heads]
-    e = np.where(e > 0, e, 0.2 * e) if mode_id == 0 else e
-    P = A.toarray().astype(bool)
-    for i in (3, 11, 12, 20, 5):
-        sc = e[i][P[i]]
-        mx = max(sc.max(0).max(), 0.0) if False else (np.maximum(sc.max(0), 0.0) if mode_id == 1 else sc.max(0))
-        D = np.exp(sc - mx).sum(0) + ((20000 - P[i].sum()) * np.exp(-mx) if mode_id == 1 else 0.0)
-        np.testing.assert_allclose(r1[i, :, 1].cpu().numpy(), mx, rtol=1e-6)
-        np.testing.assert_allclose(r1[i, :, 2].cpu().numpy(), 1.0 / D, rtol=2e-5)
