@@ -85,11 +85,22 @@ class KernelTimer:
 def exchange_summary(probe, P, dev, world):
     """The rank-0 view of engine.ExchangeProbe.summary() plus, per (direction, round), the MAX over ranks of the transfer and of the
     exposed wait (the rank that waits longest sets the step).  Every rank calls this (collective)."""
-    rep = probe.summary()
+    try:
+        rep = probe.summary()
+    except Exception as e:           # (first contact with real xGMI: the diagnostics must never cost the line itself)
+        rep = {"error": repr(e)[:300]}
     keys = [(tag, i) for tag in ("forward", "backward") for i in range(len(rep.get(tag, [])))]
     vals = [rep[tag][i][k] for tag, i in keys for k in ("ms", "exposed_ms")]
     ar = rep.get("allreduce")
     vals += [ar["ms"], ar["exposed_ms"]] if ar else [0.0, 0.0]
+    nkeys = torch.tensor([len(vals)], dtype=torch.int64, device=dev)
+    if world > 1:                    # (every rank has the same rounds; a rank whose summary failed must not desynchronise the collective)
+        lo = nkeys.clone()
+        P._all_reduce(nkeys, dist.ReduceOp.MAX)
+        P._all_reduce(lo, dist.ReduceOp.MIN)
+        if int(nkeys) != int(lo):
+            rep["what"] = "the ranks disagree about the exchange records (%d..%d values): no max over ranks" % (int(lo), int(nkeys))
+            return rep
     t = torch.tensor(vals, dtype=torch.float64, device=dev)
     if world > 1:
         P._all_reduce(t, dist.ReduceOp.MAX)
@@ -726,8 +737,7 @@ def bench_gat(args, rank, world, dev, backend, stage):
             label = ("%s_kernel (XCD-sliced SDDMM <dOut_i, Z_j> + softmax / LeakyReLU backward, one pass over the "
                      "stored entries)" % kname)
         ach = alg / (avg * 1e-3)
-        traffic, traffic_note = (pmc_traffic_for(args, world, F, "gat_grad") if kname == "spmm_heads_grad" and not emul
-                                 else (None, "no PMC record"))
+        traffic, traffic_note = (pmc_traffic_for(args, world, F, "gat_grad") if kname == "spmm_heads_grad" else (None, "no PMC record"))
         roofline = {"bound": "hbm", "kernel": label,
                     "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
                     "traffic_note": traffic_note,

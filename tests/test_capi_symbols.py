@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(L, n), "libpgcn_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "%s is not bound in _lib.SIGNATURES" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert L.pgcn_abi_version() == 2
+    assert L.pgcn_abi_version() == 3
 
 
 def _decode(tasks):

@@ -4,7 +4,7 @@
 # (products, SBM, mid, GAT), the shard shapes (--emulate-rank) and one rank of the papers100M shape from its shard.
 # usage: [FINAL_TESTS_K=expr] bash tools/final_profile.sh r04 [hp-partvec workload]
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-tag=${1:-r04}
+tag=${1:-r06}
 HP=${2:-tests/golden/partvec/products4-sbm.A.mtx.8.hp.gz}; W3=${3:-products4}
 out=gpurun_out/final_$tag; rm -rf $out; mkdir -p $out
 # (FINAL_TESTS_K="expr": only the GPU tests matching it -- when the full suite already ran in its own call)
@@ -40,6 +40,15 @@ done
 python tools/pmc_summary.py $out/pmc_gat spmm_heads > $out/pmc_summary_gat.txt
 python tools/make_pmc_traffic.py $out/pmc_summary_gat.txt $out/pmc_traffic.json profiles/${tag}_pmc_gat.txt reddit-gat rmat 1 256 random gat_grad "spmm_heads_kernel<4, true, true, false>"
 rm -rf $out/pmc_gat
+# ... and of rank 0 of 4 of the same line.  N > 1: the transposed structure runs as its halo rows and its local rows (two
+# launches of the same kernel per layer); the record is their mean per launch
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  t=$(echo "$set" | tr ' ' '+')
+  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm_heads" --output-format csv -d $out/pmc_gat_r4/$t -- python bench.py --workload reddit-gat --emulate-rank 0/4 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/pmc_gat_r4_$t.log 2>&1
+done
+python tools/pmc_summary.py $out/pmc_gat_r4 spmm_heads > $out/pmc_summary_gat_r4.txt
+python tools/make_pmc_traffic.py $out/pmc_summary_gat_r4.txt $out/pmc_traffic.json profiles/${tag}_pmc_gat_r4.txt reddit-gat rmat 0/4 256 random gat_grad "spmm_heads_kernel<4, true, true, false>"
+rm -rf $out/pmc_gat_r4
 cp $out/pmc_traffic.json profiles/pmc_traffic.json      # (bench.py reads it from there for the lines below)
 else python tools/make_shards.py --workload papers --ranks 8 --only-rank 0 --device cuda --out /tmp/papers > $out/papers_make_shards.txt 2>&1; fi
 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1200 $out/bench.json; echo
@@ -71,3 +80,15 @@ try:
 except Exception as e: print("$(basename $f)", "FAILED", e)
 PY
 done
+
+# the evidence the round's documents cite, copied where it is tracked
+cp $out/bench.json profiles/${tag}_bench_stdout.json 2>/dev/null
+cp $out/pytest_gpu_full.txt profiles/${tag}_pytest_gpu.txt 2>/dev/null
+f=$(ls $out/prof/*/*kernel_stats.csv $out/prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${tag}_bench_kernel_stats.csv
+f=$(ls $out/prof_gat/*/*kernel_stats.csv $out/prof_gat/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${tag}_bench_gat_kernel_stats.csv
+for w in products sbm mid gat; do cp $out/bench_$w.json profiles/${tag}_bench_${w}_stdout.json 2>/dev/null; done
+for f in $out/bench_rank_*.json $out/bench_gat_rank_0_4.json $out/bench_papers_full_rank_*.json $out/bench_${W3}_sbm_*_rank_*.json $out/papers_full_rank_0_8_check.json; do
+  [ -f "$f" ] && cp "$f" profiles/${tag}_$(basename $f)
+done
+[ -f gpurun_out/parity_observed.jsonl ] && cp gpurun_out/parity_observed.jsonl profiles/${tag}_parity_observed.jsonl
+ls profiles | grep "^${tag}_" | wc -l
