@@ -619,10 +619,11 @@ class GatKernelTimer:
     """HIP events around every launch of the dominant GAT kernel: the fused transposed product + edge gradient
     (pgcn_spmm_heads_grad_f32), or -- shapes it does not cover -- the stand-alone edge gradient."""
     NAMES = ("spmm_heads_grad", "gat_edge_grad_tasks", "gat_edge_grad_sliced")
+    PARTS = ("gat_blocks_backward", "gat_blocks_forward", "spmm_heads_forward2")   # r06: the block part of the same pass, and the forward pass
 
     def __init__(self, kernels, device):
         self.k, self.device, self.records, self.on = kernels, device, {}, False
-        for name in self.NAMES:                                             # whichever variant the engine uses
+        for name in self.NAMES + self.PARTS:                                # whichever variant the engine uses
             if hasattr(kernels, name):
                 setattr(kernels, name, self._wrap(name, getattr(kernels, name)))
 
@@ -647,6 +648,10 @@ class GatKernelTimer:
             if ts:
                 return name, sum(ts) / len(ts), len(ts)
         return None, None, 0
+
+    def part_ms(self, name):
+        ts = [a.elapsed_time(b) for a, b in self.records.get(name, [])]
+        return sum(ts) / len(ts) if ts else None
 
 
 def bench_gat(args, rank, world, dev, backend, stage):
@@ -736,13 +741,21 @@ def bench_gat(args, rank, world, dev, backend, stage):
             alg = (4 + 8 * heads) * eng.nnz + 4 * F * (n_c + n_r)  # col + alpha + de per entry and head; Z and dOut panels
             label = ("%s_kernel (XCD-sliced SDDMM <dOut_i, Z_j> + softmax / LeakyReLU backward, one pass over the "
                      "stored entries)" % kname)
+        blocks_ms = timer.part_ms("gat_blocks_backward") if kname == "spmm_heads_grad" else None
+        gather_ms = avg
+        if blocks_ms:                      # r06: the pass = the gather kernel over the remaining entries + the dense blocks on the matrix cores
+            avg += blocks_ms
+            label += (" + gat_blocks_kernel<backward> (pgcn_gat_blocks_backward_f32: %.0f %% of the entries in 512 x 128 blocks on the bf16 "
+                      "matrix cores, weights computed in registers)" % (100.0 * eng.blocks_nnz / max(eng.nnz, 1)))
         ach = alg / (avg * 1e-3)
         traffic, traffic_note = (pmc_traffic_for(args, world, F, "gat_grad") if kname == "spmm_heads_grad" else (None, "no PMC record"))
         roofline = {"bound": "hbm", "kernel": label,
                     "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
                     "traffic_note": traffic_note,
                     "alg_bytes_per_launch": alg, "avg_launch_ms": avg, "launches_timed": launches,
-                    "gather_model_GBs": 4.0 * F * eng.nnz / (avg * 1e-3) / 1e9}
+                    "gather_model_GBs": 4.0 * F * eng.nnz / (avg * 1e-3) / 1e9,
+                    "pass_split_ms": {"backward_gather": gather_ms, "backward_blocks": blocks_ms,
+                                      "forward_gather": timer.part_ms("spmm_heads_forward2"), "forward_blocks": timer.part_ms("gat_blocks_forward")}}
     out = {"metric": "edges aggregated/sec (%s-shaped %d-layer GAT, %d heads x %d, full training epoch)" % (
                base.capitalize(), L, heads, dh),
            "value": 2 * L * (eng.nnz if emul else nnz) * args.steps / elapsed, "unit": "edges/s", "n_gpus": world,
@@ -758,6 +771,9 @@ def bench_gat(args, rank, world, dev, backend, stage):
                       "exchange": exch.name if exch else "none",
                       "rank_shape": {"n_local": part.n_local, "n_halo": part.n_halo, "n_send": part.n_send, "nnz_rank": eng.nnz},
                       "multi_head_spmm": bool(eng.multi_head), "fused_edge_gradient": bool(eng.fused_grad),
+                      "blocks": None if eng.fwd_blocks is None else {"entries_on_blocks": eng.blocks_nnz / max(eng.nnz, 1),
+                                                                    "pieces": eng.fwd_blocks.npieces, "panels": eng.fwd_blocks.npanels,
+                                                                    "blocks": int(eng.fwd_blocks.blk_img.numel())},
                       "vertex_order": {k: v for k, v in (part.order_info or {}).items() if not k.startswith("_")}},
            "roofline": roofline, "ms_per_epoch": ms, "ms_per_layer_fwd_bwd": ms / L, "loss": float(loss), "setup_s": setup_s,
            "cpu_baseline": None}

@@ -294,6 +294,31 @@ int pgcn_spmm_heads_forward2_f32(const int64_t *rowptr, const int32_t *col, cons
                                  float *C2, int64_t ldc2, float *partial_ws, int64_t partial_ws_elems, int64_t nslots,
                                  uint32_t flags, pgcn_stream_t stream);
 
+/* The dense 512 x 128 BLOCKS of the attention pattern on the bf16 matrix cores (r06, pgcn_gat_blocks.hip): the entries inside the
+ * listed blocks of the products above, with the weights computed in registers from the same statistics and split into three bf16
+ * planes (fp32 accuracy, as pgcn_spmm_dense_bf16x3_f32).  work / blk_img / panel_list / npanels / image_ws: the block structure and
+ * work-space of pgcn_spmm_dense_bf16x3_f32 (image of heads * d features); work_row0[nwork]: first matrix row of every piece;
+ * bits: the PATTERN of the blocks, 16 bytes per (block, wave w of 8, lane of 64) in that order -- byte u = 2 ks + rb, bit e = position
+ * (row 64 w + 32 rb + lane % 32, column 16 ks + 8 (lane / 32) + e) of the block.  mode 0 (LeakyReLU + softmax) only, d = 64,
+ * heads * d <= 256; PGCN_EUNSUPPORTED otherwise (callers keep every entry in the gather kernels).  The calls write SLOT rows only; the
+ * caller adds them to the outputs with pgcn_spmm_fixup_f32 (PGCN_SPMM_ACCUMULATE) after the gather kernel of the remaining entries:
+ *   forward  (rowstat of the rows [nrows x heads x 4], s2 of the columns, B = Z):  partial_ws = nslots x F floats (out), then
+ *            nslots x (F + heads rounded up to 4) floats (V | C | 0): the two outputs of pgcn_spmm_heads_forward2_f32;
+ *   backward (the transposed pattern: rowstat and t of the COLUMNS, s2 and Z of the ROWS, B = dOut):  partial_ws = nslots x
+ *            (F + heads rounded up to 4) floats (dZ | ds2 | 0): the output row of pgcn_spmm_heads_grad_f32 (de is not available).
+ * GPU/PGAT.py:144-149 and its autograd.                                                                                        */
+int pgcn_gat_blocks_forward_f32(const int32_t *work, int64_t nwork, const int32_t *work_row0, const int32_t *blk_img,
+                                const uint32_t *bits, const int32_t *panel_list, int64_t npanels, const float *rowstat,
+                                const float *s2, int64_t lds2, float slope, int32_t heads, int32_t d, int64_t nrows,
+                                int64_t ncols, const float *B, int64_t ldb, void *image_ws, int64_t image_ws_bytes,
+                                float *partial_ws, int64_t partial_ws_elems, int64_t nslots, pgcn_stream_t stream);
+int pgcn_gat_blocks_backward_f32(const int32_t *work, int64_t nwork, const int32_t *work_row0, const int32_t *blk_img,
+                                 const uint32_t *bits, const int32_t *panel_list, int64_t npanels, const float *rowstat,
+                                 const float *s2, int64_t lds2, const float *t, const float *Z, int64_t ldz, float slope,
+                                 int32_t heads, int32_t d, int64_t nrows, int64_t ncols, const float *B, int64_t ldb,
+                                 void *image_ws, int64_t image_ws_bytes, float *partial_ws, int64_t partial_ws_elems,
+                                 int64_t nslots, pgcn_stream_t stream);
+
 /* ---- GAT path: attention over the stored entries ----------------------
  * Replaces the dense n x n arithmetic of PGAT.forward, GPU/PGAT.py:138-151.  Per head k with
  * s1 = Z a1, s2 = Z a2 (:141-142):  raw_ij = s1[i,k] + s2[col,k]  (:144).

@@ -61,6 +61,10 @@ SIGNATURES = {
     "pgcn_spmm_heads_forward2_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_float, _i32, _i32, _i32, _i64, _vp, _i64,
                                                     _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _u32,
                                                     _vp]),
+    "pgcn_gat_blocks_forward_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, ctypes.c_float, _i32, _i32, _i64, _i64,
+                                                   _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "pgcn_gat_blocks_backward_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, ctypes.c_float, _i32,
+                                                    _i32, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "pgcn_spmm_dense_bf16x3_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),
     "pgcn_dense_bf16x3_image_bytes": (_i64, [_i64, _i32]),
     "pgcn_spmm_fixup_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _u32, _vp]),

@@ -50,6 +50,7 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "pgcn_bf16x3.h"
 #include "pgcn_internal.h"
 #include "pgcn_once.h"
 
@@ -64,107 +65,28 @@
 #endif
 
 namespace {
+using namespace pgcn_bf16x3;
 
 constexpr int kProbe = PGCN_DENSE3_PROBE;
-constexpr int kT = 128;                  // columns of a block = rows of a panel = features per feature block
 constexpr int kBR = PGCN_STRIP_TR;       // 512 rows per block
 constexpr int kThreads = 512;            // 8 waves x 64 rows
-constexpr int kSplitThreads = 256;
 static_assert(kBR == 8 * 64, "a wave owns 64 rows of a block");
-constexpr int kQBytes = 3 * 4 * kT * 16; // one quarter image: 3 planes x 4 k groups x 128 columns x 16 B = 24 KB
-constexpr int kImgBytes = 4 * kQBytes;   // one panel x feature block: 96 KB
 constexpr int kUnitBytes = 2 * 1024;     // a wave's A values of one unit (k step x row block): 2 float4 per lane
 constexpr int kRingUnits = 4;            // units of A in flight per wave (one quarter)
 constexpr int kOffA = 2 * kQBytes;       // LDS: two quarter images of B, then the A rings [slot][wave]
 constexpr size_t kSmem3 = kOffA + (size_t)kRingUnits * 8 * kUnitBytes;
 static_assert(kSmem3 <= 160 * 1024, "LDS budget of one CU");
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-
-typedef __attribute__((address_space(1))) const void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
-
-__device__ __forceinline__ uint32_t pack_bf16(float x, float y) {     // {bf16(x) in bits 0-15, bf16(y) in bits 16-31}, RNE
-    const f32x2 v = {x, y};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float lo_as_f32(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float hi_as_f32(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-
-// x, y -> the three bf16 planes of both, packed {x in bits 0-15, y in bits 16-31}
-__device__ __forceinline__ void split_pair(float x, float y, uint32_t &u1, uint32_t &u2, uint32_t &u3) {
-    u1 = pack_bf16(x, y);
-    const float rx = x - lo_as_f32(u1), ry = y - hi_as_f32(u1);          // exact
-    u2 = pack_bf16(rx, ry);
-    u3 = pack_bf16(rx - lo_as_f32(u2), ry - hi_as_f32(u2));              // exact, and a bf16 number
-}
-
 __device__ __forceinline__ f32x16 mma(const u32x4 &a, const u32x4 &b, const f32x16 &c) {
     if constexpr (kProbe == 1) return c;
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// ---- the panel split ------------------------------------------------------------------------------------------
-// grid (panels in the list, feature blocks of 128); thread t: column n = t & 127, k groups 8 (t >> 7) .. + 8
-__global__ __launch_bounds__(kSplitThreads) void spmm_split_panels_kernel(const int32_t *__restrict__ panel_list, const float *__restrict__ B,
-                                                                  int64_t ldb, int64_t ncols, int32_t f, u32x4 *__restrict__ image) {
-    const int64_t r0 = (int64_t)panel_list[blockIdx.x];          // first row of the panel (r06: any row -- a grid aligned to the vertex order's bands)
-    const int fcol0 = blockIdx.y * kT;
-    const int n = threadIdx.x & (kT - 1);
-    const bool n_ok = fcol0 + n < f;
-    const float *col = B + fcol0 + (n_ok ? n : 0);
-    u32x4 *img = image + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (kImgBytes / 16);
-    const int kg0 = (threadIdx.x >> 7) * 8;
-#pragma unroll 2
-    for (int kgi = 0; kgi < 8; ++kgi) {
-        const int kga = kg0 + kgi;                         // k group of the panel: rows 8 kga .. 8 kga + 7
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t r = r0 + 8 * kga + j;
-            x[j] = (n_ok && r < ncols) ? col[r * ldb] : 0.f;
-        }
-        u32x4 p1, p2, p3;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            uint32_t u1, u2, u3;
-            split_pair(x[2 * d], x[2 * d + 1], u1, u2, u3);
-            p1[d] = u1; p2[d] = u2; p3[d] = u3;
-        }
-        const int q = kga >> 2, kg = kga & 3;
-        u32x4 *dst = img + ((q * 3) * 4 + kg) * kT + n;
-        dst[0] = p1;
-        dst[4 * kT] = p2;
-        dst[8 * kT] = p3;
-    }
-}
-
 // ---- the tile kernel ------------------------------------------------------------------------------------------
-// LDS reads the compiler does not see as memory operations; the matching waits take the results as read-write operands
-template <int OFF>
-__device__ __forceinline__ void lds_read_b128(u32x4 &v, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read_b128(f32x4 &v, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-}
+// (LDS reads: pgcn_bf16x3.h lds_read_b128 -- inline asm the compiler does not see; the matching waits take the results as read-write operands)
 template <int N>                                                       // all but the N newest LDS reads have landed
 __device__ __forceinline__ void lds_wait(u32x4 (&b)[3]) {
     asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N));
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
 }
 
 // the three reads (one per plane) of step T of a quarter: k step s = T / NBLK, column block nb = T % NBLK

@@ -129,6 +129,24 @@ def build_gat_graph(part: Partition, positive_only: bool = False, long_row: Opti
     return g
 
 
+def _split_blocks(csr: HostCSR, kernels, chunk: int, small: int, long_row: int):
+    """(gather structure of the remaining entries, device blocks) of an attention pattern, or None when too little of it is dense
+    (``tuning.gat_block_tau``: a block pays from ~4 % fill on -- four heads of a block cost ~45 us of one CU, a gathered entry
+    ~18 ns)."""
+    from .partition import split_dense3
+    if csr.nnz == 0 or csr.ncols < 128 or csr.nrows < 1:
+        return None
+    rows = torch.repeat_interleave(torch.arange(csr.nrows, dtype=torch.int64, device=csr.rowptr.device), csr.rowptr[1:] - csr.rowptr[:-1])
+    cols = csr.col.to(torch.int64)
+    ones = torch.ones(rows.numel(), dtype=torch.float32, device=rows.device)
+    keep, h3 = split_dense3(rows, cols, ones, csr.nrows, csr.ncols, float(_T.gat_block_tau))
+    if h3 is None or h3.nnz < _T.gat_block_min_frac * csr.nnz:
+        return None
+    rest = csr_from_coo(rows[keep], cols[keep], ones[:int(keep.sum())], csr.nrows, csr.ncols, nslices=csr.nslices, core=False)
+    rest_dev = kernels.prepare_gat(rest, *_row_lists(rest.rowptr, long_row), chunk=chunk, small_row=small)
+    return rest_dev, kernels.prepare_gat_blocks(h3)
+
+
 @dataclass
 class GatLayerState:
     """Per-layer buffers that live from forward to backward."""
@@ -178,6 +196,18 @@ class GatEngine(BoundaryExchange):
         if g.fwd_halo is not None:
             self.fwd_local = kernels.prepare_gat(g.fwd_local, *g.fwd_local_lists, chunk=chunk, small_row=small)
             self.fwd_halo = kernels.prepare_gat(g.fwd_halo, *g.fwd_halo_lists, chunk=chunk, small_row=small)
+        # r06: the dense 512 x 128 blocks of the pattern on the bf16 matrix cores (pgcn_gat_blocks.hip) -- weights computed in registers from
+        # the row / column statistics; the gather kernels keep the remaining entries.  Standard mode, unsplit structures (N = 1, or
+        # PGCN_OVERLAP=0): the split structures of the overlapped exchange stay gather-only
+        self.fwd_blocks = self.bwd_blocks = self.fwd_rest = self.bwd_rest = None
+        self.blocks_nnz = 0
+        if _T.gat_blocks and mode == "standard" and g.fwd_halo is None and hasattr(kernels, "prepare_gat_blocks"):
+            lr = LONG_ROW if long_row is None else long_row
+            fb = _split_blocks(g.fwd, kernels, chunk, small, lr)
+            bb = _split_blocks(g.bwd, kernels, chunk, small, lr) if fb is not None else None
+            if fb is not None and bb is not None:
+                (self.fwd_rest, self.fwd_blocks), (self.bwd_rest, self.bwd_blocks) = fb, bb
+                self.blocks_nnz = self.fwd_blocks.nnz
         self.perm = g.perm.to(self.device)
         self._inv_perm = None              # forward entry -> its position in the transposed structure (built on demand)
         self._scratch = {}
@@ -306,7 +336,11 @@ class GatEngine(BoundaryExchange):
             pw2 = F + (K + 3) // 4 * 4
             if st.V is None or st.V.shape != (n_p, pw2):
                 st.V = torch.empty((n_p, pw2), dtype=torch.float32, device=self.device)
-            st.fused = self.k.spmm_heads_forward2(self.fwd, st.rowstat, st.s2c, self.slope, self.mode_id, Zc, out, st.V, K, d)
+            blocks = self.fwd_blocks is not None and d == 64
+            st.fused = self.k.spmm_heads_forward2(self.fwd_rest if blocks else self.fwd, st.rowstat, st.s2c, self.slope, self.mode_id, Zc,
+                                                  out, st.V, K, d)
+            if blocks and st.fused and not self.k.gat_blocks_forward(self.fwd_blocks, st.rowstat, st.s2c, self.slope, Zc, out, st.V, K, d):
+                raise RuntimeError("the block part of the GAT forward was refused after the gather part was taken")
         if not st.fused:
             alpha = self.planes(st)
             self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,
@@ -356,7 +390,11 @@ class GatEngine(BoundaryExchange):
         if st.fused:
             # one gather pass: dZc = A_alpha^T . dOut and ds2 = the row sums of the edge gradient, which is not stored:
             # ds1 = its column sums = <dOut_i, V_i> - t_i C_i from the forward pass's second accumulator
-            if self.k.spmm_heads_grad(self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, st.Zc, t, dZc, None, K, d):
+            blocks = self.bwd_blocks is not None and d == 64
+            if self.k.spmm_heads_grad(self.bwd_rest if blocks else self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, st.Zc, t,
+                                      dZc, None, K, d):
+                if blocks and not self.k.gat_blocks_backward(self.bwd_blocks, st.rowstat, st.s2c, self.slope, dOut, st.Zc, t, dZc, K, d):
+                    raise RuntimeError("the block part of the GAT backward was refused after the gather part was taken")
                 ds1 = dots[1] if dots is not None and dots[1] is not None else \
                     (dOut.view(n_p, K, d) * st.V[:, :F].view(n_p, K, d)).sum(-1) - t * st.V[:, F:F + K]
                 return self._finish_backward(st, dOut, dZc, ds1, pack)

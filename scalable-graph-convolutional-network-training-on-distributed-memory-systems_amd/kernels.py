@@ -87,6 +87,27 @@ class DeviceDense3:
 
 
 @dataclass
+class DeviceGatBlocks:
+    """The dense 512 x 128 blocks of an attention pattern (pgcn_gat_blocks.hip): the block structure of ``DeviceDense3`` with the PATTERN
+    as one bit per position, and the slot lists that add a piece's partial rows to the outputs."""
+    nrows: int
+    ncols: int
+    work: torch.Tensor            # int32 [npieces, 4]
+    work_row0: torch.Tensor       # int32 [npieces] first matrix row of a piece
+    blk_img: torch.Tensor
+    bits: torch.Tensor            # int32 [nblocks, 8, 64, 4]
+    panel_list: torch.Tensor
+    fix: torch.Tensor             # int32 [rows with a slot, 4] {row, begin, count, 0}
+    slot_ids: torch.Tensor
+    npieces: int
+    npanels: int
+    nslots: int
+    nnz: int
+    image: Optional[torch.Tensor] = None
+    ws: Optional[torch.Tensor] = None
+
+
+@dataclass
 class DeviceStrip:
     work: torch.Tensor
     rec: torch.Tensor
@@ -537,6 +558,11 @@ class HipKernels:
         if B.shape[1] < F or C.shape[1] < F or C2.shape[1] < pw2 or A.row_map is not None:
             raise _lib.PgcnError("B / C narrower than heads * d, C2 narrower than heads * d + heads (rounded up to 4), "
                                  "or a compact-row structure")
+        if A.col.numel() == 0:               # nothing stored (every entry of the pattern sits in blocks, r06): the outputs are defined all the same
+            if not accumulate:
+                C[:A.nrows, :F].zero_()
+                C2[:A.nrows, :pw2].zero_()
+            return True
         need = A.nslots * (F + pw2)
         if need and (A.ws is None or A.ws.numel() < need):
             A.ws = torch.empty(need, dtype=torch.float32, device=self.device)
@@ -580,6 +606,10 @@ class HipKernels:
         if de is not None and not (de.is_cuda and de.dtype is torch.float32 and de.is_contiguous()
                                    and de.numel() >= nnz * heads):
             raise _lib.PgcnError("de must be a contiguous fp32 CUDA tensor of nnz * heads elements")
+        if nnz == 0:
+            if not accumulate:
+                C[:AT.nrows, :pw].zero_()
+            return True
         need = AT.nslots * pw
         if need and (AT.ws is None or AT.ws.numel() < need):
             AT.ws = torch.empty(need, dtype=torch.float32, device=self.device)
@@ -593,6 +623,114 @@ class HipKernels:
         if rc == _lib.PGCN_EUNSUPPORTED:
             return False
         _lib.check(rc, "pgcn_spmm_heads_grad_f32")
+        return True
+
+    # -- the dense blocks of an attention pattern (pgcn_gat_blocks.hip, r06) ------------------------------------------
+    @staticmethod
+    def gat_block_bits(h3) -> torch.Tensor:
+        """The pattern of ``HostDense3`` blocks as bits: [nblocks, 8 waves, 64 lanes, 4 words] int32 -- byte u = 2 ks + rb of a lane's
+        16 bytes, bit 4 h + e, the A-operand order of ``partition.dense3_index`` (include/pgcn_hip.h, pgcn_gat_blocks_forward_f32)."""
+        nb = h3.vals3.shape[0]
+        nz = (h3.vals3 != 0).view(nb, 8, 16, 2, 64, 4)                                  # [block][w][unit][h][lane][e]
+        wgt = (1 << (4 * torch.arange(2, device=nz.device).view(2, 1, 1) + torch.arange(4, device=nz.device).view(1, 1, 4))).to(torch.int64)
+        byte = (nz.to(torch.int64) * wgt.view(1, 1, 1, 2, 1, 4)).sum((3, 5))            # [block][w][unit][lane]
+        byte = byte.permute(0, 1, 3, 2).reshape(nb, 8, 64, 4, 4)                        # [block][w][lane][word][byte of the word]
+        word = (byte << (8 * torch.arange(4, device=nz.device).view(1, 1, 1, 1, 4))).sum(-1)
+        word = torch.where(word >= (1 << 31), word - (1 << 32), word)
+        return word.to(torch.int32).contiguous()
+
+    def prepare_gat_blocks(self, h3) -> DeviceGatBlocks:
+        """Upload the blocks split off an attention pattern (``partition.split_dense3`` on the pattern's coordinates)."""
+        dev = self.device
+        work = h3.work.to(torch.int32)
+        w64 = work.cpu().to(torch.int64)
+        p0, pr = h3.piece_row0.cpu().to(torch.int64), h3.piece_rows.cpu().to(torch.int64)
+        start = torch.cumsum(pr, 0) - pr
+        rit = torch.arange(int(pr.sum()), dtype=torch.int64) - torch.repeat_interleave(start, pr)
+        rows = torch.repeat_interleave(p0, pr) + rit
+        slots = torch.repeat_interleave(w64[:, 3], pr) + rit
+        seq = torch.repeat_interleave(torch.arange(w64.shape[0], dtype=torch.int64), pr)
+        ok = rows < h3.nrows
+        rows, slots, seq = rows[ok], slots[ok], seq[ok]
+        order = torch.argsort(rows * (1 << 32) + seq)
+        rows, slots = rows[order], slots[order]
+        urows, counts = torch.unique_consecutive(rows, return_counts=True)
+        begin = torch.cumsum(counts, 0) - counts
+        fix = torch.stack([urows, begin, counts, torch.zeros_like(urows)], 1).to(torch.int32)
+        return DeviceGatBlocks(h3.nrows, h3.ncols, work.to(dev).contiguous(), h3.piece_row0.to(dev, torch.int32).contiguous(),
+                               h3.blk_img.to(dev).contiguous(), self.gat_block_bits(h3).to(dev), h3.panel_list.to(dev).contiguous(),
+                               fix.to(dev).contiguous(), slots.to(torch.int32).to(dev).contiguous(), h3.npieces,
+                               int(h3.panel_list.numel()), h3.nslots, h3.nnz)
+
+    def _gat_blocks_ws(self, G: DeviceGatBlocks, F: int, per_slot: int):
+        need_img = int(self.lib.pgcn_dense_bf16x3_image_bytes(G.npanels, F))
+        if G.image is None or G.image.numel() < need_img:
+            G.image = torch.empty(need_img, dtype=torch.uint8, device=self.device)
+        need = G.nslots * per_slot
+        if G.ws is None or G.ws.numel() < need:
+            G.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+
+    def gat_blocks_forward(self, G: DeviceGatBlocks, rowstat: torch.Tensor, s2: torch.Tensor, slope: float, B: torch.Tensor,
+                           C: torch.Tensor, C2: torch.Tensor, heads: int, d: int) -> bool:
+        """C[:, :F] += the blocks' part of A_alpha . B, C2 += their part of V | C (the outputs of ``spmm_heads_forward2``, which must have
+        run over the remaining entries before: this call accumulates).  False = shape not covered (d = 64, standard mode only)."""
+        F = heads * d
+        if d != 64 or F > 256:
+            return False
+        pw2 = F + (heads + 3) // 4 * 4
+        self._check_rows(s2, G.ncols, heads, "s2")
+        if not (rowstat.is_cuda and rowstat.dtype is torch.float32 and rowstat.is_contiguous() and rowstat.numel() == G.nrows * heads * 4):
+            raise _lib.PgcnError("rowstat must be a contiguous fp32 [nrows, heads, 4] CUDA tensor")
+        self._check_dense(B, G.ncols, "B")
+        self._check_dense(C, G.nrows, "C")
+        self._check_dense(C2, G.nrows, "C2")
+        if B.shape[1] < F or C.shape[1] < F or C2.shape[1] < pw2:
+            raise _lib.PgcnError("B / C narrower than heads * d or C2 narrower than heads * d + heads (rounded up to 4)")
+        self._gat_blocks_ws(G, F, F + pw2)
+        st = self._stream()
+        rc = self.lib.pgcn_gat_blocks_forward_f32(
+            G.work.data_ptr(), G.npieces, G.work_row0.data_ptr(), G.blk_img.data_ptr(), G.bits.data_ptr(), G.panel_list.data_ptr(),
+            G.npanels, rowstat.data_ptr(), s2.data_ptr(), s2.stride(0), slope, heads, d, G.nrows, G.ncols, B.data_ptr(), B.stride(0),
+            G.image.data_ptr(), G.image.numel(), G.ws.data_ptr(), G.ws.numel(), G.nslots, st)
+        if rc == _lib.PGCN_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "pgcn_gat_blocks_forward_f32")
+        nfix = G.fix.shape[0]
+        _lib.check(self.lib.pgcn_spmm_fixup_f32(G.fix.data_ptr(), nfix, G.slot_ids.data_ptr(), None, G.ws.data_ptr(), C.data_ptr(),
+                                                C.stride(0), F, _lib.SPMM_ACCUMULATE, st), "pgcn_spmm_fixup_f32")
+        _lib.check(self.lib.pgcn_spmm_fixup_f32(G.fix.data_ptr(), nfix, G.slot_ids.data_ptr(), None, G.ws.data_ptr() + 4 * G.nslots * F,
+                                                C2.data_ptr(), C2.stride(0), pw2, _lib.SPMM_ACCUMULATE, st), "pgcn_spmm_fixup_f32")
+        return True
+
+    def gat_blocks_backward(self, G: DeviceGatBlocks, rowstat: torch.Tensor, s2: torch.Tensor, slope: float, B: torch.Tensor,
+                            Z: torch.Tensor, t: torch.Tensor, C: torch.Tensor, heads: int, d: int) -> bool:
+        """C[:, :F] += the blocks' part of A_alpha^T . B and C[:, F:F+heads] += their part of ds2 (the outputs of ``spmm_heads_grad`` with
+        de = None, which must have run over the remaining entries before).  ``G``: blocks of the TRANSPOSED pattern; rowstat / t of its
+        columns, s2 / Z of its rows.  False = shape not covered."""
+        F = heads * d
+        if d != 64 or F > 256:
+            return False
+        pw = F + (heads + 3) // 4 * 4
+        self._check_rows(s2, G.nrows, heads, "s2")
+        self._check_rows(t, G.ncols, heads, "t")
+        if not (rowstat.is_cuda and rowstat.dtype is torch.float32 and rowstat.is_contiguous() and rowstat.numel() == G.ncols * heads * 4):
+            raise _lib.PgcnError("rowstat must be a contiguous fp32 [ncols, heads, 4] CUDA tensor")
+        self._check_dense(B, G.ncols, "B")
+        self._check_dense(Z, G.nrows, "Z")
+        self._check_dense(C, G.nrows, "C")
+        if B.shape[1] < F or Z.shape[1] < F or C.shape[1] < pw or t.stride(0) != heads:
+            raise _lib.PgcnError("B / Z narrower than heads * d, C narrower than heads * d + heads (rounded up to 4) or t not contiguous")
+        self._gat_blocks_ws(G, F, pw)
+        st = self._stream()
+        rc = self.lib.pgcn_gat_blocks_backward_f32(
+            G.work.data_ptr(), G.npieces, G.work_row0.data_ptr(), G.blk_img.data_ptr(), G.bits.data_ptr(), G.panel_list.data_ptr(),
+            G.npanels, rowstat.data_ptr(), s2.data_ptr(), s2.stride(0), t.data_ptr(), Z.data_ptr(), Z.stride(0), slope, heads, d,
+            G.nrows, G.ncols, B.data_ptr(), B.stride(0), G.image.data_ptr(), G.image.numel(), G.ws.data_ptr(), G.ws.numel(), G.nslots, st)
+        if rc == _lib.PGCN_EUNSUPPORTED:
+            return False
+        _lib.check(rc, "pgcn_gat_blocks_backward_f32")
+        _lib.check(self.lib.pgcn_spmm_fixup_f32(G.fix.data_ptr(), G.fix.shape[0], G.slot_ids.data_ptr(), None, G.ws.data_ptr(), C.data_ptr(),
+                                                C.stride(0), pw, _lib.SPMM_ACCUMULATE, st), "pgcn_spmm_fixup_f32")
         return True
 
     def gat_edge_softmax(self, A: DeviceCSR, s1, s2, heads: int, slope: float, mode: int, n_global: int,

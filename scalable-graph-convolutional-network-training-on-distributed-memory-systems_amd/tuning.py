@@ -94,6 +94,9 @@ class Tuning:
                                      # and long rows cut into pieces of 8 192 (GCN: 1 024).  Reddit shape, 4 heads x 64, ms per epoch: 96 / 1 024
                                      # 58.7; 192 / 1 024 55.5; 384 / 1 024 56.4; 192 / 2 048 54.2; 192 / 4 096 53.2; 192 / 8 192 52.8;
                                      # 192 / 16 384 52.8; 320 / 8 192 52.9 (tools/probes_r05/p20_gat_plan.sh)
+    gat_blocks: bool = True          # r06: the dense 512 x 128 blocks of the attention pattern on the bf16 matrix cores (pgcn_gat_blocks.hip), weights
+    gat_block_tau: float = 0.10      # computed in registers; blocks at least this full (a block costs ~45 us of one CU for four heads, a gathered
+    gat_block_min_frac: float = 0.10 # entry ~18 ns: break-even near 4 %); patterns with less than this fraction of their entries in blocks stay gather-only
     gat_sliced: bool = True          # XCD-sliced edge gradient
     gat_task_grad: bool = True       # edge gradient over the SpMM plan's balanced tasks
     gat_multihead: bool = True       # all heads of attention @ Z in one launch
