@@ -741,7 +741,7 @@ def bench_gat(args, rank, world, dev, backend, stage):
             alg = (4 + 8 * heads) * eng.nnz + 4 * F * (n_c + n_r)  # col + alpha + de per entry and head; Z and dOut panels
             label = ("%s_kernel (XCD-sliced SDDMM <dOut_i, Z_j> + softmax / LeakyReLU backward, one pass over the "
                      "stored entries)" % kname)
-        blocks_ms = timer.part_ms("gat_blocks_backward") if kname == "spmm_heads_grad" else None
+        blocks_ms = timer.part_ms("gat_blocks_backward") if kname == "spmm_heads_grad" and eng.parts else None
         gather_ms = avg
         if blocks_ms:                      # r06: the pass = the gather kernel over the remaining entries + the dense blocks on the matrix cores
             avg += blocks_ms
@@ -771,9 +771,9 @@ def bench_gat(args, rank, world, dev, backend, stage):
                       "exchange": exch.name if exch else "none",
                       "rank_shape": {"n_local": part.n_local, "n_halo": part.n_halo, "n_send": part.n_send, "nnz_rank": eng.nnz},
                       "multi_head_spmm": bool(eng.multi_head), "fused_edge_gradient": bool(eng.fused_grad),
-                      "blocks": None if eng.fwd_blocks is None else {"entries_on_blocks": eng.blocks_nnz / max(eng.nnz, 1),
-                                                                    "pieces": eng.fwd_blocks.npieces, "panels": eng.fwd_blocks.npanels,
-                                                                    "blocks": int(eng.fwd_blocks.blk_img.numel())},
+                      "blocks": None if not eng.parts else {"entries_on_blocks": eng.blocks_nnz / max(eng.nnz, 1), "structures": {
+                          k: {"entries": v[1].nnz, "blocks": int(v[1].blk_img.numel()), "pieces": v[1].npieces, "panels": v[1].npanels}
+                          for k, v in eng.parts.items()}},
                       "vertex_order": {k: v for k, v in (part.order_info or {}).items() if not k.startswith("_")}},
            "roofline": roofline, "ms_per_epoch": ms, "ms_per_layer_fwd_bwd": ms / L, "loss": float(loss), "setup_s": setup_s,
            "cpu_baseline": None}

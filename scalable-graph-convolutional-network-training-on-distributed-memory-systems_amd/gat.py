@@ -139,7 +139,7 @@ def _split_blocks(csr: HostCSR, kernels, chunk: int, small: int, long_row: int):
     rows = torch.repeat_interleave(torch.arange(csr.nrows, dtype=torch.int64, device=csr.rowptr.device), csr.rowptr[1:] - csr.rowptr[:-1])
     cols = csr.col.to(torch.int64)
     ones = torch.ones(rows.numel(), dtype=torch.float32, device=rows.device)
-    keep, h3 = split_dense3(rows, cols, ones, csr.nrows, csr.ncols, float(_T.gat_block_tau))
+    keep, h3 = split_dense3(rows, cols, ones, csr.nrows, csr.ncols, float(_T.gat_block_tau), piece=int(_T.gat_block_piece) or None)
     if h3 is None or h3.nnz < _T.gat_block_min_frac * csr.nnz:
         return None
     rest = csr_from_coo(rows[keep], cols[keep], ones[:int(keep.sum())], csr.nrows, csr.ncols, nslices=csr.nslices, core=False)
@@ -197,17 +197,20 @@ class GatEngine(BoundaryExchange):
             self.fwd_local = kernels.prepare_gat(g.fwd_local, *g.fwd_local_lists, chunk=chunk, small_row=small)
             self.fwd_halo = kernels.prepare_gat(g.fwd_halo, *g.fwd_halo_lists, chunk=chunk, small_row=small)
         # r06: the dense 512 x 128 blocks of the pattern on the bf16 matrix cores (pgcn_gat_blocks.hip) -- weights computed in registers from
-        # the row / column statistics; the gather kernels keep the remaining entries.  Standard mode, unsplit structures (N = 1, or
-        # PGCN_OVERLAP=0): the split structures of the overlapped exchange stay gather-only
-        self.fwd_blocks = self.bwd_blocks = self.fwd_rest = self.bwd_rest = None
+        # the row / column statistics; the gather kernels keep the remaining entries.  Standard mode; every structure the fused passes walk
+        # (the whole pattern, or its local / halo parts under the overlapped exchange) is split on its own: self.parts[name] =
+        # (gather structure of the remaining entries, blocks) where enough of it is dense
+        self.parts = {}
         self.blocks_nnz = 0
-        if _T.gat_blocks and mode == "standard" and g.fwd_halo is None and hasattr(kernels, "prepare_gat_blocks"):
+        if _T.gat_blocks and mode == "standard" and hasattr(kernels, "prepare_gat_blocks"):
             lr = LONG_ROW if long_row is None else long_row
-            fb = _split_blocks(g.fwd, kernels, chunk, small, lr)
-            bb = _split_blocks(g.bwd, kernels, chunk, small, lr) if fb is not None else None
-            if fb is not None and bb is not None:
-                (self.fwd_rest, self.fwd_blocks), (self.bwd_rest, self.bwd_blocks) = fb, bb
-                self.blocks_nnz = self.fwd_blocks.nnz
+            names = ("fwd_local", "fwd_halo", "bwd_local", "bwd_halo") if g.fwd_halo is not None else ("fwd", "bwd")
+            for name in names:
+                sp = _split_blocks(getattr(g, name), kernels, chunk, small, lr)
+                if sp is not None:
+                    self.parts[name] = sp
+            self.blocks_nnz = sum(self.parts[k][1].nnz for k in self.parts if k.startswith("fwd"))
+        self.fwd_blocks = self.parts["fwd"][1] if "fwd" in self.parts else None      # (what bench.py and the tests report)
         self.perm = g.perm.to(self.device)
         self._inv_perm = None              # forward entry -> its position in the transposed structure (built on demand)
         self._scratch = {}
@@ -263,6 +266,26 @@ class GatEngine(BoundaryExchange):
             self.allreduce_sum(buf)          # BoundaryExchange: same communicator AND stream as the slabs
         return buf
 
+    # -- one pass = the gather kernel over the entries outside the blocks + the blocks ------------------------------
+    def _forward2(self, name: str, st: GatLayerState, s2, B, out, K: int, d: int, accumulate: bool = False) -> bool:
+        A = getattr(self, name)
+        part = self.parts.get(name) if d == 64 else None
+        if not self.k.spmm_heads_forward2(part[0] if part else A, st.rowstat, s2, self.slope, self.mode_id, B, out, st.V, K, d,
+                                          accumulate=accumulate):
+            return False
+        if part and not self.k.gat_blocks_forward(part[1], st.rowstat, s2, self.slope, B, out, st.V, K, d):
+            raise RuntimeError("the block part of the GAT forward was refused after the gather part was taken")
+        return True
+
+    def _grad(self, name: str, st: GatLayerState, s2, dOut, Z, t, dZc, K: int, d: int) -> bool:
+        AT = getattr(self, name)
+        part = self.parts.get(name) if d == 64 else None
+        if not self.k.spmm_heads_grad(part[0] if part else AT, st.rowstat, s2, self.slope, self.mode_id, dOut, Z, t, dZc, None, K, d):
+            return False
+        if part and not self.k.gat_blocks_backward(part[1], st.rowstat, s2, self.slope, dOut, Z, t, dZc, K, d):
+            raise RuntimeError("the block part of the GAT backward was refused after the gather part was taken")
+        return True
+
     # -- forward ---------------------------------------------------------
     def forward(self, st: GatLayerState, Z: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor,
                 panel: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -312,12 +335,11 @@ class GatEngine(BoundaryExchange):
             pw2 = F + (K + 3) // 4 * 4
             if st.V is None or st.V.shape != (n_p, pw2):
                 st.V = torch.empty((n_p, pw2), dtype=torch.float32, device=self.device)
-            ok = self.k.spmm_heads_forward2(self.fwd_local, st.rowstat, st.s2c[:n_p], self.slope, self.mode_id, Zc[:n_p], out, st.V, K, d)
+            ok = self._forward2("fwd_local", st, st.s2c[:n_p], Zc[:n_p], out, K, d)
             for w in wz:
                 w()
             if ok:
-                ok = self.k.spmm_heads_forward2(self.fwd_halo, st.rowstat, st.s2c[n_p:], self.slope, self.mode_id, Zc[n_p:], out, st.V,
-                                                K, d, accumulate=True)
+                ok = self._forward2("fwd_halo", st, st.s2c[n_p:], Zc[n_p:], out, K, d, accumulate=True)
             if not ok:
                 raise RuntimeError("the split GAT forward was refused by a kernel whose shape `covers` accepted")
             st.fused = True
@@ -336,11 +358,7 @@ class GatEngine(BoundaryExchange):
             pw2 = F + (K + 3) // 4 * 4
             if st.V is None or st.V.shape != (n_p, pw2):
                 st.V = torch.empty((n_p, pw2), dtype=torch.float32, device=self.device)
-            blocks = self.fwd_blocks is not None and d == 64
-            st.fused = self.k.spmm_heads_forward2(self.fwd_rest if blocks else self.fwd, st.rowstat, st.s2c, self.slope, self.mode_id, Zc,
-                                                  out, st.V, K, d)
-            if blocks and st.fused and not self.k.gat_blocks_forward(self.fwd_blocks, st.rowstat, st.s2c, self.slope, Zc, out, st.V, K, d):
-                raise RuntimeError("the block part of the GAT forward was refused after the gather part was taken")
+            st.fused = self._forward2("fwd", st, st.s2c, Zc, out, K, d)
         if not st.fused:
             alpha = self.planes(st)
             self.k.gat_edge_softmax(self.fwd, st.s1, st.s2c, K, self.slope, self.mode_id, self.n_global,
@@ -375,14 +393,12 @@ class GatEngine(BoundaryExchange):
         if st.fused and self.bwd_halo is not None and self.overlap and n_h > 0:
             # N > 1 (r06): the same pass in two parts -- the HALO rows of [dZ | ds2] first, their way home on the comm stream under the
             # local rows' part
-            if self.k.spmm_heads_grad(self.bwd_halo, st.rowstat, st.s2c[n_p:], self.slope, self.mode_id, dOut, st.Zc[n_p:], t,
-                                      dZc[n_p:], None, K, d):
+            if self._grad("bwd_halo", st, st.s2c[n_p:], dOut, st.Zc[n_p:], t, dZc[n_p:], K, d):
                 if Fp > F + K:
                     dZc[n_p:, F + K:].zero_()
                 back = self._slab("gat_send", self.n_send, Fp)
                 waits = self._exchange_all(dZc[n_p:], self.round_recv_off, back, self.round_send_off, Fp, tag="backward")
-                if not self.k.spmm_heads_grad(self.bwd_local, st.rowstat, st.s2c[:n_p], self.slope, self.mode_id, dOut, st.Zc[:n_p], t,
-                                              dZc[:n_p], None, K, d):
+                if not self._grad("bwd_local", st, st.s2c[:n_p], dOut, st.Zc[:n_p], t, dZc[:n_p], K, d):
                     raise RuntimeError("the local part of the fused GAT backward was refused after its halo part was taken")
                 ds1 = dots[1] if dots is not None and dots[1] is not None else \
                     (dOut.view(n_p, K, d) * st.V[:, :F].view(n_p, K, d)).sum(-1) - t * st.V[:, F:F + K]
@@ -390,11 +406,7 @@ class GatEngine(BoundaryExchange):
         if st.fused:
             # one gather pass: dZc = A_alpha^T . dOut and ds2 = the row sums of the edge gradient, which is not stored:
             # ds1 = its column sums = <dOut_i, V_i> - t_i C_i from the forward pass's second accumulator
-            blocks = self.bwd_blocks is not None and d == 64
-            if self.k.spmm_heads_grad(self.bwd_rest if blocks else self.bwd, st.rowstat, st.s2c, self.slope, self.mode_id, dOut, st.Zc, t,
-                                      dZc, None, K, d):
-                if blocks and not self.k.gat_blocks_backward(self.bwd_blocks, st.rowstat, st.s2c, self.slope, dOut, st.Zc, t, dZc, K, d):
-                    raise RuntimeError("the block part of the GAT backward was refused after the gather part was taken")
+            if self._grad("bwd", st, st.s2c, dOut, st.Zc, t, dZc, K, d):
                 ds1 = dots[1] if dots is not None and dots[1] is not None else \
                     (dOut.view(n_p, K, d) * st.V[:, :F].view(n_p, K, d)).sum(-1) - t * st.V[:, F:F + K]
                 return self._finish_backward(st, dOut, dZc, ds1, pack)

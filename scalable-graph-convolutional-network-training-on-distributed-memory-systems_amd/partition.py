@@ -259,7 +259,7 @@ def band_grid(x64: torch.Tensor, size: int, unit: int, bands: Optional[torch.Ten
 
 
 def split_dense3(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, ncols: int, tau: float = None,
-                 row_bands: Optional[torch.Tensor] = None, col_bands: Optional[torch.Tensor] = None):
+                 row_bands: Optional[torch.Tensor] = None, col_bands: Optional[torch.Tensor] = None, piece: Optional[int] = None):
     """Separate the entries of 512 x 128 blocks at least ``tau`` full.  Returns (keep_mask or None, HostDense3 or None).
     With the default ``tau`` a matrix with fewer than DENSE3_MIN_BLOCKS such blocks keeps them for the other paths.
     ``row_bands / col_bands`` (r06): starts of the bands the block grid restarts at -- the communities of the vertex order, so
@@ -289,7 +289,7 @@ def split_dense3(r: torch.Tensor, c: torch.Tensor, v: torch.Tensor, nrows: int, 
     blk_c0 = torch.zeros(nb, dtype=torch.int64, device=r64.device).index_copy_(0, bl, c0[is3])
     blk_rows = torch.clamp(torch.zeros(nb, dtype=torch.int64, device=r64.device).index_copy_(0, bl, rend[is3]) - blk_r0, max=BR)
     h3 = build_dense3(r64[is3], c64[is3], v[is3], bl, nb, (bk // ncp).to(torch.int32), (bk % ncp).to(torch.int32),
-                      nrows, ncols, None, blk_r0, blk_c0, blk_rows)
+                      nrows, ncols, piece, blk_r0, blk_c0, blk_rows)
     return ~is3, h3
 
 

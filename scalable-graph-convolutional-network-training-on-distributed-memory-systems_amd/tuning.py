@@ -96,6 +96,7 @@ class Tuning:
                                      # 192 / 16 384 52.8; 320 / 8 192 52.9 (tools/probes_r05/p20_gat_plan.sh)
     gat_blocks: bool = True          # r06: the dense 512 x 128 blocks of the attention pattern on the bf16 matrix cores (pgcn_gat_blocks.hip), weights
     gat_block_tau: float = 0.10      # computed in registers; blocks at least this full (a block costs ~45 us of one CU for four heads, a gathered
+    gat_block_piece: int = 0         # blocks per piece of the attention blocks (0 = the adaptive rule of the GCN blocks: one round of 256 pieces, 1..8)
     gat_block_min_frac: float = 0.10 # entry ~18 ns: break-even near 4 %); patterns with less than this fraction of their entries in blocks stay gather-only
     gat_sliced: bool = True          # XCD-sliced edge gradient
     gat_task_grad: bool = True       # edge gradient over the SpMM plan's balanced tasks

@@ -32,22 +32,23 @@ pmc reddit_sbm  reddit sbm 1 128 random loc --generator sbm
 python tools/make_shards.py --workload papers --ranks 8 --only-rank 0 --device cuda --out /tmp/papers > $out/papers_make_shards.txt 2>&1
 pmc papers_r8l  papers rmat 0/8 64 block loc   --workload papers --shards /tmp/papers --emulate-rank 0/8 --features 64 --block loc
 pmc papers_r8h0 papers rmat 0/8 64 block halo0 --workload papers --shards /tmp/papers --emulate-rank 0/8 --features 64 --block halo0
-# BASELINE config 5: the dominant pass of the GAT epoch (the fused transposed product + edge gradient), counters over the bench command itself
+# BASELINE config 5: the dominant pass of the GAT epoch (the fused transposed product + edge gradient: the gather kernel over the entries outside the
+# dense blocks + the block kernel, r06), counters over the bench command itself
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   t=$(echo "$set" | tr ' ' '+')
-  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm_heads" --output-format csv -d $out/pmc_gat/$t -- python bench.py --workload reddit-gat --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/pmc_gat_$t.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm_heads|gat_blocks" --output-format csv -d $out/pmc_gat/$t -- python bench.py --workload reddit-gat --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/pmc_gat_$t.log 2>&1
 done
-python tools/pmc_summary.py $out/pmc_gat spmm_heads > $out/pmc_summary_gat.txt
-python tools/make_pmc_traffic.py $out/pmc_summary_gat.txt $out/pmc_traffic.json profiles/${tag}_pmc_gat.txt reddit-gat rmat 1 256 random gat_grad "spmm_heads_kernel<4, true, true, false>"
+python tools/pmc_summary.py $out/pmc_gat "spmm_heads|gat_blocks" > $out/pmc_summary_gat.txt
+python tools/make_pmc_traffic.py $out/pmc_summary_gat.txt $out/pmc_traffic.json profiles/${tag}_pmc_gat.txt reddit-gat rmat 1 256 random gat_grad "spmm_heads_kernel<4, true, true, false>|gat_blocks_kernel<true"
 rm -rf $out/pmc_gat
 # ... and of rank 0 of 4 of the same line.  N > 1: the transposed structure runs as its halo rows and its local rows (two
 # launches of the same kernel per layer); the record is their mean per launch
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   t=$(echo "$set" | tr ' ' '+')
-  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm_heads" --output-format csv -d $out/pmc_gat_r4/$t -- python bench.py --workload reddit-gat --emulate-rank 0/4 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/pmc_gat_r4_$t.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "spmm_heads|gat_blocks" --output-format csv -d $out/pmc_gat_r4/$t -- python bench.py --workload reddit-gat --emulate-rank 0/4 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/pmc_gat_r4_$t.log 2>&1
 done
-python tools/pmc_summary.py $out/pmc_gat_r4 spmm_heads > $out/pmc_summary_gat_r4.txt
-python tools/make_pmc_traffic.py $out/pmc_summary_gat_r4.txt $out/pmc_traffic.json profiles/${tag}_pmc_gat_r4.txt reddit-gat rmat 0/4 256 random gat_grad "spmm_heads_kernel<4, true, true, false>"
+python tools/pmc_summary.py $out/pmc_gat_r4 "spmm_heads|gat_blocks" > $out/pmc_summary_gat_r4.txt
+python tools/make_pmc_traffic.py $out/pmc_summary_gat_r4.txt $out/pmc_traffic.json profiles/${tag}_pmc_gat_r4.txt reddit-gat rmat 0/4 256 random gat_grad "spmm_heads_kernel<4, true, true, false>|gat_blocks_kernel<true"
 rm -rf $out/pmc_gat_r4
 cp $out/pmc_traffic.json profiles/pmc_traffic.json      # (bench.py reads it from there for the lines below)
 else python tools/make_shards.py --workload papers --ranks 8 --only-rank 0 --device cuda --out /tmp/papers > $out/papers_make_shards.txt 2>&1; fi

@@ -23,11 +23,13 @@ def source_stamp():
 def main():
     txt = open(sys.argv[1]).read().splitlines()
     per, cur = {}, None
-    only = sys.argv[10] if len(sys.argv) > 10 else None     # keep ONE kernel: a substring of its name incl. template arguments
+    only = sys.argv[10] if len(sys.argv) > 10 else None     # keep the kernels whose name (incl. template arguments) contains one of these
+    alts = only.split("|") if only is not None else []      # '|'-separated substrings: the kernels of ONE pass (their traffic is summed)
+    hit = lambda ln: any(a in ln for a in alts)
     for ln in txt:
         m = re.search(r"counter_collection\.csv \| .*::(\w+)[<(]", ln)
         if m:
-            if only is not None and only not in ln:
+            if only is not None and not hit(ln):
                 cur = None
                 continue
             cur = per.setdefault(m.group(1), {})
@@ -38,7 +40,7 @@ def main():
         if "kernel_trace.csv" in ln:
             cur = None
             m = re.search(r"::(\w+)[<(].*mean=([\d.]+) us", ln)
-            if m and (only is None or only in ln):
+            if m and (only is None or hit(ln)):
                 per.setdefault(m.group(1), {}).setdefault("mean_us", float(m.group(2)))
     read = sum(2 * 1024 * v.get("FETCH_SIZE", 0) for v in per.values())
     write = sum(1024 * v.get("WRITE_SIZE", 0) for v in per.values())
