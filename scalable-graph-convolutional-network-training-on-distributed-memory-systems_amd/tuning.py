@@ -130,7 +130,7 @@ def _parse(spec: str, base: Tuning) -> Tuning:
 # what else the package reads from the environment: transports, ingest path, seeds, a cache path, a deadline -- no kernel shape
 _OTHER_SWITCHES = {"PGCN_TUNING", "PGCN_EXCHANGE", "PGCN_OVERLAP", "PGCN_INGEST", "PGCN_BACKEND", "PGCN_SEED", "PGCN_DATA_DIR",
                    "PGCN_TUNABLEOP_CACHE", "PGCN_SELFTEST_TIMEOUT", "PGCN_BENCH_BACKEND", "PGCN_BENCH_WATCHDOG", "PGCN_EXTRA_FLAGS",
-                   "PGCN_STRIP_PROBE"}
+                   "PGCN_STRIP_PROBE", "PGCN_GATB_PROBE"}
 
 
 def load(env=None) -> Tuning:

@@ -36,5 +36,6 @@ def test_package_reads_no_other_tuning_switch():
             names |= set(re.findall(r'(?:environ\.get|environ\[|getenv)\(?\s*["\'](PG[A-Z]+_[A-Z0-9_]+)', src))
     allowed = {"PGCN_TUNING", "PGCN_EXCHANGE", "PGCN_OVERLAP", "PGCN_INGEST", "PGCN_BACKEND", "PGCN_SEED", "PGAT_MODE",
                "PGCN_TUNABLEOP_CACHE", "PGCN_SELFTEST_TIMEOUT",     # a cache path and a deadline (r04)
-               "PGCN_STRIP_PROBE"}                 # (the last one only inside #ifdef PGCN_EXPERIMENTS)
+               "PGCN_STRIP_PROBE",                 # (only inside #ifdef PGCN_EXPERIMENTS)
+               "PGCN_GATB_PROBE"}                  # (only inside #ifdef PGCN_GATB_PROBES: timing-only variants of the GAT block kernel)
     assert names <= allowed, names - allowed
