@@ -59,6 +59,7 @@ python bench.py --workload products --steps 5 --warmup 2 --no-cpu-baseline > $ou
 python bench.py --generator sbm --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_sbm.json 2>/dev/null
 python bench.py --workload mid --steps 10 --warmup 2 > $out/bench_mid.json 2>/dev/null
 python bench.py --workload reddit-gat --steps 5 --warmup 2 > $out/bench_gat.json 2>/dev/null
+PGCN_TUNING=gat_blocks=0 python bench.py --workload reddit-gat --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_gat_noblocks.json 2>/dev/null   # (the same line with every entry in the gather kernels)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_gat -o gat -- python bench.py --workload reddit-gat --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/prof_gat_stdout.log 2> $out/prof_gat_stderr.log
 rm -f $out/prof_gat/*kernel_trace.csv $out/prof_gat/*/*kernel_trace.csv
 python bench.py --workload papers --emulate-rank 0/8 --shards /tmp/papers --partvec block --features 64 --layers 2 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_papers_full_rank_0_8.json 2>/dev/null
@@ -67,6 +68,7 @@ for rp in 0/8 3/8 7/8 0/4 0/2; do t=$(echo $rp | tr '/' '_')
   python bench.py --emulate-rank $rp --graph --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rank_$t.json 2>/dev/null
 done
 python bench.py --workload reddit-gat --emulate-rank 0/4 --steps 5 --warmup 2 > $out/bench_gat_rank_0_4.json 2>/dev/null
+python bench.py --workload reddit-gat --emulate-rank 0/4 --pace-exchange 153 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_gat_rank_0_4_paced.json 2>/dev/null   # (exchange priced at the xGMI link rate)
 if [ -f "$HP" ]; then
   for r in 0 3; do
     python bench.py --workload $W3 --generator sbm --partvec $HP --emulate-rank $r/8 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_${W3}_sbm_hp_rank_${r}_8.json 2>/dev/null
@@ -87,7 +89,7 @@ cp $out/bench.json profiles/${tag}_bench_stdout.json 2>/dev/null
 cp $out/pytest_gpu_full.txt profiles/${tag}_pytest_gpu.txt 2>/dev/null
 f=$(ls $out/prof/*/*kernel_stats.csv $out/prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${tag}_bench_kernel_stats.csv
 f=$(ls $out/prof_gat/*/*kernel_stats.csv $out/prof_gat/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${tag}_bench_gat_kernel_stats.csv
-for w in products sbm mid gat; do cp $out/bench_$w.json profiles/${tag}_bench_${w}_stdout.json 2>/dev/null; done
+for w in products sbm mid gat gat_noblocks; do cp $out/bench_$w.json profiles/${tag}_bench_${w}_stdout.json 2>/dev/null; done
 for f in $out/bench_rank_*.json $out/bench_gat_rank_0_4.json $out/bench_papers_full_rank_*.json $out/bench_${W3}_sbm_*_rank_*.json $out/papers_full_rank_0_8_check.json; do
   [ -f "$f" ] && cp "$f" profiles/${tag}_$(basename $f)
 done
