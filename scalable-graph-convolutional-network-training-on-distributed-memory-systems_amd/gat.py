@@ -129,7 +129,7 @@ def build_gat_graph(part: Partition, positive_only: bool = False, long_row: Opti
     return g
 
 
-def _split_blocks(csr: HostCSR, kernels, chunk: int, small: int, long_row: int):
+def _split_blocks(csr: HostCSR, kernels, chunk: int, small: int, long_row: int, row_bands=None, col_bands=None):
     """(gather structure of the remaining entries, device blocks) of an attention pattern, or None when too little of it is dense
     (``tuning.gat_block_tau``: a block pays from ~4 % fill on -- four heads of a block cost ~45 us of one CU, a gathered entry
     ~18 ns)."""
@@ -139,7 +139,8 @@ def _split_blocks(csr: HostCSR, kernels, chunk: int, small: int, long_row: int):
     rows = torch.repeat_interleave(torch.arange(csr.nrows, dtype=torch.int64, device=csr.rowptr.device), csr.rowptr[1:] - csr.rowptr[:-1])
     cols = csr.col.to(torch.int64)
     ones = torch.ones(rows.numel(), dtype=torch.float32, device=rows.device)
-    keep, h3 = split_dense3(rows, cols, ones, csr.nrows, csr.ncols, float(_T.gat_block_tau), piece=int(_T.gat_block_piece) or None)
+    keep, h3 = split_dense3(rows, cols, ones, csr.nrows, csr.ncols, float(_T.gat_block_tau), row_bands, col_bands,
+                            piece=int(_T.gat_block_piece) or None)
     if h3 is None or h3.nnz < _T.gat_block_min_frac * csr.nnz:
         return None
     rest = csr_from_coo(rows[keep], cols[keep], ones[:int(keep.sum())], csr.nrows, csr.ncols, nslices=csr.nslices, core=False)
@@ -205,8 +206,13 @@ class GatEngine(BoundaryExchange):
         if _T.gat_blocks and mode == "standard" and hasattr(kernels, "prepare_gat_blocks"):
             lr = LONG_ROW if long_row is None else long_row
             names = ("fwd_local", "fwd_halo", "bwd_local", "bwd_halo") if g.fwd_halo is not None else ("fwd", "bwd")
+            # the block grid restarts at the bands of the vertex order (its communities) along every LOCAL index space, as the GCN blocks' does
+            lb = getattr(part, "local_bands", None)
+            lb_all = None if lb is None else torch.cat([lb.to(torch.int64).cpu(), torch.tensor([g.n_local], dtype=torch.int64)]) if g.n_halo else lb
+            bands = {"fwd": (lb, lb_all), "bwd": (lb_all, lb), "fwd_local": (lb, lb), "bwd_local": (lb, lb), "fwd_halo": (lb, None),
+                     "bwd_halo": (None, lb)}
             for name in names:
-                sp = _split_blocks(getattr(g, name), kernels, chunk, small, lr)
+                sp = _split_blocks(getattr(g, name), kernels, chunk, small, lr, *bands[name])
                 if sp is not None:
                     self.parts[name] = sp
             self.blocks_nnz = sum(self.parts[k][1].nnz for k in self.parts if k.startswith("fwd"))

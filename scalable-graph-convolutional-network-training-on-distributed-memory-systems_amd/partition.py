@@ -684,6 +684,8 @@ class Partition:
     send_global: torch.Tensor   # int64 [n_send] global ids of the send slab rows
     nnz_global: int = 0
     order_info: Optional[dict] = None   # how the global vertex order was chosen (vertex_order)
+    local_bands: Optional[torch.Tensor] = None   # int64 starts of the vertex order's bands in LOCAL row numbering (None: one band); the grid of
+                                                 # the bf16 blocks of A_loc -- and of the attention blocks, gat.py -- restarts there
 
     @property
     def rounds(self) -> int:
@@ -1084,7 +1086,7 @@ def _finish_partition(row_m: torch.Tensor, col_m: torch.Tensor, val_m: torch.Ten
                      A_loc_T=A_loc_T, A_halo_T=A_halo_T, send_idx=send_idx.contiguous(), unpack=unpack,
                      send_owner=send_owner, halo_owner=halo_owner, round_send_off=round_send_off,
                      round_recv_off=round_recv_off, halo_global=halo_global,
-                     send_global=send_global, nnz_global=nnz_global)
+                     send_global=send_global, nnz_global=nnz_global, local_bands=lbands)
 
 
 def read_partvec(path: str) -> List[int]:

@@ -189,18 +189,32 @@ def test_blocks_refuse_what_they_do_not_cover(K, dev):
 
 
 @gpu
-def test_engine_with_and_without_blocks(dev):
-    """One rank, three layers' worth of forward / backward of the aggregation: the engine built with the blocks against the engine
-    built without them (the path test_gat_gpu.py holds to the reference's layers)."""
+@pytest.mark.parametrize("shape", ["corner", "communities"])
+def test_engine_with_and_without_blocks(dev, shape):
+    """One rank, forward / backward of the aggregation: the engine built with the blocks against the engine built without them (the
+    path test_gat_gpu.py holds to the reference's layers).  "communities": two planted communities, so that the vertex order has bands and
+    the block grid restarts inside the matrix (blocks of any origin, bands that end inside a block)."""
     import dataclasses
     partition, gat, kernels, tuning = pkg("partition"), pkg("gat"), pkg("kernels"), pkg("tuning")
-    n = 1300
-    A, rng = _corner_graph(n, n, 11, fill=0.25, rows=800, cols=500)
+    if shape == "corner":
+        n = 1300
+        A, rng = _corner_graph(n, n, 11, fill=0.25, rows=800, cols=500)
+    else:
+        n = 5000                                             # ten planted communities of 470-530 vertices: the order becomes a community order
+        rng = np.random.default_rng(12)
+        lab = np.minimum(np.arange(n) // 500 + (rng.random(n) < 0.06), 9)
+        same = lab[:, None] == lab[None, :]
+        A = sp.csr_matrix(((rng.random((n, n)) < np.where(same, 0.2, 0.0005))).astype(np.float32))
     A = sp.csr_matrix(((A + A.T) > 0).astype(np.float32))
     A.setdiag(1)
     Ac = sp.coo_matrix(A)
     row, col = torch.from_numpy(Ac.row.astype(np.int64)), torch.from_numpy(Ac.col.astype(np.int64))
-    part = partition.build_partition(row, col, torch.ones(row.numel()), n, torch.zeros(n, dtype=torch.int64), 0, 1)
+    band_min = partition.ORDER_BAND_MIN
+    partition.ORDER_BAND_MIN = 400                           # (a band per community at this size)
+    try:
+        part = partition.build_partition(row, col, torch.ones(row.numel()), n, torch.zeros(n, dtype=torch.int64), 0, 1)
+    finally:
+        partition.ORDER_BAND_MIN = band_min
     Kp = kernels.HipKernels(dev)
     saved = gat._T
     heads, d = 4, 64
@@ -213,6 +227,9 @@ def test_engine_with_and_without_blocks(dev):
             assert (eng.fwd_blocks is not None) == on
             if on:
                 assert eng.blocks_nnz > 0.2 * eng.nnz
+                if shape == "communities":
+                    assert part.local_bands is not None and part.local_bands.numel() >= 2
+                    assert int((eng.fwd_blocks.work_row0 % 512 != 0).sum()) > 0      # a block row that starts at a band, not on the global grid
             g = torch.Generator().manual_seed(5)
             Z = (torch.randn(n, F, generator=g) * 0.7).to(dev)
             s1, s2 = (torch.randn(n, heads, generator=g) * 1.5).to(dev), (torch.randn(n, heads, generator=g) * 1.5).to(dev)
