@@ -306,6 +306,8 @@ int pgcn_spmm_heads_forward2_f32(const int64_t *rowptr, const int32_t *col, cons
  *            nslots x (F + heads rounded up to 4) floats (V | C | 0): the two outputs of pgcn_spmm_heads_forward2_f32;
  *   backward (the transposed pattern: rowstat and t of the COLUMNS, s2 and Z of the ROWS, B = dOut):  partial_ws = nslots x
  *            (F + heads rounded up to 4) floats (dZ | ds2 | 0): the output row of pgcn_spmm_heads_grad_f32 (de is not available).
+ * A non-finite value in a listed panel of B reaches every row of the blocks over that panel (0 x inf inside the MFMA), also rows that do
+ * not reference it -- unlike the gather kernels and unlike pgcn_spmm_dense_bf16x3_f32, which redoes such pieces exactly.
  * GPU/PGAT.py:144-149 and its autograd.                                                                                        */
 int pgcn_gat_blocks_forward_f32(const int32_t *work, int64_t nwork, const int32_t *work_row0, const int32_t *blk_img,
                                 const uint32_t *bits, const int32_t *panel_list, int64_t npanels, const float *rowstat,
