@@ -247,6 +247,11 @@ def test_bench_gat_two_ranks_share_the_gpu():
     assert rec["config"]["partition"].startswith("random") and rec["exchange_rows_total"] > 0
     assert np.isfinite(rec["loss"]) and rec["value"] > 0
     assert rec["roofline"] and rec["roofline"]["frac"] > 0
+    # r06: the dense blocks of the attention pattern run on the split structures of a shard too, and the line says so
+    blocks = rec["config"]["blocks"]
+    assert blocks and blocks["entries_on_blocks"] > 0.2 and {"fwd_local", "bwd_local"} <= set(blocks["structures"])
+    split = rec["roofline"]["pass_split_ms"]
+    assert split["backward_blocks"] > 0 and split["forward_blocks"] > 0 and split["backward_gather"] > 0
 
 
 @pytest.mark.gpu
